@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- neighbor-group SpMM aggregation (GNNAdvisor `SAG`) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path -- `gnna_sag_f32` through the C ABI (prologue +
+aggregation kernel) -- over the whole synthetic graph, inputs already resident in HBM.
+Workload (BASELINE.json config 3, the one the metric is quoted on): a seeded Reddit-like
+power-law graph (N = 232,965, ~1.1e8 CSR entries, max degree ~21.6k, random node order),
+D = 64 fp32 features, partSize = 32.  N > 1 (launched by torch.distributed.run, one rank
+per GPU): weak scaling -- every rank owns a Reddit-sized block of destination rows whose
+sources are drawn from all ranks' nodes; each step all-gathers the feature blocks over
+RCCL/xGMI and aggregates locally (gnnadvisor_osdi21_amd/dist.py).
+
+Rank 0 prints ONE JSON line; `value` = total aggregated edges per second over all ranks.
+`roofline` prices the aggregation kernel with the gather model of SURVEY.md 8(d) /
+BASELINE.md 2: bytes = nnz*(4D+4) + N*(4D+4) + P*8 per launch, divided by the kernel's
+average duration measured with HIP events on the launch stream (gnna_profile_begin/end).
+`cpu_baseline` times the oracle (CPU port of the same computation) on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6290
+
+
+def gather_model_bytes(nnz: int, n_rows: int, parts: int, dim: int) -> int:
+    """per edge one fp32 source row + one int32 column id; per destination
+    row one fp32 output row + one row pointer; per neighbor-group partPtr + part2Node."""
+    return nnz * (4 * dim + 4) + n_rows * (4 * dim + 4) + parts * 8
+
+
+def compulsory_bytes(nnz: int, n_rows: int, n_src: int, dim: int) -> int:
+    return nnz * 4 + (n_rows + 1) * 4 + (n_rows + n_src) * dim * 4
+
+
+def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
+    """Oracle timed on the host: row-parallel fp32 CSR SpMM on all cores (value) and the
+    single-thread neighbor-group port on a bounded slice of groups."""
+    import numpy as np
+    import oracle
+    rp = g_cpu.row_pointers.numpy(); ci = g_cpu.column_index.numpy(); X = X_cpu.numpy()
+    nnz = int(ci.size)
+    cores = len(os.sched_getaffinity(0))
+    out = np.zeros_like(X)
+    oracle.csr_sag_omp(X, rp, ci, 0, 1024, out)  # page in / thread pool warm-up
+    reps, best = 0, float("inf")
+    t_all = time.perf_counter()
+    while reps < 3 or (time.perf_counter() - t_all < 8.0 and reps < 20):
+        t0 = time.perf_counter()
+        oracle.csr_sag_omp(X, rp, ci, out=out)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    # scalar port of the reference algorithm on ~1/16 of the groups
+    ppn, p2nn = pp.numpy(), p2n.numpy()
+    P = int(p2nn.size)
+    g_end = max(1, P // 16)
+    out1 = np.zeros_like(X)
+    t0 = time.perf_counter()
+    oracle.sag_groups_slice(X, ci, ppn, p2nn, 0, g_end, out1)
+    t1 = time.perf_counter() - t0
+    e1 = int(ppn[g_end] - ppn[0])
+    return {
+        "value": nnz / best, "unit": "edges/s", "cores": cores, "kind": "port",
+        "sample": f"full graph ({nnz} edges, D={dim}), best of {reps} passes of the OpenMP row-parallel "
+                  f"fp32 CSR SpMM in oracle/gnna_oracle.c",
+        "ms": best * 1e3,
+        "gather_model_GBs": gather_model_bytes(nnz, len(rp) - 1, P, dim) / best / 1e9,
+        "single_thread": {"value": e1 / t1, "unit": "edges/s", "cores": 1,
+                          "sample": f"first {g_end} neighbor-groups ({e1} edges), scalar neighbor-group port"},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--partSize", type=int, default=32)
+    ap.add_argument("--config", default="reddit-like")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
+    ap.add_argument("--locality", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from gnnadvisor_osdi21_amd import _lib, graph
+    from gnnadvisor_osdi21_amd.dist import ShardedAggregator
+    _lib.load()
+
+    cfg = graph.CONFIGS[args.config]
+    D, ps = args.dim, args.partSize
+    n_local = max(2, int(cfg["num_nodes"] * args.scale))
+    e_target = int(cfg["num_edges"] * args.scale)
+
+    # ---- build the workload on the GPU -------------------------------------------------
+    if world == 1:
+        g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
+        rp_cpu = g.row_pointers.cpu()
+        pp, p2n = _lib.build_part(ps, rp_cpu)
+        ppd, p2nd = pp.to(dev), p2n.to(dev)
+        nnz_local, n_src = g.nnz, g.num_nodes
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        X = torch.randn(n_local, D, device=dev, generator=gen)
+        out = torch.empty_like(X)
+
+        def step():
+            _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
+        P = int(p2n.numel())
+    else:
+        n_global = n_local * world
+        rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
+                                      seed=cfg["seed"] * 1000 + rank, device=dev)
+        bounds = [i * n_local for i in range(world + 1)]
+        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev)
+        nnz_local, n_src = agg.nnz_local, n_global
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        X = torch.randn(n_local, D, device=dev, generator=gen)
+        out = torch.empty_like(X)
+
+        def step():
+            agg.sag(X, out=out)
+        P = int(agg.part2Node.numel())
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    _lib.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_end()
+
+    # max over ranks, total edges over ranks
+    stats = torch.tensor([elapsed, float(nnz_local), prof["main_ms"], float(P)], dtype=torch.float64, device=dev)
+    if world > 1:
+        mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, total_edges, kern_ms = float(mx[0]), float(sm[1]), float(mx[2])
+    else:
+        total_edges, kern_ms = float(nnz_local), prof["main_ms"]
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        value = total_edges * args.steps / elapsed
+        alg_bytes = gather_model_bytes(nnz_local, n_local, P, D)
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        rec = {
+            "metric": "aggregated edges/sec, GCN sum-aggregation SpMM (SAG) hidden=64",
+            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config} power-law graph, random node order"
+                                   + (f", locality={args.locality}" if args.locality else "")
+                                   + (f", scale={args.scale}" if args.scale != 1.0 else ""),
+                       "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
+                       "num_parts_per_gpu": P, "source_nodes": n_src,
+                       "parallelism": "single GPU" if world == 1 else f"dst-range shards x{world} + RCCL all-gather",
+                       "tuning": _lib.get_tuning()},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "agg_kernel<4,16,SAG>", "kernel_ms": kern_ms,
+                         "prologue_ms": prof["prologue_ms"], "algorithmic_bytes": alg_bytes,
+                         "model": "gather: nnz*(4D+4) + N*(4D+4) + P*8",
+                         "compulsory_GBs": compulsory_bytes(nnz_local, n_local, n_src, D) / (kern_ms * 1e-3) / 1e9
+                         if kern_ms > 0 else 0.0,
+                         "kernel_edges_per_s": nnz_local / (kern_ms * 1e-3) if kern_ms > 0 else 0.0},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), X.cpu(), pp, p2n, D)
+        print(json.dumps(rec), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

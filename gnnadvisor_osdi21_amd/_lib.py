@@ -1,0 +1,197 @@
+"""ctypes binding of the C ABI in ``include/gnna.h`` (``csrc/libgnna.so``).
+
+PyTorch is used here only as the owner of device memory and streams: every call hands
+raw ``data_ptr()`` addresses and the current HIP stream handle to the library.  There
+is no CPU fallback -- if the shared library is missing the import of the product path
+fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgnna.so")
+
+GNNA_OK = 0
+
+
+class GnnaError(RuntimeError):
+    pass
+
+
+class Tuning(ctypes.Structure):
+    _fields_ = [("groups_per_chunk", ctypes.c_int), ("loads_in_flight", ctypes.c_int),
+                ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
+                ("trust_canonical", ctypes.c_int)]
+
+
+_lib = None
+
+_AGG_COMMON = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]  # input, row_pointers, column_index
+_TAIL = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,        # part_pointers, part2Node, out
+         ctypes.c_int64, ctypes.c_int, ctypes.c_int64,             # num_nodes, dim, num_parts
+         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]  # partSize, dimWorker, warpPerBlock, stream
+
+EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_part_i32",
+           "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
+           "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32")
+
+
+def load() -> ctypes.CDLL:
+    """dlopen libgnna.so (built by ``python -m gnnadvisor_osdi21_amd.build``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -m gnnadvisor_osdi21_amd.build`). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    L.gnna_version.restype = ctypes.c_int
+    L.gnna_last_error.restype = ctypes.c_char_p
+    L.gnna_count_parts.restype = ctypes.c_int64
+    L.gnna_count_parts.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
+    L.gnna_build_part_i32.restype = ctypes.c_int
+    L.gnna_build_part_i32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]
+    L.gnna_sag_f32.restype = ctypes.c_int
+    L.gnna_sag_f32.argtypes = _AGG_COMMON + [ctypes.c_void_p] + _TAIL
+    L.gnna_agg_gcn_f32.restype = ctypes.c_int
+    L.gnna_agg_gcn_f32.argtypes = _AGG_COMMON + [ctypes.c_void_p] + _TAIL
+    L.gnna_agg_gin_f32.restype = ctypes.c_int
+    L.gnna_agg_gin_f32.argtypes = _AGG_COMMON + [ctypes.c_float] + _TAIL
+    L.gnna_set_tuning.restype = None
+    L.gnna_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    L.gnna_get_tuning.restype = None
+    L.gnna_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
+    L.gnna_agg_rect_f32.restype = ctypes.c_int
+    L.gnna_agg_rect_f32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                    ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    L.gnna_profile_begin.restype = ctypes.c_int
+    L.gnna_profile_begin.argtypes = [ctypes.c_int]
+    L.gnna_profile_end.restype = ctypes.c_int
+    L.gnna_profile_end.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double),
+                                   ctypes.POINTER(ctypes.c_int)]
+    _lib = L
+    return L
+
+
+def _check(rc: int) -> None:
+    if rc != GNNA_OK:
+        raise GnnaError(f"libgnna error {rc}: {load().gnna_last_error().decode()}")
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
+               trust_canonical=-1) -> None:
+    t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical)
+    load().gnna_set_tuning(ctypes.byref(t))
+
+
+def reset_tuning() -> None:
+    load().gnna_set_tuning(None)
+
+
+def get_tuning() -> dict:
+    t = Tuning()
+    load().gnna_get_tuning(ctypes.byref(t))
+    return {name: getattr(t, name) for name, _ in Tuning._fields_}
+
+
+def profile_begin(max_calls: int) -> None:
+    _check(load().gnna_profile_begin(int(max_calls)))
+
+
+def profile_end() -> dict:
+    """-> {main_ms, prologue_ms, calls}: HIP-event averages of the two kernels per call."""
+    a, b, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    _check(load().gnna_profile_end(ctypes.byref(a), ctypes.byref(b), ctypes.byref(n)))
+    return dict(main_ms=a.value, prologue_ms=b.value, calls=n.value)
+
+
+def count_parts(partSize: int, indptr: torch.Tensor) -> int:
+    assert indptr.dtype == torch.int32 and not indptr.is_cuda and indptr.is_contiguous()
+    n = load().gnna_count_parts(int(partSize), indptr.data_ptr(), indptr.numel() - 1)
+    if n < 0:
+        _check(int(n))
+    return int(n)
+
+
+def build_part(partSize: int, indptr: torch.Tensor):
+    """C-ABI partitioner -> (partPtr int32 [P+1], part2Node int32 [P]) on the CPU."""
+    indptr = indptr.contiguous()
+    P = count_parts(partSize, indptr)
+    pp = torch.empty(P + 1, dtype=torch.int32)
+    p2n = torch.empty(P, dtype=torch.int32)
+    _check(load().gnna_build_part_i32(int(partSize), indptr.data_ptr(), indptr.numel() - 1,
+                                      pp.data_ptr(), p2n.data_ptr(), P))
+    return pp, p2n
+
+
+def _agg(fn, X, row_pointers, column_index, extra, part_pointers, part2Node, partSize, dimWorker,
+         warpPerBlock, out):
+    if not X.is_cuda:
+        raise GnnaError("aggregation needs device tensors: there is no CPU path in libgnna")
+    assert X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2
+    for t in (column_index, part_pointers, part2Node):
+        assert t.dtype == torch.int32 and t.is_contiguous() and t.device == X.device
+    if out is None:
+        out = torch.empty_like(X)
+    with torch.cuda.device(X.device):
+        _check(fn(X.data_ptr(), _ptr(row_pointers), column_index.data_ptr(), extra,
+                  part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
+                  X.shape[0], X.shape[1], part2Node.numel(),
+                  int(partSize), int(dimWorker), int(warpPerBlock), _stream(X.device)))
+    return out
+
+
+def sag(X, row_pointers, column_index, degrees, part_pointers, part2Node, partSize=32, dimWorker=32,
+        warpPerBlock=4, out=None):
+    return _agg(load().gnna_sag_f32, X, row_pointers, column_index, _ptr(degrees), part_pointers,
+                part2Node, partSize, dimWorker, warpPerBlock, out)
+
+
+def agg_gcn(X, row_pointers, column_index, degrees, part_pointers, part2Node, partSize=32,
+            dimWorker=32, warpPerBlock=4, out=None):
+    assert degrees.dtype == torch.float32 and degrees.device == X.device
+    return _agg(load().gnna_agg_gcn_f32, X, row_pointers, column_index, degrees.data_ptr(),
+                part_pointers, part2Node, partSize, dimWorker, warpPerBlock, out)
+
+
+def agg_gin(X, row_pointers, column_index, epsilon, part_pointers, part2Node, partSize=32,
+            dimWorker=32, warpPerBlock=4, out=None):
+    return _agg(load().gnna_agg_gin_f32, X, row_pointers, column_index, ctypes.c_float(epsilon),
+                part_pointers, part2Node, partSize, dimWorker, warpPerBlock, out)
+
+
+MODE_SAG, MODE_GCN, MODE_GIN = 0, 1, 2
+
+
+def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, partSize=32,
+             degrees_out=None, degrees_in=None, epsilon=1.0, out=None):
+    """Destination-shard aggregation: X is [num_in_rows, dim] (all sources), out is
+    [num_out_rows, dim]; column_index indexes X."""
+    if not X.is_cuda:
+        raise GnnaError("aggregation needs device tensors: there is no CPU path in libgnna")
+    assert X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2
+    if out is None:
+        out = torch.empty(num_out_rows, X.shape[1], dtype=torch.float32, device=X.device)
+    with torch.cuda.device(X.device):
+        _check(load().gnna_agg_rect_f32(int(mode), X.data_ptr(), X.shape[0], column_index.data_ptr(),
+                                        _ptr(degrees_out), _ptr(degrees_in), float(epsilon),
+                                        part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
+                                        int(num_out_rows), X.shape[1], part2Node.numel(), int(partSize),
+                                        _stream(X.device)))
+    return out

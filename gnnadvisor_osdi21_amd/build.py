@@ -1,0 +1,84 @@
+"""In-tree build of the native code for gfx950 (MI355X).
+
+    python -m gnnadvisor_osdi21_amd.build [--force]
+
+Produces, next to the sources (git-ignored, shipped to the GPU box by gpurun):
+
+* ``csrc/libgnna.so``  -- HIP kernels + C ABI (include/gnna.h); hipcc --offload-arch=gfx950.
+  No torch dependency.
+* ``GNNAdvisor.so``     -- the pybind11/torch extension module named ``GNNAdvisor`` (the
+  reference's module name, GNNAdvisor/GNNConv/setup.py:5-8), host-only C++ that links
+  libgnna.so.  Replaces the reference's ``CUDAExtension`` build script (setup.py:4-17).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+import sysconfig
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(CSRC, "libgnna.so")
+EXT = os.path.join(PKG, "GNNAdvisor.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+LIB_SOURCES = [os.path.join(CSRC, "gnna_kernels.hip"), os.path.join(CSRC, "gnna_host.cpp")]
+LIB_DEPS = LIB_SOURCES + [os.path.join(CSRC, "gnna_internal.h"), os.path.join(INCLUDE, "gnna.h")]
+EXT_SOURCES = [os.path.join(CSRC, "gnna_torch.cpp")]
+EXT_DEPS = EXT_SOURCES + [os.path.join(INCLUDE, "gnna.h")]
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    if force or _stale(LIB, LIB_DEPS):
+        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-munsafe-fp-atomics", "-ffp-contract=off", "-fvisibility=hidden",
+               "-I" + INCLUDE, "-I" + CSRC, *LIB_SOURCES, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_ext(force: bool = False, verbose: bool = False) -> str:
+    build_lib(force, verbose)
+    if force or _stale(EXT, EXT_DEPS + [LIB]):
+        import pybind11
+        import torch
+        tdir = os.path.dirname(torch.__file__)
+        cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-w",
+               "-DTORCH_EXTENSION_NAME=GNNAdvisor", "-DTORCH_API_INCLUDE_EXTENSION_H",
+               "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__",
+               f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
+               "-I" + INCLUDE,
+               "-I" + os.path.join(tdir, "include"),
+               "-I" + os.path.join(tdir, "include", "torch", "csrc", "api", "include"),
+               "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+               "-I/opt/rocm/include",
+               "-x", "c++", *EXT_SOURCES, "-o", EXT,
+               "-L" + CSRC, "-lgnna", "-Wl,-rpath,$ORIGIN/csrc",
+               "-L" + os.path.join(tdir, "lib"), "-lc10", "-lc10_hip", "-ltorch", "-ltorch_cpu",
+               "-ltorch_hip", "-ltorch_python", "-Wl,-rpath," + os.path.join(tdir, "lib")]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return EXT
+
+
+def build_all(force: bool = False, verbose: bool = False) -> None:
+    build_ext(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)
+    print("built", LIB, "and", EXT)

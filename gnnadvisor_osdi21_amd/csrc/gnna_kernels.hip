@@ -1,0 +1,580 @@
+// gnna_kernels.hip -- CDNA4 (gfx950) neighbor-group aggregation kernels + C-ABI launchers.
+//
+// Replaces the five CUDA kernels of the reference (GNNAdvisor/GNNConv/GNNAdvisor_kernel.cu:
+// SAG :186-259, GCN fwd :324-415, GCN bwd :478-552, GIN fwd :620-689, GIN bwd :749-814) with
+// one templated HIP kernel.  Not a translation: see DESIGN.md "Kernel".
+//
+// Shape of the computation (all three modes):
+//   out[part2Node[p], :] += sum_{e in [partPtr[p], partPtr[p+1])} coef * X[colidx[e], :]
+//
+// CDNA4 mapping
+//   * a 64-lane wavefront owns a *chunk* of G consecutive neighbor-groups.  Groups of one
+//     destination row are adjacent (build_part emits them consecutively), so a run of
+//     same-row groups is one contiguous edge segment that the wave reduces in registers;
+//     only a row that continues into a neighbouring chunk needs atomics.
+//   * lanes are laid out (slot, c): c = lane % LPR addresses a VEC-float piece of the
+//     feature row, slot = lane / LPR addresses one of RPI = 64/LPR neighbor rows, so one
+//     wave-wide global_load_dwordx4 fetches RPI complete, fully coalesced rows (D=64:
+//     4 rows = 1 KiB per instruction).  U such loads are issued back-to-back before the
+//     first add (memory-level parallelism; the kernel is gather-bandwidth bound).
+//   * column ids are fetched 64 at a time with one coalesced non-temporal load and
+//     handed to the slots with ds_bpermute; partial rows live in VGPRs (the reference's
+//     shared-memory read-modify-write chain, .cu:245-249, is what it is bound by).
+//   * slots are folded once per destination row with v_permlane16_swap /
+//     v_permlane32_swap (strides 16/32) and ds_bpermute (strides < 16).
+//   * flush: plain (non-temporal) vector store when the row is wholly owned by the wave,
+//     hardware global_atomic_add_f32 only for rows shared with a neighbouring chunk.
+//   * a prologue kernel zero-fills `out` and checks that the partition is canonical
+//     (part2Node and partPtr non-decreasing); if it is not, every group is flushed with
+//     atomics, which is correct for any partition.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "gnna.h"
+#include "gnna_internal.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;
+
+enum { MODE_SAG = 0, MODE_GCN = 1, MODE_GIN = 2 };
+
+template <int VEC> struct VecOf;
+template <> struct VecOf<1> { typedef float T; };
+template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
+
+struct AggParams {
+    const float *X;
+    const int32_t *col;
+    const float *deg_row;  // per destination row (GCN)
+    const float *deg_col;  // per source row (GCN)
+    const int32_t *pp;
+    const int32_t *p2n;
+    float *Y;
+    int64_t P;           // number of neighbor-groups
+    int64_t num_chunks;  // ceil(P / G)
+    int64_t num_items;   // ceil(num_chunks / waves per block)
+    int64_t items_per_xcd;
+    const int32_t *flag; // *flag == seq  <=>  partition is NOT canonical
+    int32_t seq;
+    int32_t trust;
+    int32_t D;
+    int32_t G;
+    int32_t xcd_remap;
+    float eps;
+};
+
+// ---- wave-level helpers ----------------------------------------------------------------
+
+__device__ __forceinline__ float fold_xor16(float v)
+{
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float fold_xor32(float v)
+{
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Sum over the 64/LPR lanes that share lane % LPR; result in every lane.
+template <int LPR>
+__device__ __forceinline__ float slot_reduce(float v)
+{
+    if constexpr (LPR <= 4) v += __shfl_xor(v, 4);
+    if constexpr (LPR <= 8) v += __shfl_xor(v, 8);
+    if constexpr (LPR <= 16) v = fold_xor16(v);
+    if constexpr (LPR <= 32) v = fold_xor32(v);
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ typename VecOf<VEC>::T vzero()
+{
+    typename VecOf<VEC>::T z;
+    if constexpr (VEC == 1) z = 0.f; else z = (typename VecOf<VEC>::T)(0.f);
+    return z;
+}
+
+template <int VEC>
+__device__ __forceinline__ float vget(const typename VecOf<VEC>::T &v, int k)
+{
+    if constexpr (VEC == 1) return v; else return v[k];
+}
+
+template <int VEC>
+__device__ __forceinline__ void vset(typename VecOf<VEC>::T &v, int k, float x)
+{
+    if constexpr (VEC == 1) v = x; else v[k] = x;
+}
+
+// ---- prologue: zero-fill + partition validation ------------------------------------------
+
+__global__ void __launch_bounds__(kBlock)
+prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restrict__ p2n,
+                const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+        const size_t n4 = n_floats >> 2;
+        f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
+        const f32x4 z = (f32x4)(0.f);
+        for (size_t i = tid; i < n4; i += nthreads) Y4[i] = z;
+        for (size_t i = (n4 << 2) + tid; i < n_floats; i += nthreads) Y[i] = 0.f;
+    } else {
+        for (size_t i = tid; i < n_floats; i += nthreads) Y[i] = 0.f;
+    }
+    if (validate) {
+        bool bad = false;
+        for (int64_t g = (int64_t)tid; g < P; g += (int64_t)nthreads) {
+            if (pp[g + 1] < pp[g]) bad = true;
+            if (g + 1 < P && p2n[g + 1] < p2n[g]) bad = true;
+        }
+        if (bad) *flag = seq;  // every writer stores the same value
+    }
+}
+
+// ---- main kernel --------------------------------------------------------------------------
+
+template <int VEC, int LPR, int MODE, int U, bool WIDE>
+__global__ void __launch_bounds__(kBlock)
+agg_kernel(const AggParams p)
+{
+    typedef typename VecOf<VEC>::T VT;
+    // byte offsets into X: 32-bit (SGPR base + VGPR offset addressing) unless X exceeds 4 GiB
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
+    constexpr int RPI = kWave / LPR;  // neighbor rows per wave-wide load
+    static_assert(U * RPI <= kWave, "a batch must fit one 64-edge id tile");
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int slot = lane / LPR;
+    const int c = lane % LPR;
+    const int D = p.D;
+    const int G = p.G;
+    const bool canonical = p.trust || (*p.flag != p.seq);
+    const char *xbase = reinterpret_cast<const char *>(p.X);
+    const OffT row_bytes = (OffT)D * (OffT)sizeof(float);
+
+    // item = 4 consecutive chunks handled by the 4 waves of one block.
+    const int64_t item_span = p.xcd_remap ? p.items_per_xcd * kXcds : p.num_items;
+    for (int64_t it = blockIdx.x; it < item_span; it += gridDim.x) {
+        int64_t item = it;
+        if (p.xcd_remap) {
+            // blocks land on XCD (blockIdx % 8): give each XCD one contiguous range of items
+            item = (it % kXcds) * p.items_per_xcd + it / kXcds;
+            if (item >= p.num_items) continue;
+        }
+        const int64_t chunk = item * kWavesPerBlock + wib;
+        if (chunk >= p.num_chunks) continue;
+        const int64_t g0 = chunk * G;
+        const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
+
+        // chunk metadata: one coalesced load each (G <= 63)
+        const int my_row = lane < ng ? p.p2n[g0 + lane] : -1;
+        const int my_pp = lane <= ng ? p.pp[g0 + lane] : 0;
+        int prev_row = -1, next_row = -1;
+        if (g0 > 0) prev_row = p.p2n[g0 - 1];
+        if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
+
+        int up_row = __shfl_up(my_row, 1);
+        bool is_start = lane < ng && (lane == 0 || my_row != up_row || !canonical);
+        unsigned long long starts = __ballot(is_start);
+
+        while (starts) {
+            const int js = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const int je = starts ? __builtin_ctzll(starts) : ng;
+            const int row = __builtin_amdgcn_readlane(my_row, js);
+            const int sb = __builtin_amdgcn_readlane(my_pp, js);
+            const int se = __builtin_amdgcn_readlane(my_pp, je);
+            const bool shared = (js == 0 && prev_row == row) || (je == ng && next_row == row);
+            const bool use_atomic = shared || !canonical;
+
+            float row_deg = 1.f;
+            if constexpr (MODE == MODE_GCN) row_deg = p.deg_row[row];
+
+            for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
+                const int dcol = d0 + c * VEC;
+                const bool cvalid = dcol < D;
+                // lanes past the end of a ragged row re-read piece 0 (same cache line, never stored)
+                const OffT col_off = (OffT)(cvalid ? dcol : d0) * (OffT)sizeof(float);
+                VT acc = vzero<VEC>();
+
+                int id_next = 0;
+                if (sb + lane < se) id_next = __builtin_nontemporal_load(p.col + sb + lane);
+                for (int t = sb; t < se; t += kWave) {
+                    const int nv = se - t < kWave ? se - t : kWave;
+                    const int id = id_next;
+                    // software prefetch of the next 64 column ids
+                    if (t + kWave + lane < se) id_next = __builtin_nontemporal_load(p.col + t + kWave + lane);
+                    float dgn = 0.f;
+                    if constexpr (MODE == MODE_GCN) {
+                        if (lane < nv) dgn = p.deg_col[id];
+                    }
+#pragma unroll 1
+                    for (int b = 0; b < nv; b += U * RPI) {
+                        VT v[U];
+                        int nid[U];
+                        float cf[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) nid[u] = __shfl(id, b + u * RPI + slot);
+                        if (b + U * RPI <= nv) {
+                            // full batch: U unpredicated wave-wide row loads back to back
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+                                v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)nid[u] * row_bytes + col_off);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                v[u] = vzero<VEC>();
+                                if (b + u * RPI + slot < nv)
+                                    v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)nid[u] * row_bytes + col_off);
+                            }
+                        }
+                        if constexpr (MODE == MODE_GCN) {
+#pragma unroll
+                            for (int u = 0; u < U; u++) cf[u] = row_deg * __shfl(dgn, b + u * RPI + slot);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            if constexpr (MODE == MODE_GCN) {
+                                // reference rounds coef*x and the accumulate separately
+                                // (__fmaf_rn(c, x, 0) then +=, .cu:405); built with -ffp-contract=off
+                                VT tmp = v[u] * cf[u];
+                                acc += tmp;
+                            } else {
+                                acc += v[u];
+                            }
+                        }
+                    }
+                }
+
+                // fold the RPI slots; every slot then holds the row's partial sum
+#pragma unroll
+                for (int k = 0; k < VEC; k++) {
+                    float s = slot_reduce<LPR>(vget<VEC>(acc, k));
+                    if constexpr (MODE == MODE_GIN) s *= p.eps;
+                    vset<VEC>(acc, k, s);
+                }
+
+                if (slot == 0 && cvalid) {
+                    float *dst = p.Y + (size_t)row * D + dcol;
+                    if (!use_atomic) {
+                        __builtin_nontemporal_store(acc, reinterpret_cast<VT *>(dst));
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < VEC; k++) unsafeAtomicAdd(dst + k, vget<VEC>(acc, k));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------
+
+struct DeviceState {
+    bool init = false;
+    int num_cus = 256;
+    int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
+};
+constexpr int kFlagSlots = 1024;
+constexpr int kMaxDevices = 64;
+DeviceState g_dev[kMaxDevices];
+std::mutex g_dev_mutex;
+std::atomic<uint32_t> g_seq{0};
+
+int get_device_state(DeviceState **out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+    if (dev < 0 || dev >= kMaxDevices) return gnna::fail(GNNA_ERR_UNSUPPORTED, "device ordinal %d", dev);
+    DeviceState &s = g_dev[dev];
+    if (!s.init) {
+        std::lock_guard<std::mutex> lock(g_dev_mutex);
+        if (!s.init) {
+            hipDeviceProp_t prop;
+            e = hipGetDeviceProperties(&prop, dev);
+            if (e != hipSuccess)
+                return gnna::fail(GNNA_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+            s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            e = hipMalloc(reinterpret_cast<void **>(&s.flags), kFlagSlots * sizeof(int32_t));
+            if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMalloc(flags): %s", hipGetErrorString(e));
+            e = hipMemset(s.flags, 0, kFlagSlots * sizeof(int32_t));
+            if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMemset(flags): %s", hipGetErrorString(e));
+            s.init = true;
+        }
+    }
+    *out = &s;
+    return GNNA_OK;
+}
+
+// ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------
+struct ProfileState {
+    bool on = false;
+    int max_calls = 0;
+    int calls = 0;
+    std::vector<hipEvent_t> ev;  // 3 per call: before prologue, between, after main
+};
+ProfileState g_prof;
+std::mutex g_prof_mutex;
+
+hipEvent_t prof_event(int call, int which)
+{
+    return g_prof.ev[(size_t)call * 3 + which];
+}
+
+typedef void (*AggKernel)(const AggParams);
+
+template <int VEC, int LPR, int MODE, int U>
+AggKernel pick_wide(bool wide)
+{
+    if (wide) return agg_kernel<VEC, LPR, MODE, U, true>;
+    return agg_kernel<VEC, LPR, MODE, U, false>;
+}
+
+template <int VEC, int LPR, int MODE>
+AggKernel pick_u(int u, bool wide)
+{
+    constexpr int RPI = kWave / LPR;
+    constexpr int UMAX = kWave / RPI;  // == LPR
+    if constexpr (VEC == 4 && UMAX >= 16) {
+        if (u >= 16) return pick_wide<VEC, LPR, MODE, 16>(wide);
+    }
+    if constexpr (UMAX >= 8) {
+        if (u >= 8) return pick_wide<VEC, LPR, MODE, 8>(wide);
+    }
+    if constexpr (VEC == 4 || UMAX < 8) {
+        return pick_wide<VEC, LPR, MODE, 4>(wide);
+    } else {
+        return pick_wide<VEC, LPR, MODE, 8>(wide);
+    }
+}
+
+template <int VEC, int MODE>
+AggKernel pick_lpr(int lpr, int u, bool wide)
+{
+    switch (lpr) {
+    case 4: return pick_u<VEC, 4, MODE>(u, wide);
+    case 8: return pick_u<VEC, 8, MODE>(u, wide);
+    case 16: return pick_u<VEC, 16, MODE>(u, wide);
+    case 32: return pick_u<VEC, 32, MODE>(u, wide);
+    default: return pick_u<VEC, 64, MODE>(u, wide);
+    }
+}
+
+template <int MODE>
+AggKernel pick_vec(int vec, int lpr, int u, bool wide)
+{
+    switch (vec) {
+    case 4: return pick_lpr<4, MODE>(lpr, u, wide);
+    case 2: return pick_lpr<2, MODE>(lpr, u, wide);
+    default: return pick_lpr<1, MODE>(lpr, u, wide);
+    }
+}
+
+AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide)
+{
+    switch (mode) {
+    case MODE_GCN: return pick_vec<MODE_GCN>(vec, lpr, u, wide);
+    case MODE_GIN: return pick_vec<MODE_GIN>(vec, lpr, u, wide);
+    default: return pick_vec<MODE_SAG>(vec, lpr, u, wide);
+    }
+}
+
+int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
+               const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
+               const int32_t *part2Node, float *out, int64_t num_nodes, int dim, int64_t num_parts,
+               int partSize, int dimWorker, int warpPerBlock, void *stream_v)
+{
+    if (num_nodes < 0 || dim < 0 || num_parts < 0 || num_in_rows < 0)
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "negative size (num_nodes=%lld dim=%d num_parts=%lld)",
+                          (long long)num_nodes, dim, (long long)num_parts);
+    if (partSize <= 0 || dimWorker <= 0 || warpPerBlock <= 0)
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT,
+                          "partSize, dimWorker and warpPerBlock must be positive (got %d, %d, %d)",
+                          partSize, dimWorker, warpPerBlock);
+    if (num_nodes == 0 || dim == 0) return GNNA_OK;
+    if (!out || !input) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null feature pointer");
+    if (num_parts > 0 && (!column_index || !part_pointers || !part2Node))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null index pointer");
+    if (mode == MODE_GCN && (!degrees || !degrees_in))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null degrees pointer");
+    if (out == input) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "out must not alias input");
+
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    DeviceState *ds = nullptr;
+    int rc = get_device_state(&ds);
+    if (rc != GNNA_OK) return rc;
+
+    gnna_tuning tune;
+    gnna_get_tuning(&tune);
+
+    const uint32_t seq_u = g_seq.fetch_add(1) + 1;
+    const int32_t seq = (int32_t)(seq_u & 0x7fffffff) | 1;  // never 0
+    int32_t *flag = ds->flags + (seq_u % kFlagSlots);
+
+    int prof_call = -1;
+    if (g_prof.on) {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (g_prof.on && g_prof.calls < g_prof.max_calls && num_parts > 0) prof_call = g_prof.calls++;
+    }
+    if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 0), stream);
+
+    // prologue: zero-fill + validation
+    const size_t n_floats = (size_t)num_nodes * (size_t)dim;
+    {
+        size_t work = std::max(n_floats / 4, (size_t)num_parts);
+        int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);
+        blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
+        hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
+                           part2Node, part_pointers, num_parts, flag, seq,
+                           (num_parts > 0 && !tune.trust_canonical) ? 1 : 0);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
+    }
+    if (num_parts == 0) return GNNA_OK;
+    if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 1), stream);
+
+    // vector width / lane layout
+    const uintptr_t align_bits = reinterpret_cast<uintptr_t>(input) | reinterpret_cast<uintptr_t>(out);
+    int vec = 1;
+    if (dim % 4 == 0 && (align_bits & 15) == 0) vec = 4;
+    else if (dim % 2 == 0 && (align_bits & 7) == 0) vec = 2;
+    int lpr = 4;
+    while (lpr < 64 && lpr * vec < dim) lpr <<= 1;
+
+    AggParams p;
+    p.X = input; p.col = column_index; p.deg_row = degrees; p.deg_col = degrees_in; p.pp = part_pointers; p.p2n = part2Node;
+    p.Y = out; p.P = num_parts; p.D = dim; p.eps = epsilon;
+    p.G = std::max(1, std::min(tune.groups_per_chunk, 63));
+    p.num_chunks = (num_parts + p.G - 1) / p.G;
+    p.num_items = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    p.items_per_xcd = (p.num_items + kXcds - 1) / kXcds;
+    p.xcd_remap = tune.xcd_remap ? 1 : 0;
+    p.flag = flag; p.seq = seq; p.trust = tune.trust_canonical ? 1 : 0;
+
+    int64_t span = p.xcd_remap ? p.items_per_xcd * kXcds : p.num_items;
+    int64_t grid = span;
+    if (tune.blocks_per_cu > 0) grid = std::min<int64_t>(grid, (int64_t)tune.blocks_per_cu * ds->num_cus);
+    grid = std::max<int64_t>(1, std::min<int64_t>(grid, 0x7fffffff));
+    if (p.xcd_remap && grid < span) grid = std::max<int64_t>(kXcds, grid / kXcds * kXcds);  // keep it % 8 stable
+
+    const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
+    AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
+    if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 2), stream);
+    return GNNA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int gnna_sag_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
+                 const float *degrees, const int32_t *part_pointers, const int32_t *part2Node,
+                 float *out, int64_t num_nodes, int dim, int64_t num_parts,
+                 int partSize, int dimWorker, int warpPerBlock, void *stream)
+{
+    (void)row_pointers; (void)degrees;  // unused by the reference kernel as well (.cu:186-259)
+    return launch_agg(MODE_SAG, input, num_nodes, column_index, nullptr, nullptr, 1.f, part_pointers,
+                      part2Node, out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream);
+}
+
+int gnna_agg_gcn_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
+                     const float *degrees, const int32_t *part_pointers, const int32_t *part2Node,
+                     float *out, int64_t num_nodes, int dim, int64_t num_parts,
+                     int partSize, int dimWorker, int warpPerBlock, void *stream)
+{
+    (void)row_pointers;
+    return launch_agg(MODE_GCN, input, num_nodes, column_index, degrees, degrees, 1.f, part_pointers,
+                      part2Node, out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream);
+}
+
+int gnna_agg_gin_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
+                     float epsilon, const int32_t *part_pointers, const int32_t *part2Node,
+                     float *out, int64_t num_nodes, int dim, int64_t num_parts,
+                     int partSize, int dimWorker, int warpPerBlock, void *stream)
+{
+    (void)row_pointers;
+    return launch_agg(MODE_GIN, input, num_nodes, column_index, nullptr, nullptr, epsilon, part_pointers,
+                      part2Node, out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream);
+}
+
+int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
+                      const float *degrees_out, const float *degrees_in, float epsilon,
+                      const int32_t *part_pointers, const int32_t *part2Node, float *out,
+                      int64_t num_out_rows, int dim, int64_t num_parts, int partSize, void *stream)
+{
+    if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
+                      part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream);
+}
+
+int gnna_profile_begin(int max_calls)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (g_prof.on) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "profiling already active");
+    if (max_calls <= 0 || max_calls > (1 << 20))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "max_calls out of range: %d", max_calls);
+    g_prof.ev.resize((size_t)max_calls * 3);
+    for (auto &e : g_prof.ev) {
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc));
+    }
+    g_prof.max_calls = max_calls;
+    g_prof.calls = 0;
+    g_prof.on = true;
+    return GNNA_OK;
+}
+
+int gnna_profile_end(double *avg_main_ms, double *avg_prologue_ms, int *num_calls)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (!g_prof.on) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "profiling not active");
+    g_prof.on = false;
+    double main_ms = 0, pro_ms = 0;
+    int rc_out = GNNA_OK;
+    for (int c = 0; c < g_prof.calls; c++) {
+        hipError_t rc = hipEventSynchronize(prof_event(c, 2));
+        float a = 0, b = 0;
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&a, prof_event(c, 0), prof_event(c, 1));
+        if (rc == hipSuccess) rc = hipEventElapsedTime(&b, prof_event(c, 1), prof_event(c, 2));
+        if (rc != hipSuccess) { rc_out = gnna::fail(GNNA_ERR_HIP, "profile events: %s", hipGetErrorString(rc)); break; }
+        pro_ms += a;
+        main_ms += b;
+    }
+    const int n = g_prof.calls;
+    for (auto &e : g_prof.ev) hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.calls = 0;
+    if (num_calls) *num_calls = n;
+    if (avg_main_ms) *avg_main_ms = n ? main_ms / n : 0.0;
+    if (avg_prologue_ms) *avg_prologue_ms = n ? pro_ms / n : 0.0;
+    return rc_out;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"

@@ -1,0 +1,159 @@
+"""Multi-GPU aggregation: destination-range sharding + RCCL all-gather of source features.
+
+The reference is single-GPU (no distributed code at all); this module is
+the MI355X design for BASELINE.json config 5.  One process per GPU (torch.distributed,
+backend "nccl" == RCCL over xGMI):
+
+* destination rows (CSR rows) are split into ``world`` contiguous blocks; rank r owns the
+  CSR rows of block r, its block of X, and writes only its block of Y -- no collective on
+  the outputs, no cross-GPU atomics.
+* before an aggregation every rank needs the source rows it references: one
+  ``all_gather_into_tensor`` of the [rows_per_rank, D] fp32 blocks (a single large
+  collective; on the fully connected 8-GPU xGMI node every block moves one hop).
+* blocks are padded to a common ``rows_per_rank`` so the gather lands directly in the
+  layout the kernel reads; column ids are remapped once, at construction, into that
+  padded global numbering -- no per-step unpadding copy.
+
+``aggregate_fn`` is the local kernel (defaults to the HIP path through the C ABI); the
+CPU/gloo tests inject a checker there, the product never does.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def balanced_row_splits(row_pointers: torch.Tensor, world: int) -> list[int]:
+    """Row boundaries [b_0=0, ..., b_world=N] balancing nnz (not node count) per block."""
+    rp = row_pointers.to(torch.int64).cpu()
+    n = rp.numel() - 1
+    nnz = int(rp[-1])
+    targets = torch.arange(1, world, dtype=torch.float64) * (nnz / world)
+    cuts = torch.searchsorted(rp[1:].to(torch.float64), targets).tolist() if world > 1 else []
+    bounds = [0]
+    for c in cuts:
+        bounds.append(int(min(max(c + 1, bounds[-1]), n)))
+    bounds.append(n)
+    return bounds
+
+
+def shard_csr(row_pointers: torch.Tensor, column_index: torch.Tensor, lo: int, hi: int):
+    """Rows [lo, hi) of a CSR -> (rebased int32 row_pointers, column slice with GLOBAL ids)."""
+    rp = row_pointers.to(torch.int64)
+    beg, end = int(rp[lo]), int(rp[hi])
+    local_rp = (rp[lo:hi + 1] - beg).to(torch.int32)
+    return local_rp, column_index[beg:end].contiguous()
+
+
+def remap_columns_to_padded(column_index: torch.Tensor, bounds: Sequence[int], rows_per_rank: int):
+    """Global node id -> position in the padded all-gather layout
+    (owner_rank * rows_per_rank + id - bounds[owner_rank])."""
+    b = torch.as_tensor(list(bounds), dtype=torch.int64, device=column_index.device)
+    ci = column_index.to(torch.int64)
+    owner = torch.searchsorted(b[1:], ci, right=True)
+    out = owner * rows_per_rank + (ci - b[owner])
+    if int(out.max()) >= 2**31 if out.numel() else False:
+        raise ValueError("padded node id exceeds int32")
+    return out.to(torch.int32)
+
+
+def _default_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
+                       degrees_out=None, degrees_in=None, epsilon=1.0, out=None):
+    from . import _lib
+    return _lib.agg_rect(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
+                         degrees_out, degrees_in, epsilon, out)
+
+
+class ShardedAggregator:
+    """Aggregation over one destination-range shard of a graph.
+
+    Parameters
+    ----------
+    local_row_pointers : int32 [n_local + 1]   CSR rows owned by this rank (rebased to 0)
+    column_index       : int32 [nnz_local]     GLOBAL source ids of those rows
+    bounds             : world + 1 row boundaries (``balanced_row_splits``)
+    partSize           : neighbor-group size for the local partition
+    """
+
+    def __init__(self, local_row_pointers: torch.Tensor, column_index: torch.Tensor,
+                 bounds: Sequence[int], partSize: int = 32, *, group=None, device=None,
+                 aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        assert len(bounds) == self.world + 1
+        self.bounds = [int(b) for b in bounds]
+        self.n_local = self.bounds[self.rank + 1] - self.bounds[self.rank]
+        assert local_row_pointers.numel() == self.n_local + 1
+        self.rows_per_rank = max(1, max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world)))
+        self.partSize = int(partSize)
+        self.device = torch.device(device) if device is not None else column_index.device
+        self.aggregate_fn = aggregate_fn or _default_aggregate
+        if build_part_fn is None:
+            from . import _lib
+            build_part_fn = _lib.build_part
+        pp, p2n = build_part_fn(self.partSize, local_row_pointers.cpu().contiguous())
+        self.row_pointers = local_row_pointers.to(self.device)
+        self.column_index = remap_columns_to_padded(column_index.to(self.device), self.bounds,
+                                                    self.rows_per_rank)
+        self.part_pointers = pp.to(self.device)
+        self.part2Node = p2n.to(self.device)
+        self._gather_buf: Optional[torch.Tensor] = None
+        self._pad_buf: Optional[torch.Tensor] = None
+        self._deg_all: Optional[torch.Tensor] = None
+        self._deg_src: Optional[torch.Tensor] = None
+
+    @property
+    def nnz_local(self) -> int:
+        return int(self.column_index.numel())
+
+    def gather_features(self, X_local: torch.Tensor) -> torch.Tensor:
+        """all-gather the per-rank feature blocks into the padded [world * rows_per_rank, D] layout."""
+        assert X_local.shape[0] == self.n_local
+        D = X_local.shape[1]
+        if self.world == 1:
+            return X_local
+        shape = (self.world * self.rows_per_rank, D)
+        if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != X_local.device:
+            self._gather_buf = torch.empty(shape, dtype=X_local.dtype, device=X_local.device)
+        src = X_local
+        if self.n_local != self.rows_per_rank:
+            if self._pad_buf is None or self._pad_buf.shape != (self.rows_per_rank, D):
+                self._pad_buf = torch.zeros(self.rows_per_rank, D, dtype=X_local.dtype, device=X_local.device)
+            self._pad_buf[: self.n_local].copy_(X_local)
+            src = self._pad_buf
+        dist.all_gather_into_tensor(self._gather_buf, src.contiguous(), group=self.group)
+        return self._gather_buf
+
+    def prepare_degrees(self, degrees_local: torch.Tensor) -> torch.Tensor:
+        """all-gather the per-node degree norms once (graph constant) into the padded layout."""
+        assert degrees_local.numel() == self.n_local
+        if self.world == 1:
+            self._deg_all = degrees_local
+        else:
+            pad = torch.ones(self.rows_per_rank, dtype=degrees_local.dtype, device=degrees_local.device)
+            pad[: self.n_local] = degrees_local
+            buf = torch.empty(self.world * self.rows_per_rank, dtype=degrees_local.dtype,
+                              device=degrees_local.device)
+            dist.all_gather_into_tensor(buf, pad, group=self.group)
+            self._deg_all = buf
+        self._deg_src = degrees_local
+        return self._deg_all
+
+    def aggregate(self, X_local: torch.Tensor, mode: int = 0, *, degrees_local=None, epsilon: float = 1.0,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Y_local = A[rows of this rank, :] @ X   (mode 0 sag / 1 gcn / 2 gin)."""
+        deg_in = None
+        if mode == 1:
+            assert degrees_local is not None
+            if self._deg_all is None or self._deg_src is not degrees_local:
+                self.prepare_degrees(degrees_local)
+            deg_in = self._deg_all
+        X_all = self.gather_features(X_local)
+        return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
+                                 self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
+
+    def sag(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.aggregate(X_local, 0, out=out)

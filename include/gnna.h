@@ -1,0 +1,137 @@
+/*
+ * gnna.h -- C ABI of libgnna.so, the MI355X (gfx950) neighbor-group aggregation runtime.
+ *
+ * This is the drop-in boundary for GNNAdvisor's aggregation hot path.  Every entry point
+ * replaces one symbol the reference's extension binds (paths relative to
+ * GNNAdvisor/GNNConv/ in the reference):
+ *
+ *   gnna_sag_f32            <- SAG_cuda                  GNNAdvisor_kernel.cu:110-184 (+ kernel :186-259)
+ *   gnna_agg_gcn_f32        <- the aggregation half of spmm_forward_cuda   .cu:282-322 (+ kernel :324-415)
+ *                              and of spmm_backward_cuda                   .cu:436-470 (+ kernel :478-552)
+ *   gnna_agg_gin_f32        <- the aggregation half of spmm_forward_cuda_gin  .cu:575-603 (+ kernel :620-689)
+ *                              and of spmm_backward_cuda_gin               .cu:712-744 (+ kernel :749-814)
+ *   gnna_count_parts /
+ *   gnna_build_part_i32     <- build_part                GNNAdvisor.cpp:210-251
+ *
+ * The dense update (torch::mm at .cu:280,472,473,605,710,711) stays with the caller's
+ * BLAS exactly as in the reference; the pybind module `GNNAdvisor` shipped in
+ * gnnadvisor_osdi21_amd/csrc/gnna_torch.cpp composes both and re-exports the reference's
+ * six Python-visible functions (GNNAdvisor.cpp:253-263) with identical signatures.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / STL types.
+ *   - feature matrices: float32, row-major, contiguous, `dim` floats per row
+ *     (rows need only 4-byte alignment; 16-byte aligned bases and dim % 4 == 0 take the
+ *     vectorised path).
+ *   - index arrays: int32 (packed_accessor32<int,1> in the reference).
+ *   - all pointers passed to gnna_sag/agg_* are DEVICE pointers; build_part pointers are HOST.
+ *   - inputs are borrowed and never written; `out` is fully overwritten (the reference
+ *     returns a fresh zeros_like + accumulate, .cu:121).
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only
+ *     enqueue work; they never synchronise the device.
+ *   - return value: GNNA_OK or a negative gnna_status; gnna_last_error() gives the
+ *     message for the calling thread.  (The reference printf()s and exit(-1)s on launch
+ *     failure, .cu:177-181; this library reports instead.)
+ *   - partSize / dimWorker / warpPerBlock keep the reference's argument positions and
+ *     are validated (> 0).  On CDNA4 they are scheduling hints: a 64-lane wavefront
+ *     always covers the whole feature row, so dimWorker cannot drop dimensions the way
+ *     dimWorker < 32 lanes strides them in the reference (.cu:246).
+ */
+#ifndef GNNA_H_
+#define GNNA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GNNA_VERSION 100 /* 0.1.0 */
+#define GNNA_API __attribute__((visibility("default")))
+
+typedef enum gnna_status {
+    GNNA_OK = 0,
+    GNNA_ERR_INVALID_ARGUMENT = -1,
+    GNNA_ERR_HIP = -2,
+    GNNA_ERR_UNSUPPORTED = -3
+} gnna_status;
+
+GNNA_API int gnna_version(void);
+GNNA_API const char *gnna_last_error(void);
+
+/* ---- partitioner (host) --------------------------------------------------------------
+ * Neighbor-group partition of a CSR: row i with degree d_i yields ceil(d_i / partSize)
+ * groups of at most partSize consecutive neighbors; group p covers edge offsets
+ * [partPtr[p], partPtr[p+1]) and belongs to row part2Node[p].
+ * Replaces build_part (GNNAdvisor.cpp:210-251).  Deliberate divergences:
+ * exact int32 storage instead of float32, and partPtr[P] = indptr[N] is always written.
+ */
+GNNA_API int64_t gnna_count_parts(int partSize, const int32_t *indptr, int64_t num_nodes);
+GNNA_API int gnna_build_part_i32(int partSize, const int32_t *indptr, int64_t num_nodes,
+                        int32_t *partPtr /* [num_parts + 1] */,
+                        int32_t *part2Node /* [num_parts] */, int64_t num_parts);
+
+/* ---- aggregation (device) ------------------------------------------------------------
+ * out[i, :] = sum over groups p with part2Node[p] == i, over e in [part_pointers[p],
+ *             part_pointers[p+1]):  coef(i, column_index[e]) * input[column_index[e], :]
+ *   sag : coef = 1
+ *   gcn : coef = degrees[i] * degrees[column_index[e]]     (a product, as in the reference)
+ *   gin : coef = 1, the row sum is scaled by epsilon
+ * row_pointers and (for sag) degrees are accepted for signature parity and unused, as
+ * in the reference kernels.
+ */
+GNNA_API int gnna_sag_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
+                 const float *degrees, const int32_t *part_pointers, const int32_t *part2Node,
+                 float *out, int64_t num_nodes, int dim, int64_t num_parts,
+                 int partSize, int dimWorker, int warpPerBlock, void *stream);
+
+GNNA_API int gnna_agg_gcn_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
+                     const float *degrees, const int32_t *part_pointers, const int32_t *part2Node,
+                     float *out, int64_t num_nodes, int dim, int64_t num_parts,
+                     int partSize, int dimWorker, int warpPerBlock, void *stream);
+
+GNNA_API int gnna_agg_gin_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
+                     float epsilon, const int32_t *part_pointers, const int32_t *part2Node,
+                     float *out, int64_t num_nodes, int dim, int64_t num_parts,
+                     int partSize, int dimWorker, int warpPerBlock, void *stream);
+
+/* Rectangular form for a destination-range shard (multi-GPU; no counterpart in
+ * the single-GPU reference): `out` has num_out_rows rows (the shard's destination nodes),
+ * `input` has num_in_rows rows (all source nodes, e.g. the all-gathered feature matrix) and
+ * column_index holds ids into `input`.  mode: 0 = sag, 1 = gcn, 2 = gin.  For gcn,
+ * degrees_out is indexed by destination row and degrees_in by source row.
+ */
+GNNA_API int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows,
+                      const int32_t *column_index, const float *degrees_out, const float *degrees_in,
+                      float epsilon, const int32_t *part_pointers, const int32_t *part2Node,
+                      float *out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
+                      void *stream);
+
+/* ---- scheduling knobs (not part of the reference API; used by the tuner and bench) ----
+ * Any field <= 0 (or < 0 where 0 is meaningful) keeps the built-in choice.
+ */
+typedef struct gnna_tuning {
+    int groups_per_chunk; /* neighbor-groups a wavefront walks per work item (1..64)      */
+    int loads_in_flight;  /* wave-wide row loads issued before the first add (4, 8, 16)   */
+    int blocks_per_cu;    /* > 0: persistent grid of this many 256-thread blocks per CU;
+                             0: one wavefront per work item (hardware scheduled)          */
+    int xcd_remap;        /* 1: consecutive work items stay on one XCD's L2; 0: off       */
+    int trust_canonical;  /* 1: skip the partition validation pass (build_part output)    */
+} gnna_tuning;
+
+GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
+GNNA_API void gnna_get_tuning(gnna_tuning *t);
+
+/* ---- kernel timing (HIP events on the caller's stream; used by bench.py) ---------------
+ * Between gnna_profile_begin() and gnna_profile_end() every aggregation call records HIP
+ * events around its prologue kernel and around its main kernel on the stream it was
+ * given.  gnna_profile_end() synchronises those events and returns the average
+ * durations in milliseconds over the recorded calls (at most max_calls are recorded).
+ */
+GNNA_API int gnna_profile_begin(int max_calls);
+GNNA_API int gnna_profile_end(double *avg_main_ms, double *avg_prologue_ms, int *num_calls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GNNA_H_ */
