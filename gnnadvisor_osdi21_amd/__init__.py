@@ -7,9 +7,9 @@ not a port of its CUDA code.  Layout:
 * ``csrc/``          HIP kernels + C ABI (``libgnna.so``, declared in ``include/gnna.h``)
                      and the pybind/torch module ``GNNAdvisor`` (``GNNAdvisor.so``).
 * ``_lib``           ctypes binding of the C ABI.
-* ``param``          ``inputProperty`` / Decider   (reference: GNNAdvisor/param.py)
-* ``gnn_conv``       autograd ops + GCNConv/GINConv (reference: GNNAdvisor/gnn_conv.py)
-* ``unitest``        ``Verification`` harness       (reference: GNNAdvisor/unitest.py)
+* ``decider``        ``inputProperty`` / Decider   (reference: GNNAdvisor/param.py)
+* ``ops``            autograd ops + GCNConv/GINConv (reference: GNNAdvisor/gnn_conv.py)
+* ``verify``         ``Verification`` harness       (reference: GNNAdvisor/unitest.py)
 * ``graph``          synthetic graphs, CSR + degree builder (reference: GNNAdvisor/dataset.py:99-122)
 * ``dist``           dst-range sharding + RCCL all-gather halo exchange (new)
 
@@ -42,5 +42,5 @@ def install_reference_aliases() -> None:
     (``import GNNAdvisor as GNNA``, ``from param import *``, ``from gnn_conv import *``,
     ``from unitest import *`` -- GNNA_main.py:10-12,117,131) resolve to this package."""
     sys.modules.setdefault("GNNAdvisor", load_extension())
-    for name in ("param", "gnn_conv", "unitest"):
-        sys.modules.setdefault(name, importlib.import_module(f"{__name__}.{name}"))
+    for ref_name, ours in (("param", "decider"), ("gnn_conv", "ops"), ("unitest", "verify")):
+        sys.modules.setdefault(ref_name, importlib.import_module(f"{__name__}.{ours}"))

@@ -1,0 +1,233 @@
+"""Input profile + Decider (parameter auto-tuner).
+
+Counterpart of the reference's ``inputProperty`` (GNNAdvisor/param.py:4-164): the same
+constructor arguments, public fields (``row_pointers, column_index, degrees, partSize,
+dimWorker, warpPerBlock, partPtr, part2Node`` -- read by gnn_conv.py and GNNA_main.py) and
+methods (``decider / set_input / set_hidden / print_param``).
+
+Two policies:
+
+* ``policy="compat"`` -- the reference's formulas verbatim (param.py:72-117, including the
+  ``hiddenDim`` not-times-4 slip at :82), kept so that its golden outputs reproduce bit
+  for bit (tests/golden/decider.json).  Those formulas size a 32-lane warp's shared
+  memory on an NVIDIA SM and mean nothing on CDNA4.
+* ``policy="mi355x"`` (default) -- re-derived for 64-lane wavefronts, 256 CUs and
+  register accumulation (DESIGN.md "Decider"): the kernel needs no shared-memory budget,
+  so the knobs that matter are the neighbor-group size (balance vs. metadata) and the
+  scheduler knobs of libgnna (groups per wavefront work item, loads in flight).
+  ``dimWorker``/``warpPerBlock`` keep their places in the API and are reported as the
+  lane layout actually used (lanes per feature row, wavefronts per 256-thread block).
+
+Reference quirks preserved in both policies (SURVEY.md 8a "quirks"): in auto mode the
+reordered CSR is *not* copied back into this object (param.py:108-117), in manual mode it
+is (param.py:59-64); ``degrees`` is never refreshed after reordering.
+"""
+from __future__ import annotations
+
+import math
+
+WAVE = 64                # CDNA4 wavefront
+NUM_CUS = 256            # MI355X
+WAVES_PER_BLOCK = 4      # 256-thread workgroups
+
+
+def _pow2_at_least(x: int) -> int:
+    p = 1
+    while p < x:
+        p <<= 1
+    return p
+
+
+def lanes_per_row(dim: int) -> int:
+    """Lanes of a wavefront that cover one feature row (float4 per lane when dim % 4 == 0)."""
+    vec = 4 if dim % 4 == 0 else (2 if dim % 2 == 0 else 1)
+    return max(4, min(WAVE, _pow2_at_least((dim + vec - 1) // vec)))
+
+
+def choose_part_size(avg_degree: float, dim: int) -> int:
+    """Neighbor-group size for MI355X.
+
+    The kernel merges consecutive groups of one row in registers, so the group size no
+    longer bounds shared memory; it sets (a) the metadata volume (8 B per group plus one
+    chunk descriptor load per 16 groups) and (b) the granularity of load balancing (a
+    wavefront work item is ``groups_per_chunk`` groups, i.e. at most 16 x partSize edges).
+    Measured on the Reddit-like graph at D = 64 (tools/sweep.py, DESIGN.md "Tuning"):
+    partSize 8 / 16 / 32 / 64 / 128 -> 4.04 / 2.80 / 2.64 / 2.51 / 2.62 ms.  Rule: the
+    power of two nearest the average degree, clamped to [16, 64].  ``dim`` is accepted for
+    future per-width rules and unused today.
+    """
+    del dim
+    target = max(1.0, float(avg_degree))
+    ps = 1 << max(0, int(round(math.log2(target))))
+    return int(min(max(ps, 16), 64))
+
+
+def reference_formulas(avg_degree, input_dim, hidden_dim, smem_budget_kb, max_wpb=8, gap=100):
+    """The reference Decider's arithmetic (param.py:73-106) as a pure function: it sizes
+    per-warp shared memory (ids + one partial row, in KB) for a 32-lane-warp kernel.
+    ``est_hidden`` really omits the x4 on hidden_dim (param.py:82); kept for parity."""
+    ps = int(avg_degree)
+    row_bytes = lambda dim: ps * 4 + dim * 4
+    est_in = max_wpb * (row_bytes(input_dim) + gap * 4) / 1e3
+    est_hid = max_wpb * (ps * 4 + hidden_dim + 4 * gap) / 1e3
+    sm_in, sm_hid = min(est_in, smem_budget_kb), min(est_hid, smem_budget_kb)
+    return dict(partSize=ps, est_input_kb=est_in, est_hidden_kb=est_hid,
+                smem_input_kb=sm_in, smem_hidden_kb=sm_hid,
+                wpb_input=min(int(sm_in * 1e3 / row_bytes(input_dim)), max_wpb),
+                wpb_hidden=min(int(sm_hid * 1e3 / row_bytes(hidden_dim)), max_wpb),
+                dw_input=min(input_dim, 32), dw_hidden=min(hidden_dim, 32))
+
+
+class inputProperty(object):
+    def __init__(self, row_pointers=None, column_index=None, degrees=None,
+                 partSize=None, dimWorker=None, warpPerBlock=None,
+                 sharedMem=None,
+                 hiddenDim=None,
+                 dataset_obj=None,
+                 enable_rabbit=False,
+                 manual_mode=True,
+                 verbose=False,
+                 policy="mi355x"):
+
+        if dataset_obj is None:
+            raise ValueError("Dataset object MUST SET !!!")
+        if policy not in ("mi355x", "compat"):
+            raise ValueError("policy must be 'mi355x' or 'compat'")
+
+        self.dataset_obj = dataset_obj
+        self.policy = policy
+
+        self.row_pointers = row_pointers
+        self.column_index = column_index
+        self.degrees = degrees
+
+        self.num_nodes = dataset_obj.num_nodes
+        self.avgNodeDegree = dataset_obj.avg_degree
+        self.avgEdgeSpan = dataset_obj.avg_edgeSpan
+
+        self.partSize = partSize
+        self.dimWorker = dimWorker
+        self.warpPerBlock = warpPerBlock
+
+        self.dimWorker_input = dimWorker
+        self.dimWorker_hidden = dimWorker
+        self.warpPerBlock_input = warpPerBlock
+        self.warpPerBlock_hidden = warpPerBlock
+        self.inputDim = dataset_obj.num_features
+        self.hiddenDim = hiddenDim
+
+        self.manual_mode = manual_mode
+        self.enable_rabbit = enable_rabbit
+        self.verbose_flag = verbose
+        self.state_set_input = False
+        self.reorder_status = False
+
+        self.MAX_warpPerBlock = 8
+        self.share_memory = (sharedMem if sharedMem is not None else 0) * 0.4
+        self.gap_smem = 100
+
+        self.partPtr = None
+        self.part2Node = None
+
+        # libgnna scheduler knobs chosen by the mi355x policy (None = library default)
+        self.groups_per_chunk = None
+        self.loads_in_flight = None
+
+    # ------------------------------------------------------------------ decider
+    def decider(self):
+        """manual_mode: keep the user's knobs; auto: choose them (param.py:51-120)."""
+        if self.manual_mode:
+            if self.enable_rabbit:
+                self.dataset_obj.reorder_flag = True
+                self.dataset_obj.rabbit_reorder()
+                self.reorder_status = True
+                self.row_pointers = self.dataset_obj.row_pointers
+                self.column_index = self.dataset_obj.column_index
+            else:
+                self.dataset_obj.reorder_flag = False
+                self.reorder_status = False
+            if self.verbose_flag:
+                print("\n=> MANUAL Config Complete !!!\n")
+            return
+
+        if self.policy == "compat":
+            self._decide_compat()
+        else:
+            self._decide_mi355x()
+
+        if self.enable_rabbit:
+            # reorder iff the average edge span is large relative to the graph (param.py:108-117)
+            if math.sqrt(self.avgEdgeSpan) > math.sqrt(self.num_nodes) / 100:
+                self.dataset_obj.reorder_flag = True
+                self.reorder_status = True
+            else:
+                self.dataset_obj.reorder_flag = False
+                self.reorder_status = False
+            self.dataset_obj.rabbit_reorder()
+
+        if self.verbose_flag:
+            print("\n=> AUTO Decider Complete !!!\n")
+
+    def _decide_compat(self):
+        k = reference_formulas(self.avgNodeDegree, self.inputDim, self.hiddenDim, self.share_memory,
+                               self.MAX_warpPerBlock, self.gap_smem)
+        if self.verbose_flag:
+            print("input-layer shared memory (KB): {:.3f} ".format(k["est_input_kb"]))
+            print("input-layer updated (KB): {:.3f}".format(k["smem_input_kb"]))
+            print("hidden-layer shared memory (KB): {:.3f}".format(k["est_hidden_kb"]))
+            print("hidden-layer updated (KB): {:.3f}".format(k["smem_hidden_kb"]))
+        self.partSize = k["partSize"]
+        self.warpPerBlock_input, self.warpPerBlock_hidden = k["wpb_input"], k["wpb_hidden"]
+        self.dimWorker_input, self.dimWorker_hidden = k["dw_input"], k["dw_hidden"]
+
+    def _decide_mi355x(self):
+        # one partition is shared by all layers (GNNA_main.py:102): size it for the hidden
+        # width, which is what every aggregation but GIN's first layer sees
+        self.partSize = choose_part_size(self.avgNodeDegree, self.hiddenDim)
+        self.dimWorker_input = lanes_per_row(self.inputDim)
+        self.dimWorker_hidden = lanes_per_row(self.hiddenDim)
+        self.warpPerBlock_input = WAVES_PER_BLOCK
+        self.warpPerBlock_hidden = WAVES_PER_BLOCK
+        # work item = groups_per_chunk consecutive groups per wavefront: keep >= ~8 work
+        # items per wavefront slot for balance, and ~16 groups so that most rows are
+        # wholly owned by one wavefront (plain stores instead of atomics)
+        est_parts = self.num_nodes * max(1.0, self.avgNodeDegree / self.partSize)
+        slots = NUM_CUS * 32
+        g = 16
+        while g > 1 and est_parts / g < slots * 8:
+            g //= 2
+        self.groups_per_chunk = g
+        self.loads_in_flight = 8
+
+    # ------------------------------------------------------------------ per-layer switches
+    def set_input(self):
+        """Switch to the input-layer knobs (param.py:122-131)."""
+        self.dimWorker = self.dimWorker_input
+        self.warpPerBlock = self.warpPerBlock_input
+        self.state_set_input = True
+        return self
+
+    def set_hidden(self):
+        """Switch to the hidden-layer knobs (param.py:133-141)."""
+        self.dimWorker = self.dimWorker_hidden
+        self.warpPerBlock = self.warpPerBlock_hidden
+        self.state_set_input = False
+        return self
+
+    def apply_tuning(self):
+        """Push the scheduler knobs chosen by the mi355x policy into libgnna."""
+        if self.groups_per_chunk is None and self.loads_in_flight is None:
+            return
+        from . import _lib
+        _lib.set_tuning(groups_per_chunk=self.groups_per_chunk or -1,
+                        loads_in_flight=self.loads_in_flight or -1)
+
+    def print_param(self):
+        if self.verbose_flag:
+            layer = "INPUT" if self.state_set_input else "HIDDEN"
+            mode = "manual" if self.manual_mode else "auto"
+            print("# {} {} partSize: {}".format(mode, layer, self.partSize))
+            print("# {} {} dimWorker: {}".format(mode, layer, self.dimWorker))
+            print("# {} {} warpPerBlock: {}".format(mode, layer, self.warpPerBlock))
+            if not self.manual_mode:
+                print("# {} {} reorder_flag: {}".format(mode, layer, self.reorder_status))

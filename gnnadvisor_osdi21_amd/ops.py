@@ -1,0 +1,108 @@
+"""Operator layer over the ``GNNAdvisor`` extension: autograd functions and the GCN / GIN
+convolution modules.
+
+API counterpart of the reference's GNNAdvisor/gnn_conv.py -- the names and call
+signatures its driver uses are kept (``ScatterAndGather`` :7-27, ``GNNAFunction`` :30-78,
+``GCNConv`` :80-98, ``GNNAFunction_GIN`` :101-126, ``GINConv`` :128-147; weights drawn from
+U(-1/sqrt(out), 1/sqrt(out)) :86-88; GIN epsilon fixed at 0.5 and spelled ``eplison``
+:132) -- but the implementation is this package's own: every op unpacks the graph
+bundle once through ``_graph_args`` and calls the HIP extension.  No fallback exists.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.nn import Module, Parameter
+
+from . import load_extension
+
+GNNA = load_extension()
+
+
+def _graph_args(info):
+    """(row_pointers, column_index, degrees, partPtr, part2Node) of a decider.inputProperty."""
+    return (info.row_pointers, info.column_index, info.degrees, info.partPtr, info.part2Node)
+
+
+def _knobs(info):
+    return (info.partSize, info.dimWorker, info.warpPerBlock)
+
+
+class ScatterAndGather(Function):
+    """Y = A X (unweighted neighbor sum).  A is assumed symmetric, so backward is the same op."""
+
+    @staticmethod
+    def forward(ctx, X, inputInfo):
+        ctx.graph, ctx.knobs = _graph_args(inputInfo), _knobs(inputInfo)
+        return GNNA.SAG(X, *ctx.graph, *ctx.knobs)
+
+    @staticmethod
+    def backward(ctx, d_output):
+        return GNNA.SAG(d_output.contiguous(), *ctx.graph, *ctx.knobs), None
+
+
+class GNNAFunction(Function):
+    """GCN layer: dense update X W, then degree-weighted aggregation (update -> aggregate)."""
+
+    @staticmethod
+    def forward(ctx, X, weight, inputInfo):
+        ctx.save_for_backward(X, weight)
+        ctx.graph, ctx.knobs = _graph_args(inputInfo), _knobs(inputInfo)
+        return GNNA.forward(X, weight, *ctx.graph, *ctx.knobs)[0]
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X, weight = ctx.saved_tensors
+        d_input, d_weight = GNNA.backward(d_output.contiguous(), X, weight, *ctx.graph, *ctx.knobs)
+        return d_input, d_weight, None
+
+
+class GNNAFunction_GIN(Function):
+    """GIN layer: epsilon-scaled aggregation T = eps A X, then update T W (aggregate -> update).
+    T is what backward needs, so it is saved instead of X (reference gnn_conv.py:109,119)."""
+
+    @staticmethod
+    def forward(ctx, X, weight, inputInfo, eplison):
+        rp, ci, _deg, pp, p2n = _graph_args(inputInfo)
+        ctx.graph, ctx.knobs, ctx.eplison = (rp, ci, pp, p2n), _knobs(inputInfo), eplison
+        X_prime, X_agg = GNNA.forward_gin(X, weight, rp, ci, eplison, pp, p2n, *ctx.knobs)
+        ctx.save_for_backward(X_agg, weight)
+        return X_prime
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X_agg, weight = ctx.saved_tensors
+        rp, ci, pp, p2n = ctx.graph
+        d_input, d_weight = GNNA.backward_gin(d_output.contiguous(), X_agg, weight, rp, ci,
+                                              ctx.eplison, pp, p2n, *ctx.knobs)
+        return d_input, d_weight, None, None
+
+
+class _NeighborConv(Module):
+    """Shared parameter handling of the two convolution modules."""
+
+    def __init__(self, input_dim, output_dim):
+        super().__init__()
+        self.weights = Parameter(torch.empty(input_dim, output_dim))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        bound = 1.0 / math.sqrt(self.weights.size(1))
+        with torch.no_grad():
+            self.weights.uniform_(-bound, bound)
+
+
+class GCNConv(_NeighborConv):
+    def forward(self, X, inputInfo):
+        """X: [num_nodes, input_dim]; inputInfo: decider.inputProperty holding the CSR, the
+        sqrt-degree vector and the neighbor-group partition on X's device."""
+        return GNNAFunction.apply(X, self.weights, inputInfo)
+
+
+class GINConv(_NeighborConv):
+    def __init__(self, input_dim, output_dim):
+        self.eplison = 0.5
+        super().__init__(input_dim, output_dim)
+
+    def forward(self, X, inputInfo):
+        return GNNAFunction_GIN.apply(X, self.weights, inputInfo, self.eplison)

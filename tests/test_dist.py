@@ -1,0 +1,106 @@
+"""Multi-process sharded aggregation on CPU (gloo, world_size 2): the sharding, padding,
+column remap and all-gather logic of gnnadvisor_osdi21_amd/dist.py.  The local kernel is
+the injectable ``aggregate_fn``; here (and only here) the oracle stands in for it as the
+checker, since there is no GPU in this container."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from gnnadvisor_osdi21_amd import graph
+from gnnadvisor_osdi21_amd.dist import (ShardedAggregator, balanced_row_splits, remap_columns_to_padded,
+                                        shard_csr)
+
+
+def _oracle_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
+                      degrees_out=None, degrees_in=None, epsilon=1.0, out=None):
+    X = X_all.numpy(); ci = column_index.numpy(); pp = part_pointers.numpy(); p2n = part2Node.numpy()
+    dim = X.shape[1]
+    Y = np.zeros((num_out_rows, dim), dtype=np.float32)
+    for p in range(len(p2n)):
+        r = p2n[p]
+        for e in range(pp[p], pp[p + 1]):
+            c = 1.0
+            if mode == 1:
+                c = np.float32(degrees_out[r].item()) * np.float32(degrees_in[ci[e]].item())
+            Y[r] += np.float32(c) * X[ci[e]]
+    if mode == 2:
+        Y *= np.float32(epsilon)
+    res = torch.from_numpy(Y)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
+def _oracle_build_part(ps, rp):
+    pp, p2n = oracle.build_part(ps, rp.numpy())
+    return torch.from_numpy(pp), torch.from_numpy(p2n)
+
+
+def _worker(rank, world, port, n, e, dim, seed, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = graph.powerlaw_graph(n, e, 60, seed=seed)             # same graph on every rank
+        bounds = balanced_row_splits(g.row_pointers, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        X = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1))
+        agg = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate,
+                                build_part_fn=_oracle_build_part)
+        Ys = agg.sag(X[lo:hi].contiguous())
+        Yg = agg.aggregate(X[lo:hi].contiguous(), 1, degrees_local=g.degrees[lo:hi].contiguous())
+        Yi = agg.aggregate(X[lo:hi].contiguous(), 2, epsilon=0.5)
+        rpn, cin = g.row_pointers.numpy(), g.column_index.numpy()
+        ok = True
+        ok &= np.allclose(Ys.numpy(), oracle.csr_f64(0, X.numpy(), rpn, cin)[lo:hi], atol=1e-4)
+        ok &= np.allclose(Yg.numpy(), oracle.csr_f64(1, X.numpy(), rpn, cin, g.degrees.numpy())[lo:hi], rtol=1e-4, atol=1e-2)
+        ok &= np.allclose(Yi.numpy(), oracle.csr_f64(2, X.numpy(), rpn, cin, None, 0.5)[lo:hi], atol=1e-4)
+        q.put((rank, bool(ok), lo, hi, agg.rows_per_rank))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+@pytest.mark.parametrize("n,e", [(101, 1500), (64, 40)])
+def test_two_rank_sharded_aggregation_matches_single_graph(n, e):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, e, 12, 7, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, *_ in res), res
+    spans = sorted((lo, hi) for _, _, lo, hi, _ in res)
+    assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == n   # rows tile exactly
+
+
+def test_balanced_splits_and_remap():
+    rp = torch.tensor([0, 10, 10, 11, 30, 31, 40], dtype=torch.int32)
+    b = balanced_row_splits(rp, 2)
+    assert b[0] == 0 and b[-1] == 6 and b == sorted(b)
+    assert abs(int(rp[b[1]]) - 20) <= 10
+    assert balanced_row_splits(rp, 1) == [0, 6]
+    b8 = balanced_row_splits(rp, 8)
+    assert len(b8) == 9 and b8 == sorted(b8) and b8[-1] == 6
+    # padded layout: owner * rows_per_rank + local offset
+    ci = torch.tensor([0, 2, 3, 5], dtype=torch.int32)
+    out = remap_columns_to_padded(ci, [0, 3, 6], 4)
+    assert out.tolist() == [0, 2, 4, 6]
+    lrp, lci = shard_csr(rp, torch.arange(40, dtype=torch.int32), 3, 6)
+    assert lrp.tolist() == [0, 19, 20, 29] and lci[0] == 11 and lci.numel() == 29

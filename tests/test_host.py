@@ -1,0 +1,178 @@
+"""Host-side logic and the C-ABI surface, without a GPU: the library loads and exports
+every symbol include/gnna.h declares, the partitioner is bit-exact with the oracle and
+the reference goldens, the Decider's compat policy reproduces the reference's param.py,
+and the extension rejects CPU tensors with the reference's error text."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib, decider, graph, load_extension
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gnna.h")).read()
+    declared = set(re.findall(r"GNNA_API\s+[\w\s\*]+?\b(gnna_\w+)\s*\(", header))
+    assert declared, "no GNNA_API declarations found"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gnna.h but not exported by libgnna.so"
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.gnna_version() == 100
+
+
+def test_build_part_c_abi_bit_exact_vs_oracle_and_golden(golden_dir):
+    cases = json.load(open(os.path.join(golden_dir, "build_part.json")))["cases"]
+    for c in cases:
+        indptr = torch.tensor(c["indptr"], dtype=torch.int32)
+        pp, p2n = _lib.build_part(c["partSize"], indptr)
+        opp, op2n = oracle.build_part(c["partSize"], indptr.numpy())
+        assert pp.dtype == torch.int32 and p2n.dtype == torch.int32
+        assert np.array_equal(pp.numpy(), opp) and np.array_equal(p2n.numpy(), op2n), c["name"]
+        assert p2n.tolist() == [int(v) for v in c["part2Node"]], c["name"]   # reference golden
+    rng = np.random.default_rng(1)
+    for _ in range(10):
+        deg = rng.integers(0, 200, size=int(rng.integers(1, 400)))
+        indptr = torch.tensor(np.concatenate([[0], np.cumsum(deg)]), dtype=torch.int32)
+        ps = int(rng.integers(1, 70))
+        pp, p2n = _lib.build_part(ps, indptr)
+        opp, op2n = oracle.build_part(ps, indptr.numpy())
+        assert np.array_equal(pp.numpy(), opp) and np.array_equal(p2n.numpy(), op2n)
+        # every group is non-empty, <= ps edges, and groups tile each row exactly
+        sizes = np.diff(pp.numpy())
+        assert (sizes > 0).all() and (sizes <= ps).all()
+        assert np.array_equal(np.bincount(p2n.numpy(), weights=sizes, minlength=len(deg)), deg)
+
+
+def test_build_part_errors():
+    with pytest.raises(_lib.GnnaError):
+        _lib.build_part(0, torch.tensor([0, 1], dtype=torch.int32))
+    with pytest.raises(_lib.GnnaError):
+        _lib.build_part(4, torch.tensor([0, 5, 3], dtype=torch.int32))   # decreasing indptr
+
+
+def test_extension_module_surface_and_errors():
+    GNNA = load_extension()
+    for fn in ("SAG", "forward", "backward", "forward_gin", "backward_gin", "build_part"):
+        assert callable(getattr(GNNA, fn))
+    rp = torch.tensor([0, 3, 3, 8, 9, 9], dtype=torch.int32)
+    pp, p2n = GNNA.build_part(2, rp)
+    assert pp.tolist() == [0, 2, 3, 5, 7, 8, 9] and p2n.tolist() == [0, 0, 2, 2, 2, 3]
+    assert pp.int() is pp or torch.equal(pp.int(), pp)        # caller's .int() (GNNA_main.py:109) is a no-op
+    X = torch.ones(5, 4)
+    ci = torch.zeros(9, dtype=torch.int32)
+    deg = torch.ones(5)
+    with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
+        GNNA.SAG(X, rp, ci, deg, pp, p2n, 2, 32, 4)
+    with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
+        GNNA.forward(X, torch.ones(4, 2), rp, ci, deg, pp, p2n, 2, 32, 4)
+    with pytest.raises(RuntimeError, match="d_output must be a CUDA tensor"):
+        GNNA.backward(X, X, torch.ones(4, 2), rp, ci, deg, pp, p2n, 2, 32, 4)
+    with pytest.raises(RuntimeError, match="input must be a CUDA tensor"):
+        GNNA.forward_gin(X, torch.ones(4, 2), rp, ci, 0.5, pp, p2n, 2, 32, 4)
+    with pytest.raises(RuntimeError):
+        GNNA.build_part(2, rp.long())                            # wrong dtype
+    with pytest.raises(TypeError):
+        GNNA.SAG(X, rp, ci, deg, pp, p2n, 2, 32)                 # positional arity as in the reference
+
+
+def test_product_has_no_cpu_path():
+    g = graph.uniform_graph(10, 40, seed=1)
+    pp, p2n = _lib.build_part(4, g.row_pointers)
+    with pytest.raises(_lib.GnnaError, match="no CPU path"):
+        _lib.sag(torch.ones(10, 8), g.row_pointers, g.column_index, g.degrees, pp, p2n, 4, 32, 4)
+
+
+def test_tuning_roundtrip():
+    try:
+        _lib.set_tuning(8, 4, 2, 0, 1)
+        assert _lib.get_tuning() == dict(groups_per_chunk=8, loads_in_flight=4, blocks_per_cu=2,
+                                         xcd_remap=0, trust_canonical=1)
+        _lib.set_tuning(groups_per_chunk=32)      # others keep their values
+        assert _lib.get_tuning()["groups_per_chunk"] == 32 and _lib.get_tuning()["loads_in_flight"] == 4
+    finally:
+        _lib.reset_tuning()
+    assert _lib.get_tuning()["groups_per_chunk"] == 16
+
+
+class _DS:
+    def __init__(self, c):
+        self.num_nodes = c["num_nodes"]; self.avg_degree = c["num_edges"] / c["num_nodes"]
+        self.avg_edgeSpan = c["avg_edgeSpan"]; self.num_features = c["input_dim"]
+        self.reorder_flag = False; self.reorder_calls = 0
+        self.row_pointers = "rp_after_reorder"; self.column_index = "ci_after_reorder"
+
+    def rabbit_reorder(self):
+        self.reorder_calls += 1
+
+
+def test_decider_compat_policy_reproduces_reference_goldens(golden_dir):
+    for c in json.load(open(os.path.join(golden_dir, "decider.json")))["cases"]:
+        ds = _DS(c)
+        ip = decider.inputProperty("rp", "ci", "deg", 32, 32, 4, c["sharedMem"], hiddenDim=c["hidden"],
+                                   dataset_obj=ds, enable_rabbit=c.get("enable_rabbit", True),
+                                   manual_mode=(c["mode"] == "manual"), policy="compat")
+        ip.decider()
+        e = c["expect"]
+        assert ip.partSize == e["partSize"], c["name"]
+        assert bool(ip.reorder_status) == e["reorder"], c["name"]
+        for k in ("dimWorker_input", "warpPerBlock_input", "dimWorker_hidden", "warpPerBlock_hidden",
+                  "row_pointers", "column_index", "dimWorker", "warpPerBlock"):
+            if k in e:
+                assert getattr(ip, k) == e[k], (c["name"], k)
+        for k in ("reorder_flag", "reorder_calls"):
+            if k in e:
+                assert getattr(ds, k) == e[k], (c["name"], k)
+        if "after_set_input" in e:
+            r = ip.set_input()
+            assert r is ip and [ip.dimWorker, ip.warpPerBlock, ip.state_set_input] == e["after_set_input"]
+            r = ip.set_hidden()
+            assert r is ip and [ip.dimWorker, ip.warpPerBlock, ip.state_set_input] == e["after_set_hidden"]
+
+
+def test_decider_mi355x_policy_is_sane():
+    with pytest.raises(ValueError):
+        decider.inputProperty(dataset_obj=None)
+    for n, e, f, h in [(2708, 10556, 1433, 16), (232965, 114615892, 602, 64), (2449029, 123718280, 100, 64),
+                       (111059956, 1615685872, 128, 128), (1000, 100, 8, 3)]:
+        c = dict(num_nodes=n, num_edges=e, avg_edgeSpan=n / 3, input_dim=f)
+        ip = decider.inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=h, dataset_obj=_DS(c),
+                                   manual_mode=False)
+        ip.decider()
+        assert 16 <= ip.partSize <= 64 and ip.partSize & (ip.partSize - 1) == 0
+        assert ip.dimWorker_hidden == decider.lanes_per_row(h) and 4 <= ip.dimWorker_hidden <= 64
+        assert ip.warpPerBlock_hidden == 4 and 1 <= ip.groups_per_chunk <= 16
+    assert decider.lanes_per_row(64) == 16 and decider.lanes_per_row(16) == 4
+    assert decider.lanes_per_row(41) == 64 and decider.lanes_per_row(100) == 32
+    assert decider.choose_part_size(492, 64) == 64 and decider.choose_part_size(3.9, 16) == 16
+
+
+def test_graph_builders_follow_the_reference_loader():
+    # SURVEY 8c probe: src=[0,0,0,2,2,1], dst=[3,1,3,0,0,2] -> indptr [0,2,3,4,4], indices [1,3,2,0]
+    g = graph.graph_from_edges(torch.tensor([0, 0, 0, 2, 2, 1]), torch.tensor([3, 1, 3, 0, 0, 2]), 4)
+    assert g.row_pointers.tolist() == [0, 2, 3, 4, 4] and g.column_index.tolist() == [1, 3, 2, 0]
+    assert g.num_edges_raw == 6 and g.avg_degree == 1.5
+    np.testing.assert_allclose(g.degrees.numpy(), np.sqrt([2, 1, 1, 1]).astype(np.float32))
+    rng = np.random.default_rng(3)
+    src, dst = rng.integers(0, 50, 600), rng.integers(0, 50, 600)
+    g = graph.graph_from_edges(torch.tensor(src), torch.tensor(dst), 50)
+    rp, ci = oracle.np_csr_from_edges(src, dst, 50)
+    assert np.array_equal(g.row_pointers.numpy(), rp) and np.array_equal(g.column_index.numpy(), ci)
+    np.testing.assert_array_equal(g.degrees.numpy(), oracle.np_degrees(rp))
+    assert abs(g.avg_edgeSpan - np.mean(np.abs(src - dst))) < 1e-9
+    # seeded generators are deterministic, symmetric and loop-free
+    a = graph.powerlaw_graph(500, 8000, 120, seed=9)
+    b = graph.powerlaw_graph(500, 8000, 120, seed=9)
+    assert torch.equal(a.column_index, b.column_index) and torch.equal(a.row_pointers, b.row_pointers)
+    rows = torch.repeat_interleave(torch.arange(500), (a.row_pointers[1:] - a.row_pointers[:-1]).long())
+    assert not bool((rows == a.column_index).any())
+    fwd = set(zip(rows.tolist(), a.column_index.tolist()))
+    assert all((c, r) in fwd for r, c in fwd)
+    assert int((a.row_pointers[1:] - a.row_pointers[:-1]).max()) <= 2 * 120 + 20

@@ -34,10 +34,11 @@ def check_all_modes(g, X, pp, p2n, partSize, eps=0.5, what=""):
     Xn, ci, ppn, p2nn = X.numpy(), g.column_index.numpy(), pp.numpy(), p2n.numpy()
     rp, deg = g.row_pointers.numpy(), g.degrees.numpy()
     assert_close_f64(ys, oracle.csr_f64(0, Xn, rp, ci), what=what + " sag vs fp64")
-    assert_close_f64(yg, oracle.csr_f64(1, Xn, rp, ci, deg), what=what + " gcn vs fp64")
+    gscale = oracle.csr_f64(1, np.abs(Xn), rp, ci, deg)
+    assert_close_f64(yg, oracle.csr_f64(1, Xn, rp, ci, deg), what=what + " gcn vs fp64", scale=gscale)
     assert_close_f64(yi, oracle.csr_f64(2, Xn, rp, ci, None, eps), what=what + " gin vs fp64")
     assert_close_f64(ys, oracle.sag(Xn, ci, ppn, p2nn), what=what + " sag vs oracle")
-    assert_close_f64(yg, oracle.gcn_aggregate(Xn, ci, deg, ppn, p2nn), what=what + " gcn vs oracle")
+    assert_close_f64(yg, oracle.gcn_aggregate(Xn, ci, deg, ppn, p2nn), what=what + " gcn vs oracle", scale=gscale)
     assert_close_f64(yi, oracle.gin_aggregate(Xn, ci, eps, ppn, p2nn), what=what + " gin vs oracle")
 
 
@@ -151,7 +152,8 @@ def test_non_canonical_partition_is_still_correct():
     Xn = X.numpy()
     assert_close_f64(ys, oracle.csr_f64(0, Xn, g.row_pointers.numpy(), g.column_index.numpy()), what="shuffled sag")
     assert_close_f64(yg, oracle.csr_f64(1, Xn, g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy()),
-                     what="shuffled gcn")
+                     what="shuffled gcn",
+                     scale=oracle.csr_f64(1, np.abs(Xn), g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy()))
     assert_close_f64(ys, oracle.sag(Xn, ci2.numpy(), pp2.numpy(), p2n2.numpy()), what="shuffled sag vs oracle")
 
 

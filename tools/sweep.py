@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Scheduler-knob sweep for the aggregation kernel on one GPU (used to choose the defaults
+documented in DESIGN.md "Tuning").  Prints one line per configuration:
+kernel ms (HIP events, gnna_profile_*), G edges/s, gather-model TB/s."""
+import argparse
+import itertools
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gnnadvisor_osdi21_amd import _lib, graph  # noqa: E402
+
+
+def time_cfg(fn, steps=10, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    _lib.profile_begin(steps)
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return _lib.profile_end()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="reddit-like")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--locality", type=float, default=0.0)
+    ap.add_argument("--dims", default="64")
+    ap.add_argument("--ps", default="32")
+    ap.add_argument("--G", default="16")
+    ap.add_argument("--U", default="8")
+    ap.add_argument("--bpc", default="0")
+    ap.add_argument("--xcd", default="1")
+    ap.add_argument("--trust", default="0")
+    ap.add_argument("--mode", default="sag")
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    ints = lambda s: [int(v) for v in s.split(",")]
+    dev = torch.device("cuda:0")
+    g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
+    rp_cpu = g.row_pointers.cpu()
+    print(f"# graph {args.config}: N={g.num_nodes} nnz={g.nnz}", flush=True)
+    for ps in ints(args.ps):
+        pp, p2n = _lib.build_part(ps, rp_cpu)
+        ppd, p2nd = pp.to(dev), p2n.to(dev)
+        P = p2n.numel()
+        for D in ints(args.dims):
+            X = torch.randn(g.num_nodes, D, device=dev)
+            out = torch.empty_like(X)
+            bytes_ = g.nnz * (4 * D + 4) + g.num_nodes * (4 * D + 4) + P * 8
+            for G, U, bpc, xcd, trust in itertools.product(ints(args.G), ints(args.U), ints(args.bpc),
+                                                           ints(args.xcd), ints(args.trust)):
+                _lib.set_tuning(G, U, bpc, xcd, trust)
+                if args.mode == "sag":
+                    fn = lambda: _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
+                elif args.mode == "gcn":
+                    fn = lambda: _lib.agg_gcn(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
+                else:
+                    fn = lambda: _lib.agg_gin(X, g.row_pointers, g.column_index, 0.5, ppd, p2nd, ps, 32, 4, out=out)
+                r = time_cfg(fn, args.steps)
+                ms = r["main_ms"]
+                print(json.dumps(dict(ps=ps, D=D, G=G, U=U, bpc=bpc, xcd=xcd, trust=trust, P=P,
+                                      ms=round(ms, 4), pro_ms=round(r["prologue_ms"], 4),
+                                      Gedges=round(g.nnz / ms / 1e6, 2),
+                                      TBs=round(bytes_ / ms / 1e9, 3))), flush=True)
+    _lib.reset_tuning()
+
+
+if __name__ == "__main__":
+    main()
