@@ -45,6 +45,26 @@ def compulsory_bytes(nnz: int, n_rows: int, n_src: int, dim: int) -> int:
     return nnz * 4 + (n_rows + 1) * 4 + (n_rows + n_src) * dim * 4
 
 
+def measured_traffic(workload: str, dim: int, part_size: int, nnz: int):
+    """HBM-side bytes per launch of the aggregation kernel from the committed rocprofv3 PMC
+    passes (profiles/*traffic.json; FETCH_SIZE doubled per the gfx950 calibration).  PMC
+    counters cannot be read from inside this process, so the newest profile whose workload
+    matches is reported, scaled by nnz if the graph differs slightly; None if there is none."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
+        try:
+            t = json.load(open(f))
+        except Exception:
+            continue
+        if t.get("workload") == workload and t.get("dim") == dim and t.get("partSize") == part_size:
+            best = (t, os.path.basename(f))
+    if best is None:
+        return None, None
+    t, name = best
+    return t["corrected_bytes"] * (nnz / t["nnz"]), name
+
+
 def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
     """Oracle timed on the host: row-parallel fp32 CSR SpMM on all cores (value) and the
     single-thread neighbor-group port on a bounded slice of groups."""
@@ -117,7 +137,7 @@ def main():
     cfg = graph.CONFIGS[args.config]
     D, ps = args.dim, args.partSize
     n_local = max(2, int(cfg["num_nodes"] * args.scale))
-    e_target = int(cfg["num_edges"] * args.scale)
+    e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
 
     # ---- build the workload on the GPU -------------------------------------------------
     if world == 1:
@@ -178,6 +198,10 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = total_edges * args.steps / elapsed
         alg_bytes = gather_model_bytes(nnz_local, n_local, P, D)
+        wl_name = f"{args.config} power-law graph, random node order"
+        traffic, traffic_src = (None, None)
+        if world == 1 and args.scale == 1.0 and not args.locality:
+            traffic, traffic_src = measured_traffic(wl_name, D, ps, nnz_local)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         rec = {
             "metric": "aggregated edges/sec, GCN sum-aggregation SpMM (SAG) hidden=64",
@@ -192,7 +216,7 @@ def main():
                        "parallelism": "single GPU" if world == 1 else f"dst-range shards x{world} + RCCL all-gather",
                        "tuning": _lib.get_tuning()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "agg_kernel<4,16,SAG>", "kernel_ms": kern_ms,
                          "prologue_ms": prof["prologue_ms"], "algorithmic_bytes": alg_bytes,
                          "model": "gather: nnz*(4D+4) + N*(4D+4) + P*8",
