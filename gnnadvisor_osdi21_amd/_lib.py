@@ -37,7 +37,8 @@ _TAIL = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,        # part_pointe
 
 EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_part_i32",
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
-           "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32")
+           "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
+           "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32")
 
 
 def load() -> ctypes.CDLL:
@@ -72,6 +73,16 @@ def load() -> ctypes.CDLL:
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+    L.gnna_csr_from_edges_i32.restype = ctypes.c_int64
+    L.gnna_csr_from_edges_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+    L.gnna_degrees_f32.restype = ctypes.c_int
+    L.gnna_degrees_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    L.gnna_edge_span.restype = ctypes.c_int
+    L.gnna_edge_span.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]
+    L.gnna_reorder_rcm_i32.restype = ctypes.c_int
+    L.gnna_reorder_rcm_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_void_p]
     L.gnna_profile_begin.restype = ctypes.c_int
     L.gnna_profile_begin.argtypes = [ctypes.c_int]
     L.gnna_profile_end.restype = ctypes.c_int
@@ -108,6 +119,46 @@ def get_tuning() -> dict:
     t = Tuning()
     load().gnna_get_tuning(ctypes.byref(t))
     return {name: getattr(t, name) for name, _ in Tuning._fields_}
+
+
+def _host_i32(t) -> torch.Tensor:
+    t = torch.as_tensor(t)
+    return t.to(dtype=torch.int32, device="cpu").contiguous()
+
+
+def csr_from_edges(src, dst, num_nodes: int):
+    """Host CSR builder of the C ABI: (row_pointers int32 [N+1], column_index int32 [nnz])."""
+    s, d = _host_i32(src), _host_i32(dst)
+    assert s.numel() == d.numel()
+    rp = torch.empty(int(num_nodes) + 1, dtype=torch.int32)
+    ci = torch.empty(max(1, s.numel()), dtype=torch.int32)
+    nnz = load().gnna_csr_from_edges_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes),
+                                         rp.data_ptr(), ci.data_ptr())
+    if nnz < 0:
+        _check(int(nnz))
+    return rp, ci[:nnz].clone()
+
+
+def degrees(row_pointers: torch.Tensor) -> torch.Tensor:
+    rp = _host_i32(row_pointers)
+    out = torch.empty(rp.numel() - 1, dtype=torch.float32)
+    _check(load().gnna_degrees_f32(rp.data_ptr(), rp.numel() - 1, out.data_ptr()))
+    return out
+
+
+def edge_span(src, dst) -> float:
+    s, d = _host_i32(src), _host_i32(dst)
+    v = ctypes.c_double()
+    _check(load().gnna_edge_span(s.data_ptr(), d.data_ptr(), s.numel(), ctypes.byref(v)))
+    return v.value
+
+
+def reorder_rcm(src, dst, num_nodes: int) -> torch.Tensor:
+    """new_id[old_id] from the native reverse Cuthill-McKee renumbering."""
+    s, d = _host_i32(src), _host_i32(dst)
+    out = torch.empty(int(num_nodes), dtype=torch.int32)
+    _check(load().gnna_reorder_rcm_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes), out.data_ptr()))
+    return out
 
 
 def profile_begin(max_calls: int) -> None:

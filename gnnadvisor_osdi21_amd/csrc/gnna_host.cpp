@@ -6,7 +6,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <cmath>
 #include <mutex>
+#include <numeric>
+#include <thread>
+#include <vector>
 
 #include "gnna.h"
 #include "gnna_internal.h"
@@ -56,6 +61,24 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 }  // namespace gnna
+
+namespace {
+template <typename F>
+void parallel_rows(int64_t n, F &&fn)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t nt = std::max<int64_t>(1, std::min<int64_t>(hw ? hw : 1, std::min<int64_t>(64, n / 4096 + 1)));
+    if (nt == 1) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const int64_t step = (n + nt - 1) / nt;
+    for (int64_t t = 0; t < nt; t++) {
+        const int64_t lo = t * step, hi = std::min(n, lo + step);
+        if (lo >= hi) break;
+        th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+    }
+    for (auto &t : th) t.join();
+}
+}  // namespace
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -121,6 +144,114 @@ int gnna_build_part_i32(int partSize, const int32_t *indptr, int64_t num_nodes,
         }
     }
     partPtr[p] = num_nodes > 0 ? indptr[num_nodes] : 0;
+    return GNNA_OK;
+}
+
+// ---- graph inputs --------------------------------------------------------------------------
+
+
+int64_t gnna_csr_from_edges_i32(const int32_t *src, const int32_t *dst, int64_t num_edges, int64_t num_nodes,
+                                int32_t *row_pointers, int32_t *column_index)
+{
+    if (num_edges < 0 || num_nodes < 0 || !row_pointers || (num_edges > 0 && (!src || !dst || !column_index)))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad edge list arguments");
+    if (num_edges > 0x7fffffffLL) return gnna::fail(GNNA_ERR_UNSUPPORTED, "more than 2^31-1 edges: shard the graph");
+    // counting sort by source row
+    std::vector<int64_t> start((size_t)num_nodes + 1, 0);
+    for (int64_t e = 0; e < num_edges; e++) {
+        const int32_t s = src[e], d = dst[e];
+        if (s < 0 || s >= num_nodes || d < 0 || d >= num_nodes)
+            return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)e, s, d,
+                              (long long)num_nodes);
+        start[(size_t)s + 1]++;
+    }
+    for (int64_t i = 0; i < num_nodes; i++) start[(size_t)i + 1] += start[(size_t)i];
+    std::vector<int32_t> bucket((size_t)num_edges);
+    {
+        std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+        for (int64_t e = 0; e < num_edges; e++) bucket[(size_t)cursor[(size_t)src[e]]++] = dst[e];
+    }
+    // per-row sort + unique (parallel over row ranges)
+    std::vector<int32_t> uniq((size_t)num_nodes, 0);
+    parallel_rows(num_nodes, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            int32_t *b = bucket.data() + start[(size_t)i], *e = bucket.data() + start[(size_t)i + 1];
+            std::sort(b, e);
+            uniq[(size_t)i] = (int32_t)(std::unique(b, e) - b);
+        }
+    });
+    int64_t nnz = 0;
+    row_pointers[0] = 0;
+    for (int64_t i = 0; i < num_nodes; i++) {
+        std::copy_n(bucket.data() + start[(size_t)i], uniq[(size_t)i], column_index + nnz);
+        nnz += uniq[(size_t)i];
+        row_pointers[i + 1] = (int32_t)nnz;
+    }
+    return nnz;
+}
+
+int gnna_degrees_f32(const int32_t *row_pointers, int64_t num_nodes, float *degrees)
+{
+    if (num_nodes < 0 || (num_nodes > 0 && (!row_pointers || !degrees)))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad degrees arguments");
+    for (int64_t i = 0; i < num_nodes; i++) {
+        const int32_t d = row_pointers[i + 1] - row_pointers[i];
+        degrees[i] = std::sqrt((float)(d > 0 ? d : 1));
+    }
+    return GNNA_OK;
+}
+
+int gnna_edge_span(const int32_t *src, const int32_t *dst, int64_t num_edges, double *avg_edge_span)
+{
+    if (num_edges < 0 || !avg_edge_span || (num_edges > 0 && (!src || !dst)))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad edge span arguments");
+    long double acc = 0;
+    for (int64_t e = 0; e < num_edges; e++) acc += std::llabs((long long)src[e] - (long long)dst[e]);
+    *avg_edge_span = num_edges ? (double)(acc / num_edges) : 0.0;
+    return GNNA_OK;
+}
+
+int gnna_reorder_rcm_i32(const int32_t *src, const int32_t *dst, int64_t num_edges, int64_t num_nodes,
+                         int32_t *new_id)
+{
+    if (num_edges < 0 || num_nodes < 0 || (num_nodes > 0 && !new_id) || (num_edges > 0 && (!src || !dst)))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad reorder arguments");
+    if (num_nodes > 0x7fffffffLL || 2 * num_edges > 0x7fffffffLL)
+        return gnna::fail(GNNA_ERR_UNSUPPORTED, "graph too large for int32 reorder");
+    // symmetrised adjacency via the CSR builder on (src|dst, dst|src)
+    std::vector<int32_t> s2((size_t)2 * num_edges), d2((size_t)2 * num_edges);
+    std::copy_n(src, num_edges, s2.begin()); std::copy_n(dst, num_edges, s2.begin() + num_edges);
+    std::copy_n(dst, num_edges, d2.begin()); std::copy_n(src, num_edges, d2.begin() + num_edges);
+    std::vector<int32_t> rp((size_t)num_nodes + 1), ci((size_t)2 * num_edges);
+    const int64_t nnz = gnna_csr_from_edges_i32(s2.data(), d2.data(), 2 * num_edges, num_nodes, rp.data(), ci.data());
+    if (nnz < 0) return (int)nnz;
+    auto deg = [&](int32_t v) { return rp[(size_t)v + 1] - rp[(size_t)v]; };
+    // seeds: nodes by (degree, id); BFS visiting neighbours by (degree, id) = Cuthill-McKee
+    std::vector<int32_t> seeds((size_t)num_nodes);
+    std::iota(seeds.begin(), seeds.end(), 0);
+    std::stable_sort(seeds.begin(), seeds.end(), [&](int32_t a, int32_t b) { return deg(a) < deg(b); });
+    std::vector<int32_t> order;
+    order.reserve((size_t)num_nodes);
+    std::vector<char> seen((size_t)num_nodes, 0);
+    std::vector<int32_t> nb;
+    for (int32_t seed : seeds) {
+        if (seen[(size_t)seed]) continue;
+        seen[(size_t)seed] = 1;
+        size_t head = order.size();
+        order.push_back(seed);
+        while (head < order.size()) {
+            const int32_t v = order[head++];
+            nb.clear();
+            for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++) {
+                const int32_t u = ci[(size_t)k];
+                if (!seen[(size_t)u]) { seen[(size_t)u] = 1; nb.push_back(u); }
+            }
+            std::stable_sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return deg(a) < deg(b); });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+    }
+    // reverse (RCM): the last visited node gets id 0
+    for (int64_t k = 0; k < num_nodes; k++) new_id[(size_t)order[(size_t)(num_nodes - 1 - k)]] = (int32_t)k;
     return GNNA_OK;
 }
 

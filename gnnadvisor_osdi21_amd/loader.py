@@ -1,0 +1,137 @@
+"""Graph loading: ``custom_dataset`` (counterpart of the reference's GNNAdvisor/dataset.py:20-176).
+
+Same constructor (``path, dim, num_class, load_from_txt, verbose``), same public fields read
+by the driver and the Decider (``num_nodes, num_edges, num_features, num_classes, edge_index,
+avg_degree, avg_edgeSpan, row_pointers, column_index, degrees, x, y, val, reorder_flag``) and the
+``rabbit_reorder()`` hook.  Formats (dataset.py:59-91): a text edge list with ``src dst`` per
+line, or an ``.npz`` with keys ``src_li``, ``dst_li``, ``num_nodes``.
+
+What is this package's own: CSR, degrees and edge statistics come from the native host
+builders of libgnna (counting sort + per-row sort/unique instead of scipy; ``sqrt(max(deg,1))``),
+renumbering is the native reverse Cuthill-McKee of ``gnna_reorder_rcm_i32`` instead of the
+third-party Rabbit Order module (same contract: a relabelled ``[2, E]`` int32 edge list whose CSR
+and degrees are then rebuilt, dataset.py:147-172), and tensors go to ``device`` instead of an
+unconditional ``.cuda()``.  ``from_edges`` / ``from_synthetic`` build datasets without files (no
+dataset ships with the reference and there is no network here).
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _default_device():
+    return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
+
+class custom_dataset(torch.nn.Module):
+    def __init__(self, path, dim, num_class, load_from_txt=True, verbose=False, device=None,
+                 _edges=None):
+        super().__init__()
+        self.load_from_txt = load_from_txt
+        self.num_nodes = 0
+        self.num_features = dim
+        self.num_classes = num_class
+        self.edge_index = None
+        self.reorder_flag = False
+        self.verbose_flag = verbose
+        self.avg_degree = -1
+        self.avg_edgeSpan = -1
+        self.device = torch.device(device) if device is not None else _default_device()
+
+        if _edges is not None:
+            src, dst, n = _edges
+            self._set_edges(np.asarray(src), np.asarray(dst), int(n))
+        else:
+            self.init_edges(path)
+        self.init_embedding(dim)
+        self.init_labels(num_class)
+
+        n = self.num_nodes
+        mask = lambda frac: torch.arange(n, device=self.device) < int(n * frac)   # dataset.py:45-53
+        self.train_mask, self.val_mask, self.test_mask = mask(1), mask(0.3), mask(0.1)
+
+    # ------------------------------------------------------------------ construction helpers
+    @classmethod
+    def from_edges(cls, src, dst, num_nodes, dim, num_class, verbose=False, device=None):
+        return cls(None, dim, num_class, load_from_txt=False, verbose=verbose, device=device,
+                   _edges=(src, dst, num_nodes))
+
+    @classmethod
+    def from_synthetic(cls, name, dim=None, num_class=None, scale=1.0, verbose=False, device=None):
+        """One of graph.CONFIGS (seeded power-law stand-ins for the BASELINE.json graphs)."""
+        from . import graph
+        c = graph.CONFIGS[name]
+        g = graph.make_config_graph(name, device="cuda" if torch.cuda.is_available() else "cpu", scale=scale)
+        rows = torch.repeat_interleave(torch.arange(g.num_nodes, device=g.row_pointers.device),
+                                       (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+        return cls.from_edges(rows.cpu().numpy(), g.column_index.cpu().numpy(), g.num_nodes,
+                              dim if dim is not None else c["feat"],
+                              num_class if num_class is not None else c["classes"], verbose, device)
+
+    # ------------------------------------------------------------------ loading (dataset.py:55-122)
+    def init_edges(self, path):
+        start = time.perf_counter()
+        if self.load_from_txt:
+            pairs = np.loadtxt(path, dtype=np.int64, ndmin=2, usecols=(0, 1))
+            src, dst = pairs[:, 0], pairs[:, 1]
+            n = int(max(src.max(), dst.max())) + 1 if len(src) else 0
+            tag = "txt"
+        else:
+            if not str(path).endswith(".npz"):
+                raise ValueError("graph file must be a .npz file")
+            obj = np.load(path)
+            src, dst, n = obj["src_li"], obj["dst_li"], int(obj["num_nodes"])
+            tag = "npz"
+        if self.verbose_flag:
+            print("# Loading ({})(s): {:.3f}".format(tag, time.perf_counter() - start))
+        self._set_edges(src, dst, n)
+
+    def _set_edges(self, src, dst, num_nodes):
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(len(src))
+        self.edge_index = np.stack([np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)])
+        self.avg_degree = self.num_edges / self.num_nodes if self.num_nodes else 0.0
+        self.avg_edgeSpan = _lib.edge_span(self.edge_index[0], self.edge_index[1])
+        if self.verbose_flag:
+            print('# nodes: {}'.format(self.num_nodes))
+            print("# avg_degree: {:.2f}".format(self.avg_degree))
+            print("# avg_edgeSpan: {}".format(int(self.avg_edgeSpan)))
+        self.val = [1] * self.num_edges
+        self._build_csr("# Build CSR (s): {:.3f}")
+
+    def _build_csr(self, msg):
+        start = time.perf_counter()
+        self.row_pointers, self.column_index = _lib.csr_from_edges(self.edge_index[0], self.edge_index[1],
+                                                                   self.num_nodes)
+        if self.verbose_flag:
+            print(msg.format(time.perf_counter() - start))
+        self.degrees = _lib.degrees(self.row_pointers).to(self.device)
+
+    def init_embedding(self, dim):
+        """Random node embeddings (dataset.py:124-129)."""
+        self.x = torch.randn(self.num_nodes, dim, device=self.device)
+
+    def init_labels(self, num_class):
+        """All-ones labels (dataset.py:131-136)."""
+        self.y = torch.ones(self.num_nodes, dtype=torch.long, device=self.device)
+
+    # ------------------------------------------------------------------ renumbering hook (dataset.py:138-172)
+    def rabbit_reorder(self):
+        """If the Decider set ``reorder_flag``: renumber nodes for locality, then rebuild CSR
+        and degrees; otherwise do nothing."""
+        if not self.reorder_flag:
+            if self.verbose_flag:
+                print("Reorder flag is not set. Skipped...")
+            return
+        start = time.perf_counter()
+        new_id = _lib.reorder_rcm(self.edge_index[0], self.edge_index[1], self.num_nodes).numpy().astype(np.int64)
+        self.edge_index = np.stack([new_id[self.edge_index[0]], new_id[self.edge_index[1]]])
+        if self.verbose_flag:
+            print("# Reorder time (s): {}".format(time.perf_counter() - start))
+        self.avg_edgeSpan_after = _lib.edge_span(self.edge_index[0], self.edge_index[1])
+        self._build_csr("# Re-Build CSR (s): {:.3f}")

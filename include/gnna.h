@@ -71,6 +71,32 @@ GNNA_API int gnna_build_part_i32(int partSize, const int32_t *indptr, int64_t nu
                         int32_t *partPtr /* [num_parts + 1] */,
                         int32_t *part2Node /* [num_parts] */, int64_t num_parts);
 
+/* ---- graph inputs (host) --------------------------------------------------------------
+ * Native counterparts of the reference loader's CSR construction
+ * (GNNAdvisor/dataset.py:99-122) and of the renumbering hook (rabbit.reorder,
+ * rabbit_module/src/reorder.cpp:235-295).  All pointers are HOST pointers.
+ */
+
+/* Edge list -> CSR with scipy coo->csr semantics (dataset.py:108-118): duplicate edges
+ * merged, column indices sorted per row.  column_index must have room for num_edges
+ * entries; the return value is nnz (>= 0) or a negative gnna_status. */
+GNNA_API int64_t gnna_csr_from_edges_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
+                                int64_t num_nodes, int32_t *row_pointers /* [num_nodes + 1] */,
+                                int32_t *column_index /* [num_edges] */);
+
+/* degrees[i] = sqrt(max(row_pointers[i+1] - row_pointers[i], 1))  (dataset.py:11-18,121-122) */
+GNNA_API int gnna_degrees_f32(const int32_t *row_pointers, int64_t num_nodes, float *degrees);
+
+/* avg_edge_span = mean |src - dst| over the raw edge list (dataset.py:100; Decider input) */
+GNNA_API int gnna_edge_span(const int32_t *src, const int32_t *dst, int64_t num_edges, double *avg_edge_span);
+
+/* Locality renumbering: writes new_id[old_id] (a permutation of 0..num_nodes-1) computed by
+ * a deterministic reverse Cuthill-McKee sweep over the symmetrised graph (components in
+ * order of their lowest-degree seed).  Same role as rabbit.reorder -- shrink the average
+ * edge span -- but a different, single-threaded, reproducible algorithm. */
+GNNA_API int gnna_reorder_rcm_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
+                         int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
+
 /* ---- aggregation (device) ------------------------------------------------------------
  * out[i, :] = sum over groups p with part2Node[p] == i, over e in [part_pointers[p],
  *             part_pointers[p+1]):  coef(i, column_index[e]) * input[column_index[e], :]

@@ -1,0 +1,97 @@
+"""Graph input formats, native host CSR builder, renumbering hook (CPU only)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib
+from gnnadvisor_osdi21_amd.loader import custom_dataset
+
+
+def _edges(seed, n, e):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, n, e), rng.integers(0, n, e)
+
+
+@pytest.mark.parametrize("n,e", [(1, 0), (5, 1), (50, 600), (400, 3000), (3000, 200000)])
+def test_host_csr_builder_matches_scipy_semantics(n, e):
+    src, dst = _edges(n + e, n, e)
+    rp, ci = _lib.csr_from_edges(src, dst, n)
+    orp, oci = oracle.np_csr_from_edges(src, dst, n)
+    assert rp.dtype == torch.int32 and ci.dtype == torch.int32
+    assert np.array_equal(rp.numpy(), orp) and np.array_equal(ci.numpy(), oci)
+    np.testing.assert_array_equal(_lib.degrees(rp).numpy(), oracle.np_degrees(orp))
+    if e:
+        assert abs(_lib.edge_span(src, dst) - np.mean(np.abs(src - dst))) < 1e-9
+
+
+def test_host_csr_builder_rejects_bad_edges():
+    with pytest.raises(_lib.GnnaError, match="outside"):
+        _lib.csr_from_edges(np.array([0, 7]), np.array([1, 1]), 5)
+    with pytest.raises(_lib.GnnaError):
+        _lib.csr_from_edges(np.array([0, -1]), np.array([1, 1]), 5)
+
+
+def test_survey_probe_multigraph():
+    # src=[0,0,0,2,2,1], dst=[3,1,3,0,0,2] -> indptr [0,2,3,4,4], indices [1,3,2,0]
+    rp, ci = _lib.csr_from_edges([0, 0, 0, 2, 2, 1], [3, 1, 3, 0, 0, 2], 4)
+    assert rp.tolist() == [0, 2, 3, 4, 4] and ci.tolist() == [1, 3, 2, 0]
+
+
+def test_reorder_is_a_permutation_and_shrinks_span():
+    rng = np.random.default_rng(2)
+    n = 5000
+    u = np.arange(n).repeat(5)
+    v = (u + rng.integers(1, 25, u.size)) % n          # banded graph ...
+    perm = rng.permutation(n)
+    su, sv = perm[u], perm[v]                           # ... with scrambled ids
+    new = _lib.reorder_rcm(su, sv, n).numpy()
+    assert sorted(new.tolist()) == list(range(n))
+    before, after = np.mean(np.abs(su - sv)), np.mean(np.abs(new[su] - new[sv]))
+    assert after < 0.05 * before
+    # deterministic
+    assert np.array_equal(new, _lib.reorder_rcm(su, sv, n).numpy())
+    # isolated nodes and several components are all numbered
+    new2 = _lib.reorder_rcm(np.array([0, 5]), np.array([1, 6]), 10).numpy()
+    assert sorted(new2.tolist()) == list(range(10))
+
+
+def test_dataset_formats_and_fields(tmp_path):
+    src, dst = _edges(5, 60, 500)
+    np.savez(tmp_path / "g.npz", src_li=src, dst_li=dst, num_nodes=60)
+    with open(tmp_path / "g", "w") as f:
+        for a, b in zip(src, dst):
+            f.write(f"{a} {b}\n")
+    a = custom_dataset(str(tmp_path / "g.npz"), 12, 4, load_from_txt=False, device="cpu")
+    b = custom_dataset(str(tmp_path / "g"), 12, 4, load_from_txt=True, device="cpu")
+    orp, oci = oracle.np_csr_from_edges(src, dst, 60)
+    for ds in (a, b):
+        assert ds.num_edges == 500 and ds.num_features == 12 and ds.num_classes == 4
+        assert np.array_equal(ds.row_pointers.numpy(), orp) and np.array_equal(ds.column_index.numpy(), oci)
+        assert ds.avg_degree == 500 / ds.num_nodes
+        assert abs(ds.avg_edgeSpan - np.mean(np.abs(src - dst))) < 1e-9
+        assert ds.x.shape == (ds.num_nodes, 12) and ds.y.dtype == torch.long and bool((ds.y == 1).all())
+        assert ds.edge_index.shape == (2, 500) and len(ds.val) == 500
+        assert int(ds.train_mask.sum()) == ds.num_nodes and int(ds.val_mask.sum()) == int(ds.num_nodes * 0.3)
+        np.testing.assert_array_equal(ds.degrees.numpy(), oracle.np_degrees(orp))
+    assert a.num_nodes == 60 and b.num_nodes == int(max(src.max(), dst.max())) + 1
+    with pytest.raises(ValueError):
+        custom_dataset(str(tmp_path / "g"), 12, 4, load_from_txt=False, device="cpu")
+
+
+def test_reorder_hook_rebuilds_csr_and_degrees():
+    src, dst = _edges(9, 300, 2000)
+    ds = custom_dataset.from_edges(src, dst, 300, 8, 3, device="cpu")
+    rp0 = ds.row_pointers.clone()
+    ds.rabbit_reorder()                                  # flag not set: no-op (dataset.py:146-148)
+    assert torch.equal(ds.row_pointers, rp0)
+    ds.reorder_flag = True
+    ds.rabbit_reorder()
+    assert ds.edge_index.shape == (2, 2000)
+    orp, oci = oracle.np_csr_from_edges(ds.edge_index[0], ds.edge_index[1], 300)
+    assert np.array_equal(ds.row_pointers.numpy(), orp) and np.array_equal(ds.column_index.numpy(), oci)
+    np.testing.assert_array_equal(ds.degrees.numpy(), oracle.np_degrees(orp))
+    # relabelling preserves the degree multiset
+    assert sorted(np.diff(orp).tolist()) == sorted(np.diff(rp0.numpy()).tolist())
