@@ -22,9 +22,10 @@ thread_local char t_error[512] = "";
 
 // Defaults chosen by measurement on MI355X (DESIGN.md "Tuning"); override with
 // gnna_set_tuning() or the GNNA_TUNE environment variable
-// ("G=16,U=8,BPC=0,XCD=1,TRUST=0").
+// ("G=16,U=8,BPC=0,XCD=1,TRUST=0,PHASES=0").
 const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*/8,
-                                    /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0};
+                                    /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0,
+                                    /*column_phases=*/0};
 gnna_tuning g_tuning = kDefaultTuning;
 std::mutex g_tuning_mutex;
 std::once_flag g_env_once;
@@ -46,6 +47,7 @@ void apply_env()
         else if (!std::strcmp(tok, "BPC")) g_tuning.blocks_per_cu = v;
         else if (!std::strcmp(tok, "XCD")) g_tuning.xcd_remap = v;
         else if (!std::strcmp(tok, "TRUST")) g_tuning.trust_canonical = v;
+        else if (!std::strcmp(tok, "PHASES")) g_tuning.column_phases = v;
     }
 }
 
@@ -97,6 +99,7 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->blocks_per_cu >= 0) g_tuning.blocks_per_cu = t->blocks_per_cu;
     if (t->xcd_remap >= 0) g_tuning.xcd_remap = t->xcd_remap;
     if (t->trust_canonical >= 0) g_tuning.trust_canonical = t->trust_canonical;
+    if (t->column_phases >= 0) g_tuning.column_phases = t->column_phases;
 }
 
 void gnna_get_tuning(gnna_tuning *t)

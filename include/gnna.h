@@ -143,6 +143,8 @@ typedef struct gnna_tuning {
                              0: one wavefront per work item (hardware scheduled)          */
     int xcd_remap;        /* 1: consecutive work items stay on one XCD's L2; 0: off       */
     int trust_canonical;  /* 1: skip the partition validation pass (build_part output)    */
+    int column_phases;    /* 0: automatic; 1: single pass; 2..16: gather X in that many
+                             source-id ranges, one launch each (L2-resident slices)        */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */

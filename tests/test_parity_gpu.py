@@ -218,3 +218,53 @@ def test_full_size_reddit_like_properties():
         want = X_c[nb].sum(0)
         got = yx[r].cpu().double()
         assert bool(((got - want).abs() <= 1e-4 * want.abs().clamp(min=1.0)).all()), r
+
+
+@pytest.mark.parametrize("phases", [2, 3, 8, 16])
+@pytest.mark.parametrize("partSize,dim", [(32, 64), (7, 16), (64, 100), (100, 8)])
+def test_column_phased_schedule_matches_single_pass(phases, partSize, dim):
+    """The column-phased schedule (X gathered in `phases` source-id ranges, one launch each)
+    must give the same answer as the single pass, in every mode."""
+    g, X, pp, p2n = make_case(1500, 90000, dim, partSize, seed=phases * 100 + dim, kind="powerlaw")
+    try:
+        _lib.set_tuning(column_phases=phases)
+        check_all_modes(g, X, pp, p2n, partSize, what=f"phases={phases} ps={partSize} dim={dim}")
+        # exactness on the reference's known-answer input is kept by the phased schedule too
+        ones = torch.ones(g.num_nodes, dim)
+        ys, _, _ = run_all_modes(g, ones, pp, p2n, partSize)
+        want = (g.row_pointers[1:] - g.row_pointers[:-1]).float()[:, None].expand(-1, dim).numpy()
+        assert np.array_equal(ys, want)
+    finally:
+        _lib.reset_tuning()
+
+
+def test_column_phases_fall_back_on_unsorted_columns():
+    """Column ids shuffled inside every row (legal for the reference kernels, never produced by
+    its loader): the split pre-pass must detect it and phase 0 alone must aggregate everything."""
+    g, X, pp, p2n = make_case(600, 30000, 64, 16, seed=77, kind="powerlaw")
+    ci = g.column_index.clone()
+    gen = torch.Generator().manual_seed(1)
+    rp = g.row_pointers.tolist()
+    for r in range(g.num_nodes):
+        seg = ci[rp[r]:rp[r + 1]]
+        ci[rp[r]:rp[r + 1]] = seg[torch.randperm(seg.numel(), generator=gen)]
+    g2 = graph.CSRGraph(g.num_nodes, g.row_pointers, ci, g.degrees, g.num_edges_raw, g.avg_degree, g.avg_edgeSpan)
+    try:
+        _lib.set_tuning(column_phases=4)
+        check_all_modes(g2, X, pp, p2n, 16, what="unsorted columns, 4 phases")
+    finally:
+        _lib.reset_tuning()
+
+
+def test_column_phases_with_empty_rows_hub_and_rect_shapes():
+    n = 4000
+    src = torch.cat([torch.zeros(n - 1, dtype=torch.int64), torch.arange(1, n)])
+    dst = torch.cat([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.int64)])
+    gg = graph.graph_from_edges(src, dst, n + 50)            # hub + 50 isolated rows at the end
+    pp, p2n = _lib.build_part(8, gg.row_pointers)
+    X = torch.randn(n + 50, 32, generator=torch.Generator().manual_seed(4))
+    try:
+        _lib.set_tuning(column_phases=5)
+        check_all_modes(gg, X, pp, p2n, 8, what="hub, 5 phases")
+    finally:
+        _lib.reset_tuning()
