@@ -22,8 +22,8 @@ thread_local char t_error[512] = "";
 
 // Defaults chosen by measurement on MI355X (DESIGN.md "Tuning"); override with
 // gnna_set_tuning() or the GNNA_TUNE environment variable
-// ("G=16,U=8,BPC=0,XCD=1,TRUST=0,PHASES=0").
-const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*/8,
+// ("G=16,U=4,BPC=0,XCD=1,TRUST=0,PHASES=0").
+const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*/4,
                                     /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0,
                                     /*column_phases=*/0};
 gnna_tuning g_tuning = kDefaultTuning;

@@ -220,7 +220,7 @@ split_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp, co
 
 // ---- main kernel --------------------------------------------------------------------------
 
-template <int VEC, int LPR, int MODE, int U, bool WIDE>
+template <int VEC, int LPR, int MODE, int U, bool WIDE, bool PHASED>
 __global__ void __launch_bounds__(kBlock)
 agg_kernel(const AggParams p)
 {
@@ -236,7 +236,7 @@ agg_kernel(const AggParams p)
     const int c = lane % LPR;
     const int D = p.D;
     const int G = p.G;
-    const bool canonical = (p.trust && p.num_phases == 1) || (*p.flag != p.seq);
+    const bool canonical = (p.trust && !PHASED) || (*p.flag != p.seq);
     const char *xbase = reinterpret_cast<const char *>(p.X);
     const OffT row_bytes = (OffT)D * (OffT)sizeof(float);
 
@@ -266,9 +266,9 @@ agg_kernel(const AggParams p)
         unsigned long long starts = __ballot(is_start);
 
         // column-phased schedule: per-group counts of ids below this phase's bounds, prefix-summed
-        const bool phased = p.num_phases > 1 && canonical;
+        const bool phased = PHASED && canonical;
         int scan_lo = 0, scan_hi = 0;
-        if (p.num_phases > 1) {
+        if constexpr (PHASED) {
             if (!canonical) {
                 if (p.phase > 0) return;  // fallback: phase 0 alone aggregates everything
             } else {
@@ -293,7 +293,7 @@ agg_kernel(const AggParams p)
             int se = __builtin_amdgcn_readlane(my_pp, je);
             const bool shared = (js == 0 && prev_row == row) || (je == ng && next_row == row);
             const bool use_atomic = shared || !canonical;
-            if (phased) {
+            if (PHASED && phased) {
                 // ids of a row are sorted: the ids of this phase's column range are one
                 // contiguous piece [sb + #below lower bound, sb + #below upper bound)
                 const int base_lo = js > 0 ? __builtin_amdgcn_readlane(scan_lo, js - 1) : 0;
@@ -304,7 +304,7 @@ agg_kernel(const AggParams p)
                 sb = sb + run_lo;
                 if (se <= sb) continue;  // nothing of this row in this phase (out is pre-zeroed)
             }
-            const bool accumulate = phased && p.phase > 0;
+            const bool accumulate = PHASED && phased && p.phase > 0;
 
             float row_deg = 1.f;
             if constexpr (MODE == MODE_GCN) row_deg = p.deg_row[row];
@@ -338,13 +338,13 @@ agg_kernel(const AggParams p)
                             // full batch: U unpredicated wave-wide row loads back to back
 #pragma unroll
                             for (int u = 0; u < U; u++)
-                                v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)nid[u] * row_bytes + col_off);
+                                v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
                         } else {
 #pragma unroll
                             for (int u = 0; u < U; u++) {
                                 v[u] = vzero<VEC>();
                                 if (b + u * RPI + slot < nv)
-                                    v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)nid[u] * row_bytes + col_off);
+                                    v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
                             }
                         }
                         if constexpr (MODE == MODE_GCN) {
@@ -376,7 +376,8 @@ agg_kernel(const AggParams p)
                 if (slot == 0 && cvalid) {
                     float *dst = p.Y + (size_t)row * D + dcol;
                     if (!use_atomic) {
-                        if (accumulate) acc += *reinterpret_cast<const VT *>(dst);  // earlier phases' partial
+                        // earlier phases' partial (streamed: keep the X slice resident in L2)
+                        if (accumulate) acc += __builtin_nontemporal_load(reinterpret_cast<const VT *>(dst));
                         __builtin_nontemporal_store(acc, reinterpret_cast<VT *>(dst));
                     } else {
 #pragma unroll
@@ -488,58 +489,62 @@ hipEvent_t prof_event(int call, int which)
 typedef void (*AggKernel)(const AggParams);
 
 template <int VEC, int LPR, int MODE, int U>
-AggKernel pick_wide(bool wide)
+AggKernel pick_wide(bool wide, bool phased)
 {
-    if (wide) return agg_kernel<VEC, LPR, MODE, U, true>;
-    return agg_kernel<VEC, LPR, MODE, U, false>;
+    if (phased) {
+        if (wide) return agg_kernel<VEC, LPR, MODE, U, true, true>;
+        return agg_kernel<VEC, LPR, MODE, U, false, true>;
+    }
+    if (wide) return agg_kernel<VEC, LPR, MODE, U, true, false>;
+    return agg_kernel<VEC, LPR, MODE, U, false, false>;
 }
 
 template <int VEC, int LPR, int MODE>
-AggKernel pick_u(int u, bool wide)
+AggKernel pick_u(int u, bool wide, bool phased)
 {
     constexpr int RPI = kWave / LPR;
     constexpr int UMAX = kWave / RPI;  // == LPR
     if constexpr (VEC == 4 && UMAX >= 16) {
-        if (u >= 16) return pick_wide<VEC, LPR, MODE, 16>(wide);
+        if (u >= 16) return pick_wide<VEC, LPR, MODE, 16>(wide, phased);
     }
     if constexpr (UMAX >= 8) {
-        if (u >= 8) return pick_wide<VEC, LPR, MODE, 8>(wide);
+        if (u >= 8) return pick_wide<VEC, LPR, MODE, 8>(wide, phased);
     }
     if constexpr (VEC == 4 || UMAX < 8) {
-        return pick_wide<VEC, LPR, MODE, 4>(wide);
+        return pick_wide<VEC, LPR, MODE, 4>(wide, phased);
     } else {
-        return pick_wide<VEC, LPR, MODE, 8>(wide);
+        return pick_wide<VEC, LPR, MODE, 8>(wide, phased);
     }
 }
 
 template <int VEC, int MODE>
-AggKernel pick_lpr(int lpr, int u, bool wide)
+AggKernel pick_lpr(int lpr, int u, bool wide, bool phased)
 {
     switch (lpr) {
-    case 4: return pick_u<VEC, 4, MODE>(u, wide);
-    case 8: return pick_u<VEC, 8, MODE>(u, wide);
-    case 16: return pick_u<VEC, 16, MODE>(u, wide);
-    case 32: return pick_u<VEC, 32, MODE>(u, wide);
-    default: return pick_u<VEC, 64, MODE>(u, wide);
+    case 4: return pick_u<VEC, 4, MODE>(u, wide, phased);
+    case 8: return pick_u<VEC, 8, MODE>(u, wide, phased);
+    case 16: return pick_u<VEC, 16, MODE>(u, wide, phased);
+    case 32: return pick_u<VEC, 32, MODE>(u, wide, phased);
+    default: return pick_u<VEC, 64, MODE>(u, wide, phased);
     }
 }
 
 template <int MODE>
-AggKernel pick_vec(int vec, int lpr, int u, bool wide)
+AggKernel pick_vec(int vec, int lpr, int u, bool wide, bool phased)
 {
     switch (vec) {
-    case 4: return pick_lpr<4, MODE>(lpr, u, wide);
-    case 2: return pick_lpr<2, MODE>(lpr, u, wide);
-    default: return pick_lpr<1, MODE>(lpr, u, wide);
+    case 4: return pick_lpr<4, MODE>(lpr, u, wide, phased);
+    case 2: return pick_lpr<2, MODE>(lpr, u, wide, phased);
+    default: return pick_lpr<1, MODE>(lpr, u, wide, phased);
     }
 }
 
-AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide)
+AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide, bool phased)
 {
     switch (mode) {
-    case MODE_GCN: return pick_vec<MODE_GCN>(vec, lpr, u, wide);
-    case MODE_GIN: return pick_vec<MODE_GIN>(vec, lpr, u, wide);
-    default: return pick_vec<MODE_SAG>(vec, lpr, u, wide);
+    case MODE_GCN: return pick_vec<MODE_GCN>(vec, lpr, u, wide, phased);
+    case MODE_GIN: return pick_vec<MODE_GIN>(vec, lpr, u, wide, phased);
+    default: return pick_vec<MODE_SAG>(vec, lpr, u, wide, phased);
     }
 }
 
@@ -622,10 +627,9 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     if (p.xcd_remap && grid < span) grid = std::max<int64_t>(kXcds, grid / kXcds * kXcds);  // keep it % 8 stable
 
     const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
-    AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide);
-
     const size_t x_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
     const int phases = choose_phases(tune.column_phases, x_bytes, num_parts, partSize);
+    AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
     p.cum = nullptr; p.phase = 0; p.num_phases = 1;
     if (phases > 1) {
         void *ws = nullptr;

@@ -197,7 +197,7 @@ class inputProperty(object):
         while g > 1 and est_parts / g < slots * 8:
             g //= 2
         self.groups_per_chunk = g
-        self.loads_in_flight = 8
+        self.loads_in_flight = 4
 
     # ------------------------------------------------------------------ per-layer switches
     def set_input(self):
