@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--locality", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the sharded (torch.distributed) path even with one rank")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,8 +128,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded = world > 1 or args.force_dist
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     from gnnadvisor_osdi21_amd import _lib, graph
@@ -140,7 +146,7 @@ def main():
     e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
 
     # ---- build the workload on the GPU -------------------------------------------------
-    if world == 1:
+    if not sharded:
         g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
         rp_cpu = g.row_pointers.cpu()
         pp, p2n = _lib.build_part(ps, rp_cpu)
@@ -158,7 +164,7 @@ def main():
         rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
                                       seed=cfg["seed"] * 1000 + rank, device=dev)
         bounds = [i * n_local for i in range(world + 1)]
-        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev)
+        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist)
         nnz_local, n_src = agg.nnz_local, n_global
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         X = torch.randn(n_local, D, device=dev, generator=gen)
@@ -170,7 +176,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -187,7 +193,7 @@ def main():
 
     # max over ranks, total edges over ranks
     stats = torch.tensor([elapsed, float(nnz_local), prof["main_ms"], float(P)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if sharded:
         mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, total_edges, kern_ms = float(mx[0]), float(sm[1]), float(mx[2])
@@ -200,7 +206,7 @@ def main():
         alg_bytes = gather_model_bytes(nnz_local, n_local, P, D)
         wl_name = f"{args.config} power-law graph, random node order"
         traffic, traffic_src = (None, None)
-        if world == 1 and args.scale == 1.0 and not args.locality:
+        if not sharded and args.scale == 1.0 and not args.locality:
             traffic, traffic_src = measured_traffic(wl_name, D, ps, nnz_local)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         rec = {
@@ -224,11 +230,11 @@ def main():
                          if kern_ms > 0 else 0.0,
                          "kernel_edges_per_s": nnz_local / (kern_ms * 1e-3) if kern_ms > 0 else 0.0},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not sharded and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), X.cpu(), pp, p2n, D)
         print(json.dumps(rec), flush=True)
 
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -72,7 +72,7 @@ def load() -> ctypes.CDLL:
     L.gnna_agg_rect_f32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                                    ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
+                                    ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     L.gnna_csr_from_edges_i32.restype = ctypes.c_int64
     L.gnna_csr_from_edges_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]
@@ -231,18 +231,19 @@ MODE_SAG, MODE_GCN, MODE_GIN = 0, 1, 2
 
 
 def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, partSize=32,
-             degrees_out=None, degrees_in=None, epsilon=1.0, out=None):
+             degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False):
     """Destination-shard aggregation: X is [num_in_rows, dim] (all sources), out is
     [num_out_rows, dim]; column_index indexes X."""
     if not X.is_cuda:
         raise GnnaError("aggregation needs device tensors: there is no CPU path in libgnna")
     assert X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2
     if out is None:
+        assert not accumulate, "accumulate needs an existing `out`"
         out = torch.empty(num_out_rows, X.shape[1], dtype=torch.float32, device=X.device)
     with torch.cuda.device(X.device):
         _check(load().gnna_agg_rect_f32(int(mode), X.data_ptr(), X.shape[0], column_index.data_ptr(),
                                         _ptr(degrees_out), _ptr(degrees_in), float(epsilon),
                                         part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
                                         int(num_out_rows), X.shape[1], part2Node.numel(), int(partSize),
-                                        _stream(X.device)))
+                                        1 if accumulate else 0, _stream(X.device)))
     return out

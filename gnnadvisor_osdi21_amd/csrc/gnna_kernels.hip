@@ -80,6 +80,7 @@ struct AggParams {
     const uint16_t *cum;
     int32_t phase;
     int32_t num_phases;
+    int32_t acc_in;  // 1: add to the existing contents of Y instead of overwriting (no zero-fill)
 };
 
 // ---- wave-level helpers ----------------------------------------------------------------
@@ -133,12 +134,14 @@ __device__ __forceinline__ void vset(typename VecOf<VEC>::T &v, int k, float x)
 
 __global__ void __launch_bounds__(kBlock)
 prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restrict__ p2n,
-                const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate)
+                const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate, int zero_fill)
 {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+    if (!zero_fill) {
+        // accumulate mode: Y keeps its contents
+    } else if ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
         const size_t n4 = n_floats >> 2;
         f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
         const f32x4 z = (f32x4)(0.f);
@@ -304,7 +307,7 @@ agg_kernel(const AggParams p)
                 sb = sb + run_lo;
                 if (se <= sb) continue;  // nothing of this row in this phase (out is pre-zeroed)
             }
-            const bool accumulate = PHASED && phased && p.phase > 0;
+            const bool accumulate = p.acc_in || (PHASED && phased && p.phase > 0);
 
             float row_deg = 1.f;
             if constexpr (MODE == MODE_GCN) row_deg = p.deg_row[row];
@@ -551,7 +554,7 @@ AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide, bool phased)
 int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
                const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
                const int32_t *part2Node, float *out, int64_t num_nodes, int dim, int64_t num_parts,
-               int partSize, int dimWorker, int warpPerBlock, void *stream_v)
+               int partSize, int dimWorker, int warpPerBlock, void *stream_v, bool accumulate_into_out = false)
 {
     if (num_nodes < 0 || dim < 0 || num_parts < 0 || num_in_rows < 0)
         return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "negative size (num_nodes=%lld dim=%d num_parts=%lld)",
@@ -595,7 +598,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
         hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
                            part2Node, part_pointers, num_parts, flag, seq,
-                           (num_parts > 0 && !tune.trust_canonical) ? 1 : 0);
+                           (num_parts > 0 && !tune.trust_canonical) ? 1 : 0, accumulate_into_out ? 0 : 1);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
     }
@@ -631,6 +634,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     const int phases = choose_phases(tune.column_phases, x_bytes, num_parts, partSize);
     AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
     p.cum = nullptr; p.phase = 0; p.num_phases = 1;
+    p.acc_in = accumulate_into_out ? 1 : 0;
     if (phases > 1) {
         void *ws = nullptr;
         rc = get_workspace(ds, stream, (size_t)(phases - 1) * (size_t)num_parts * sizeof(uint16_t), &ws);
@@ -703,12 +707,13 @@ int gnna_agg_gin_f32(const float *input, const int32_t *row_pointers, const int3
 int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
                       const float *degrees_out, const float *degrees_in, float epsilon,
                       const int32_t *part_pointers, const int32_t *part2Node, float *out,
-                      int64_t num_out_rows, int dim, int64_t num_parts, int partSize, void *stream)
+                      int64_t num_out_rows, int dim, int64_t num_parts, int partSize, int accumulate,
+                      void *stream)
 {
     if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
         return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
     return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
-                      part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream);
+                      part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0);
 }
 
 int gnna_profile_begin(int max_calls)

@@ -13,6 +13,11 @@ backend "nccl" == RCCL over xGMI):
 * blocks are padded to a common ``rows_per_rank`` so the gather lands directly in the
   layout the kernel reads; column ids are remapped once, at construction, into that
   padded global numbering -- no per-step unpadding copy.
+* overlap: the shard's CSR is split once into the edges whose source is local (read
+  straight from the rank's own block) and the edges whose source is remote.  Per step the
+  all-gather is issued asynchronously, the local-source part is aggregated while the
+  remote blocks arrive over xGMI, then the remote-source part is accumulated into the same
+  output (``gnna_agg_rect_f32(..., accumulate=1)``).
 
 ``aggregate_fn`` is the local kernel (defaults to the HIP path through the C ABI); the
 CPU/gloo tests inject a checker there, the product never does.
@@ -60,10 +65,30 @@ def remap_columns_to_padded(column_index: torch.Tensor, bounds: Sequence[int], r
 
 
 def _default_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
-                       degrees_out=None, degrees_in=None, epsilon=1.0, out=None):
+                       degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False):
     from . import _lib
     return _lib.agg_rect(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
-                         degrees_out, degrees_in, epsilon, out)
+                         degrees_out, degrees_in, epsilon, out, accumulate)
+
+
+def split_local_remote(local_row_pointers: torch.Tensor, column_index: torch.Tensor, lo: int, hi: int):
+    """Split a shard's CSR (global column ids) into the part whose sources lie in [lo, hi)
+    (returned with ids rebased to the local block) and the rest (ids unchanged).
+    -> (rp_local, ci_local, rp_remote, ci_remote), row pointers int32 on the input's device."""
+    rp = local_row_pointers.to(torch.int64)
+    n = rp.numel() - 1
+    deg = rp[1:] - rp[:-1]
+    rows = torch.repeat_interleave(torch.arange(n, device=rp.device), deg)
+    ci = column_index.to(torch.int64)
+    is_local = (ci >= lo) & (ci < hi)
+
+    def csr_of(mask):
+        r = torch.zeros(n + 1, dtype=torch.int64, device=rp.device)
+        r[1:] = torch.cumsum(torch.bincount(rows[mask], minlength=n), 0)
+        return r.to(torch.int32)
+
+    return (csr_of(is_local), (ci[is_local] - lo).to(torch.int32),
+            csr_of(~is_local), ci[~is_local].to(torch.int32))
 
 
 class ShardedAggregator:
@@ -79,7 +104,8 @@ class ShardedAggregator:
 
     def __init__(self, local_row_pointers: torch.Tensor, column_index: torch.Tensor,
                  bounds: Sequence[int], partSize: int = 32, *, group=None, device=None,
-                 aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None):
+                 aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None,
+                 overlap: bool = True, force_overlap: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -100,6 +126,17 @@ class ShardedAggregator:
                                                     self.rows_per_rank)
         self.part_pointers = pp.to(self.device)
         self.part2Node = p2n.to(self.device)
+        # local-source / remote-source split for the overlapped schedule
+        self.overlap = bool(overlap) and (self.world > 1 or force_overlap)
+        if self.overlap:
+            lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+            rp_l, ci_l, rp_r, ci_r = split_local_remote(local_row_pointers.to(self.device),
+                                                        column_index.to(self.device), lo, hi)
+            pp_l, p2n_l = build_part_fn(self.partSize, rp_l.cpu().contiguous())
+            pp_r, p2n_r = build_part_fn(self.partSize, rp_r.cpu().contiguous())
+            self.local_part = (ci_l.contiguous(), pp_l.to(self.device), p2n_l.to(self.device))
+            self.remote_part = (remap_columns_to_padded(ci_r, self.bounds, self.rows_per_rank).contiguous(),
+                                pp_r.to(self.device), p2n_r.to(self.device))
         self._gather_buf: Optional[torch.Tensor] = None
         self._pad_buf: Optional[torch.Tensor] = None
         self._deg_all: Optional[torch.Tensor] = None
@@ -109,12 +146,13 @@ class ShardedAggregator:
     def nnz_local(self) -> int:
         return int(self.column_index.numel())
 
-    def gather_features(self, X_local: torch.Tensor) -> torch.Tensor:
-        """all-gather the per-rank feature blocks into the padded [world * rows_per_rank, D] layout."""
+    def gather_features(self, X_local: torch.Tensor, async_op: bool = False):
+        """all-gather the per-rank feature blocks into the padded [world * rows_per_rank, D] layout.
+        With async_op the collective's work handle is returned as well: (buffer, work)."""
         assert X_local.shape[0] == self.n_local
         D = X_local.shape[1]
         if self.world == 1:
-            return X_local
+            return (X_local, None) if async_op else X_local
         shape = (self.world * self.rows_per_rank, D)
         if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != X_local.device:
             self._gather_buf = torch.empty(shape, dtype=X_local.dtype, device=X_local.device)
@@ -124,8 +162,9 @@ class ShardedAggregator:
                 self._pad_buf = torch.zeros(self.rows_per_rank, D, dtype=X_local.dtype, device=X_local.device)
             self._pad_buf[: self.n_local].copy_(X_local)
             src = self._pad_buf
-        dist.all_gather_into_tensor(self._gather_buf, src.contiguous(), group=self.group)
-        return self._gather_buf
+        work = dist.all_gather_into_tensor(self._gather_buf, src.contiguous(), group=self.group,
+                                           async_op=async_op)
+        return (self._gather_buf, work) if async_op else self._gather_buf
 
     def prepare_degrees(self, degrees_local: torch.Tensor) -> torch.Tensor:
         """all-gather the per-node degree norms once (graph constant) into the padded layout."""
@@ -151,9 +190,20 @@ class ShardedAggregator:
             if self._deg_all is None or self._deg_src is not degrees_local:
                 self.prepare_degrees(degrees_local)
             deg_in = self._deg_all
-        X_all = self.gather_features(X_local)
-        return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
-                                 self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
+        if not self.overlap:
+            X_all = self.gather_features(X_local)
+            return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
+                                     self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
+        # overlapped: remote blocks travel while the local-source edges are aggregated
+        X_all, work = self.gather_features(X_local, async_op=True)
+        ci_l, pp_l, p2n_l = self.local_part
+        out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
+                                degrees_local, degrees_local, epsilon, out)
+        if work is not None:
+            work.wait()
+        ci_r, pp_r, p2n_r = self.remote_part
+        return self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
+                                 degrees_local, deg_in, epsilon, out, accumulate=True)
 
     def sag(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.aggregate(X_local, 0, out=out)

@@ -126,12 +126,15 @@ GNNA_API int gnna_agg_gin_f32(const float *input, const int32_t *row_pointers, c
  * `input` has num_in_rows rows (all source nodes, e.g. the all-gathered feature matrix) and
  * column_index holds ids into `input`.  mode: 0 = sag, 1 = gcn, 2 = gin.  For gcn,
  * degrees_out is indexed by destination row and degrees_in by source row.
+ * accumulate != 0 adds into the existing contents of `out` instead of overwriting it (used to
+ * aggregate local-source edges while the all-gather of remote features is still in flight,
+ * then add the remote-source part).
  */
 GNNA_API int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows,
                       const int32_t *column_index, const float *degrees_out, const float *degrees_in,
                       float epsilon, const int32_t *part_pointers, const int32_t *part2Node,
                       float *out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
-                      void *stream);
+                      int accumulate, void *stream);
 
 /* ---- scheduling knobs (not part of the reference API; used by the tuner and bench) ----
  * Any field <= 0 (or < 0 where 0 is meaningful) keeps the built-in choice.

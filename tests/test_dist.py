@@ -14,11 +14,11 @@ import torch.multiprocessing as mp
 import oracle
 from gnnadvisor_osdi21_amd import graph
 from gnnadvisor_osdi21_amd.dist import (ShardedAggregator, balanced_row_splits, remap_columns_to_padded,
-                                        shard_csr)
+                                        shard_csr, split_local_remote)
 
 
 def _oracle_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
-                      degrees_out=None, degrees_in=None, epsilon=1.0, out=None):
+                      degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False):
     X = X_all.numpy(); ci = column_index.numpy(); pp = part_pointers.numpy(); p2n = part2Node.numpy()
     dim = X.shape[1]
     Y = np.zeros((num_out_rows, dim), dtype=np.float32)
@@ -33,8 +33,12 @@ def _oracle_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_o
         Y *= np.float32(epsilon)
     res = torch.from_numpy(Y)
     if out is not None:
-        out.copy_(res)
+        if accumulate:
+            out.add_(res)
+        else:
+            out.copy_(res)
         return out
+    assert not accumulate
     return res
 
 
@@ -43,7 +47,7 @@ def _oracle_build_part(ps, rp):
     return torch.from_numpy(pp), torch.from_numpy(p2n)
 
 
-def _worker(rank, world, port, n, e, dim, seed, q):
+def _worker(rank, world, port, n, e, dim, seed, q, overlap=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -54,7 +58,11 @@ def _worker(rank, world, port, n, e, dim, seed, q):
         rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
         X = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1))
         agg = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate,
-                                build_part_fn=_oracle_build_part)
+                                build_part_fn=_oracle_build_part, overlap=overlap)
+        assert agg.overlap == overlap
+        if overlap:
+            assert agg.local_part[0].numel() + agg.remote_part[0].numel() == ci.numel()
+            assert bool((agg.local_part[0] >= 0).all()) and bool((agg.local_part[0] < hi - lo).all())
         Ys = agg.sag(X[lo:hi].contiguous())
         Yg = agg.aggregate(X[lo:hi].contiguous(), 1, degrees_local=g.degrees[lo:hi].contiguous())
         Yi = agg.aggregate(X[lo:hi].contiguous(), 2, epsilon=0.5)
@@ -73,12 +81,12 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n,e", [(101, 1500), (64, 40)])
-def test_two_rank_sharded_aggregation_matches_single_graph(n, e):
+@pytest.mark.parametrize("n,e,overlap", [(101, 1500, True), (64, 40, True), (101, 1500, False)])
+def test_two_rank_sharded_aggregation_matches_single_graph(n, e, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, e, 12, 7, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, e, 12, 7, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -104,3 +112,17 @@ def test_balanced_splits_and_remap():
     assert out.tolist() == [0, 2, 4, 6]
     lrp, lci = shard_csr(rp, torch.arange(40, dtype=torch.int32), 3, 6)
     assert lrp.tolist() == [0, 19, 20, 29] and lci[0] == 11 and lci.numel() == 29
+
+
+def test_split_local_remote_partitions_every_edge():
+    g = graph.powerlaw_graph(200, 3000, 80, seed=4)
+    rp, ci = shard_csr(g.row_pointers, g.column_index, 50, 120)
+    rp_l, ci_l, rp_r, ci_r = split_local_remote(rp, ci, 50, 120)
+    assert ci_l.numel() + ci_r.numel() == ci.numel()
+    assert bool(((ci_l >= 0) & (ci_l < 70)).all()) and not bool(((ci_r >= 50) & (ci_r < 120)).any())
+    deg = (rp[1:] - rp[:-1])
+    assert torch.equal((rp_l[1:] - rp_l[:-1]) + (rp_r[1:] - rp_r[:-1]), deg)
+    for r in range(70):   # per row: local + remote ids == original ids
+        orig = sorted(ci[rp[r]:rp[r + 1]].tolist())
+        got = sorted([v + 50 for v in ci_l[rp_l[r]:rp_l[r + 1]].tolist()] + ci_r[rp_r[r]:rp_r[r + 1]].tolist())
+        assert orig == got

@@ -198,3 +198,28 @@ def test_sharded_aggregator_emulated_on_one_gpu():
         yg = _lib.agg_rect(_lib.MODE_GCN, X_pad, cid, pp.cuda(), p2n.cuda(), hi - lo, ps,
                            degrees_out=g.degrees[lo:hi].contiguous().cuda(), degrees_in=deg_pad)
         assert_close_f64(yg.cpu().numpy(), full_gcn[lo:hi], what=f"shard {r} gcn", scale=gscale[lo:hi])
+
+
+def test_rect_accumulate_local_plus_remote_equals_whole():
+    """The overlapped multi-GPU schedule on one device: aggregate the local-source edges
+    (overwrite), then add the remote-source edges (accumulate) -- must equal the one-shot result,
+    including shards with no remote or no local edges (num_parts == 0 with accumulate)."""
+    from gnnadvisor_osdi21_amd.dist import remap_columns_to_padded, shard_csr, split_local_remote
+    g = graph.powerlaw_graph(900, 30000, 200, seed=33)
+    D, ps = 64, 8
+    X = torch.randn(g.num_nodes, D, generator=torch.Generator().manual_seed(5))
+    full = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+    full_gin = oracle.csr_f64(2, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy(), None, 0.5)
+    Xd = X.cuda()
+    for lo, hi in ((0, 300), (300, 900), (0, 900), (450, 451)):
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        rp_l, ci_l, rp_r, ci_r = split_local_remote(rp, ci, lo, hi)
+        pp_l, p2n_l = _lib.build_part(ps, rp_l)
+        pp_r, p2n_r = _lib.build_part(ps, rp_r)
+        X_loc = Xd[lo:hi].contiguous()
+        for mode, ref, eps in ((_lib.MODE_SAG, full, 1.0), (_lib.MODE_GIN, full_gin, 0.5)):
+            out = torch.full((hi - lo, D), float("nan"), device="cuda")
+            _lib.agg_rect(mode, X_loc, ci_l.cuda(), pp_l.cuda(), p2n_l.cuda(), hi - lo, ps, epsilon=eps, out=out)
+            _lib.agg_rect(mode, Xd, ci_r.cuda(), pp_r.cuda(), p2n_r.cuda(), hi - lo, ps, epsilon=eps, out=out,
+                          accumulate=True)
+            assert_close_f64(out.cpu().numpy(), ref[lo:hi], what=f"shard [{lo},{hi}) mode {mode}")
