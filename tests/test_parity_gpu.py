@@ -268,3 +268,49 @@ def test_column_phases_with_empty_rows_hub_and_rect_shapes():
         check_all_modes(gg, X, pp, p2n, 8, what="hub, 5 phases")
     finally:
         _lib.reset_tuning()
+
+
+def test_wide_offsets_when_features_exceed_4gib():
+    """papers100M-scale feature matrices (BASELINE config 5: D = 128) exceed 4 GiB: the kernel
+    must switch to 64-bit row offsets.  9.0 M x 128 fp32 = 4.6 GB of X, few edges, rows picked
+    on both sides of the 2^32-byte boundary."""
+    n_in, D, n_out = 9_000_000, 128, 4096
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    X = torch.randn(n_in, D, device="cuda", generator=gen)
+    cols = torch.randint(0, n_in, (n_out, 6), device="cuda", generator=gen)
+    cols[:, 0] = n_in - 1 - torch.arange(n_out, device="cuda")          # far beyond the 4 GiB mark
+    cols[:, 1] = (2 ** 32 // (D * 4)) + torch.arange(n_out, device="cuda") - n_out // 2   # straddling it
+    cols, _ = torch.sort(cols, dim=1)
+    rp = (torch.arange(n_out + 1, device="cuda") * 6).to(torch.int32)
+    ci = cols.reshape(-1).to(torch.int32).contiguous()
+    pp, p2n = _lib.build_part(4, rp.cpu())
+    y = _lib.agg_rect(_lib.MODE_SAG, X, ci, pp.cuda(), p2n.cuda(), n_out, 4)
+    want = X[cols.reshape(-1)].reshape(n_out, 6, D).double().sum(1)
+    assert bool(((y.double() - want).abs() <= 1e-4 * want.abs().clamp(min=1.0)).all())
+    del X
+
+
+def test_full_size_products_like_gin_widths():
+    """BASELINE config 4 (ogbn-products-like, GIN): layer-1 aggregation at D = F = 100 and hidden
+    layers at D = 64, epsilon = 0.5; size-independent checks (ones -> eps * row nnz exactly,
+    sampled rows vs fp64)."""
+    g = graph.make_config_graph("products-like", device="cuda")
+    n = g.num_nodes
+    pp, p2n = _lib.build_part(32, g.row_pointers.cpu())
+    ppd, p2nd = pp.cuda(), p2n.cuda()
+    cnt = (g.row_pointers[1:] - g.row_pointers[:-1]).float()
+    rp_c, ci_c = g.row_pointers.cpu(), g.column_index.cpu()
+    for D in (100, 64):
+        ones = torch.ones(n, D, device="cuda")
+        y = _lib.agg_gin(ones, g.row_pointers, g.column_index, 0.5, ppd, p2nd, 32, 32, 4)
+        assert torch.equal(y, (0.5 * cnt)[:, None].expand(-1, D))
+        del ones, y
+        X = torch.randn(n, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(D))
+        y = _lib.agg_gin(X, g.row_pointers, g.column_index, 0.5, ppd, p2nd, 32, 32, 4)
+        rows = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:300].tolist()
+        Xc = X.cpu().double()
+        for r in rows:
+            want = 0.5 * Xc[ci_c[rp_c[r]:rp_c[r + 1]].long()].sum(0)
+            got = y[r].cpu().double()
+            assert bool(((got - want).abs() <= 1e-4 * want.abs().clamp(min=1.0)).all()), (D, r)
+        del X, y, Xc
