@@ -211,7 +211,7 @@ split_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp, co
             if (valid && id < prev) bad = true;
             carry = __shfl(id, sub * SW + (SW - 1));  // last id of a full tile (only used if one follows)
             for (int b = 1; b < B; b++) {
-                const unsigned long long m = __ballot(valid && id < b * width);
+                const unsigned long long m = __ballot(valid && (int64_t)id < (int64_t)b * width);
                 const int c = __popcll((m >> (sub * SW)) & sub_mask);
                 if (sl == b - 1) cnt += c;
             }
@@ -399,7 +399,7 @@ struct Workspace {
     size_t bytes = 0;
 };
 struct DeviceState {
-    bool init = false;
+    std::atomic<bool> init{false};
     int num_cus = 256;
     int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
     std::map<hipStream_t, Workspace> ws;  // split tables of the column-phased schedule, per stream
@@ -417,9 +417,9 @@ int get_device_state(DeviceState **out)
     if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
     if (dev < 0 || dev >= kMaxDevices) return gnna::fail(GNNA_ERR_UNSUPPORTED, "device ordinal %d", dev);
     DeviceState &s = g_dev[dev];
-    if (!s.init) {
+    if (!s.init.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(g_dev_mutex);
-        if (!s.init) {
+        if (!s.init.load(std::memory_order_relaxed)) {
             hipDeviceProp_t prop;
             e = hipGetDeviceProperties(&prop, dev);
             if (e != hipSuccess)
@@ -429,7 +429,7 @@ int get_device_state(DeviceState **out)
             if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMalloc(flags): %s", hipGetErrorString(e));
             e = hipMemset(s.flags, 0, kFlagSlots * sizeof(int32_t));
             if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMemset(flags): %s", hipGetErrorString(e));
-            s.init = true;
+            s.init.store(true, std::memory_order_release);
         }
     }
     *out = &s;
@@ -476,7 +476,7 @@ int choose_phases(int requested, size_t x_bytes, int64_t num_parts, int part_siz
 
 // ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------
 struct ProfileState {
-    bool on = false;
+    std::atomic<bool> on{false};
     int max_calls = 0;
     int calls = 0;
     std::vector<hipEvent_t> ev;  // 3 per call: before prologue, between, after main
