@@ -7,15 +7,18 @@ A "step" is one pass of the hot path -- `gnna_sag_f32` through the C ABI (prolog
 aggregation kernel) -- over the whole synthetic graph, inputs already resident in HBM.
 Workload (BASELINE.json config 3, the one the metric is quoted on): a seeded Reddit-like
 power-law graph (N = 232,965, ~1.1e8 CSR entries, max degree ~21.6k, random node order),
-D = 64 fp32 features, partSize = 32.  N > 1 (launched by torch.distributed.run, one rank
+D = 64 fp32 features; neighbor-group size and scheduling (incl. the column-phased schedule)
+are chosen by the Decider in auto mode (`--manual` = the reference's manual mode, partSize 32,
+single pass).  N > 1 (launched by torch.distributed.run, one rank
 per GPU): weak scaling -- every rank owns a Reddit-sized block of destination rows whose
 sources are drawn from all ranks' nodes; each step all-gathers the feature blocks over
 RCCL/xGMI and aggregates locally (gnnadvisor_osdi21_amd/dist.py).
 
 Rank 0 prints ONE JSON line; `value` = total aggregated edges per second over all ranks.
 `roofline` prices the aggregation kernel with the gather model of SURVEY.md 8(d) /
-BASELINE.md 2: bytes = nnz*(4D+4) + N*(4D+4) + P*8 per launch, divided by the kernel's
-average duration measured with HIP events on the launch stream (gnna_profile_begin/end).
+BASELINE.md 2: bytes = nnz*(4D+4) + N*(4D+4) + P*8 per step, divided by the aggregation
+kernel's time per step (all column-phase launches of agg_kernel together) measured with HIP
+events on the launch stream (gnna_profile_begin/end).
 `cpu_baseline` times the oracle (CPU port of the same computation) on the host cores.
 """
 from __future__ import annotations
@@ -108,7 +111,10 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dim", type=int, default=64)
-    ap.add_argument("--partSize", type=int, default=32)
+    ap.add_argument("--partSize", type=int, default=0,
+                    help="neighbor-group size; 0 = the Decider's choice (auto mode, mi355x policy)")
+    ap.add_argument("--manual", action="store_true",
+                    help="reference manual mode: partSize 32 and library-default scheduling, no Decider")
     ap.add_argument("--config", default="reddit-like")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--locality", type=float, default=0.0)
@@ -141,13 +147,31 @@ def main():
     _lib.load()
 
     cfg = graph.CONFIGS[args.config]
-    D, ps = args.dim, args.partSize
+    D = args.dim
     n_local = max(2, int(cfg["num_nodes"] * args.scale))
     e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
 
     # ---- build the workload on the GPU -------------------------------------------------
+    def decide(num_nodes, avg_degree, avg_span):
+        """Decider in auto mode (the reference's --manual_mode False): partSize + scheduler knobs + hints."""
+        from gnnadvisor_osdi21_amd.decider import inputProperty
+
+        class _Profile:
+            pass
+        prof_obj = _Profile()
+        prof_obj.num_nodes, prof_obj.avg_degree, prof_obj.avg_edgeSpan = num_nodes, avg_degree, avg_span
+        prof_obj.num_features, prof_obj.reorder_flag = cfg["feat"], False
+        prof_obj.rabbit_reorder = lambda: None
+        info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=prof_obj,
+                             enable_rabbit=False, manual_mode=args.manual)
+        info.decider()
+        if not args.manual:
+            info.apply_tuning()
+        return args.partSize if args.partSize > 0 else info.partSize
+
     if not sharded:
         g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
+        ps = decide(g.num_nodes, g.avg_degree, g.avg_edgeSpan)
         rp_cpu = g.row_pointers.cpu()
         pp, p2n = _lib.build_part(ps, rp_cpu)
         ppd, p2nd = pp.to(dev), p2n.to(dev)
@@ -164,6 +188,8 @@ def main():
         rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
                                       seed=cfg["seed"] * 1000 + rank, device=dev)
         bounds = [i * n_local for i in range(world + 1)]
+        # sources are drawn from all ranks' nodes with no locality: span ~ n_global / 3
+        ps = decide(n_local, float(ci.numel()) / n_local, n_global / 3.0)
         agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist)
         nnz_local, n_src = agg.nnz_local, n_global
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -220,6 +246,8 @@ def main():
                        "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
                        "num_parts_per_gpu": P, "source_nodes": n_src,
                        "parallelism": "single GPU" if world == 1 else f"dst-range shards x{world} + RCCL all-gather",
+                       "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
+                       "column_phases_used": _lib.last_num_phases(),
                        "tuning": _lib.get_tuning()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -25,7 +25,8 @@ class GnnaError(RuntimeError):
 class Tuning(ctypes.Structure):
     _fields_ = [("groups_per_chunk", ctypes.c_int), ("loads_in_flight", ctypes.c_int),
                 ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
-                ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int)]
+                ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int),
+                ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int)]
 
 
 _lib = None
@@ -38,7 +39,8 @@ _TAIL = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,        # part_pointe
 EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_part_i32",
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
-           "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32")
+           "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
+           "gnna_last_num_phases")
 
 
 def load() -> ctypes.CDLL:
@@ -83,6 +85,7 @@ def load() -> ctypes.CDLL:
     L.gnna_reorder_rcm_i32.restype = ctypes.c_int
     L.gnna_reorder_rcm_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p]
+    L.gnna_last_num_phases.restype = ctypes.c_int
     L.gnna_profile_begin.restype = ctypes.c_int
     L.gnna_profile_begin.argtypes = [ctypes.c_int]
     L.gnna_profile_end.restype = ctypes.c_int
@@ -106,8 +109,9 @@ def _stream(device: torch.device) -> int:
 
 
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
-               trust_canonical=-1, column_phases=-1) -> None:
-    t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases)
+               trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1) -> None:
+    t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
+               avg_degree, nonlocal_ids)
     load().gnna_set_tuning(ctypes.byref(t))
 
 
@@ -159,6 +163,10 @@ def reorder_rcm(src, dst, num_nodes: int) -> torch.Tensor:
     out = torch.empty(int(num_nodes), dtype=torch.int32)
     _check(load().gnna_reorder_rcm_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes), out.data_ptr()))
     return out
+
+
+def last_num_phases() -> int:
+    return int(load().gnna_last_num_phases())
 
 
 def profile_begin(max_calls: int) -> None:

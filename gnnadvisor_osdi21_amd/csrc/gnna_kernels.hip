@@ -74,12 +74,12 @@ struct AggParams {
     int32_t G;
     int32_t xcd_remap;
     float eps;
-    // column-phased schedule (num_phases > 1): this launch only gathers source ids in
-    // [phase * phase_width, (phase + 1) * phase_width); cum[(b-1) * P + g] = number of ids of
-    // group g below b * phase_width (written by split_kernel)
-    const uint16_t *cum;
+    // column-phased schedule (num_phases > 1): this launch consumes, for every run, the
+    // edges from the run's cursor up to the first source id >= phase_hi
+    int32_t *cursor;   // [P] next unconsumed edge of the run starting at that group
     int32_t phase;
     int32_t num_phases;
+    int32_t phase_hi;
     int32_t acc_in;  // 1: add to the existing contents of Y instead of overwriting (no zero-fill)
 };
 
@@ -160,67 +160,6 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
     }
 }
 
-// Inclusive prefix sum over the 64 lanes.
-__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
-{
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    return v;
-}
-
-// ---- split pre-pass for the column-phased schedule ------------------------------------------
-// For every neighbor-group g and every phase boundary b = 1..B-1 count the ids of g below
-// b * width (the ids of a CSR row are sorted, so each phase's ids form one contiguous piece of
-// the group).  A sub-wave of SW lanes owns one group.  Also checks what the phased schedule
-// relies on -- ids sorted within a group and across the consecutive groups of one row -- and
-// raises the same "not canonical" flag as the prologue when that does not hold.
-template <int SW>
-__global__ void __launch_bounds__(kBlock)
-split_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp, const int32_t *__restrict__ p2n,
-             int64_t P, int B, int width, uint16_t *__restrict__ cum, int32_t *flag, int32_t seq)
-{
-    constexpr int GPW = kWave / SW;  // groups per wavefront
-    const int lane = threadIdx.x & (kWave - 1);
-    const int sub = lane / SW, sl = lane % SW;
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const unsigned long long sub_mask = SW == 64 ? ~0ull : ((1ull << SW) - 1ull);
-    bool bad = false;
-    for (int64_t g0 = wave * GPW; g0 < P; g0 += nwaves * GPW) {
-        const int64_t g = g0 + sub;
-        int beg = 0, len = 0;
-        if (g < P) { beg = pp[g]; len = pp[g + 1] - beg; }
-        if (len > 65535) bad = true;
-        if (len < 0) len = 0;
-        int max_len = len;  // wave-uniform loop bound
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) max_len = max(max_len, __shfl_xor(max_len, o));
-        int cnt = 0;  // lane sl of the sub-wave keeps the count for boundary sl + 1
-        int carry = -1;
-        if (g < P && g > 0 && len > 0 && sl == 0 && p2n[g - 1] == p2n[g] && beg > 0) carry = col[beg - 1];
-        carry = __shfl(carry, sub * SW);
-        for (int t = 0; t < max_len; t += SW) {
-            const bool valid = t + sl < len;
-            int id = 0x7fffffff;
-            if (valid) id = __builtin_nontemporal_load(col + beg + t + sl);
-            int prev = __shfl_up(id, 1);
-            if (sl == 0) prev = carry;
-            if (valid && id < prev) bad = true;
-            carry = __shfl(id, sub * SW + (SW - 1));  // last id of a full tile (only used if one follows)
-            for (int b = 1; b < B; b++) {
-                const unsigned long long m = __ballot(valid && (int64_t)id < (int64_t)b * width);
-                const int c = __popcll((m >> (sub * SW)) & sub_mask);
-                if (sl == b - 1) cnt += c;
-            }
-        }
-        if (g < P && sl < B - 1) cum[(int64_t)sl * P + g] = (uint16_t)cnt;
-    }
-    if (bad) *flag = seq;
-}
-
 // ---- main kernel --------------------------------------------------------------------------
 
 template <int VEC, int LPR, int MODE, int U, bool WIDE, bool PHASED>
@@ -239,7 +178,7 @@ agg_kernel(const AggParams p)
     const int c = lane % LPR;
     const int D = p.D;
     const int G = p.G;
-    const bool canonical = (p.trust && !PHASED) || (*p.flag != p.seq);
+    const bool canonical = p.trust || (*p.flag != p.seq);
     const char *xbase = reinterpret_cast<const char *>(p.X);
     const OffT row_bytes = (OffT)D * (OffT)sizeof(float);
 
@@ -268,23 +207,11 @@ agg_kernel(const AggParams p)
         bool is_start = lane < ng && (lane == 0 || my_row != up_row || !canonical);
         unsigned long long starts = __ballot(is_start);
 
-        // column-phased schedule: per-group counts of ids below this phase's bounds, prefix-summed
-        const bool phased = PHASED && canonical;
-        int scan_lo = 0, scan_hi = 0;
+        // column-phased schedule: every run keeps a cursor (next unconsumed edge) between the
+        // phase launches, stored at the index of the run's first group
+        int my_cur = 0, new_cur = 0;
         if constexpr (PHASED) {
-            if (!canonical) {
-                if (p.phase > 0) return;  // fallback: phase 0 alone aggregates everything
-            } else {
-                int lo_cnt = 0, hi_cnt = 0;
-                const int next_pp = __shfl_down(my_pp, 1);
-                if (lane < ng) {
-                    if (p.phase > 0) lo_cnt = p.cum[(int64_t)(p.phase - 1) * p.P + g0 + lane];
-                    hi_cnt = p.phase + 1 < p.num_phases ? (int)p.cum[(int64_t)p.phase * p.P + g0 + lane]
-                                                        : next_pp - my_pp;
-                }
-                scan_lo = wave_inclusive_scan(lo_cnt, lane);
-                scan_hi = wave_inclusive_scan(hi_cnt, lane);
-            }
+            if (p.phase > 0 && lane < ng) my_cur = p.cursor[g0 + lane];
         }
 
         while (starts) {
@@ -293,25 +220,20 @@ agg_kernel(const AggParams p)
             const int je = starts ? __builtin_ctzll(starts) : ng;
             const int row = __builtin_amdgcn_readlane(my_row, js);
             int sb = __builtin_amdgcn_readlane(my_pp, js);
-            int se = __builtin_amdgcn_readlane(my_pp, je);
+            const int se = __builtin_amdgcn_readlane(my_pp, je);
             const bool shared = (js == 0 && prev_row == row) || (je == ng && next_row == row);
             const bool use_atomic = shared || !canonical;
-            if (PHASED && phased) {
-                // ids of a row are sorted: the ids of this phase's column range are one
-                // contiguous piece [sb + #below lower bound, sb + #below upper bound)
-                const int base_lo = js > 0 ? __builtin_amdgcn_readlane(scan_lo, js - 1) : 0;
-                const int base_hi = js > 0 ? __builtin_amdgcn_readlane(scan_hi, js - 1) : 0;
-                const int run_lo = __builtin_amdgcn_readlane(scan_lo, je - 1) - base_lo;
-                const int run_hi = __builtin_amdgcn_readlane(scan_hi, je - 1) - base_hi;
-                se = sb + run_hi;
-                sb = sb + run_lo;
-                if (se <= sb) continue;  // nothing of this row in this phase (out is pre-zeroed)
+            if constexpr (PHASED) {
+                if (p.phase > 0) sb = __builtin_amdgcn_readlane(my_cur, js);
+                if (lane == js) new_cur = sb;
+                if (sb >= se) continue;  // run already fully consumed by earlier phases
             }
-            const bool accumulate = p.acc_in || (PHASED && phased && p.phase > 0);
+            const bool accumulate = p.acc_in || (PHASED && p.phase > 0);
 
             float row_deg = 1.f;
             if constexpr (MODE == MODE_GCN) row_deg = p.deg_row[row];
 
+            int consumed_end = sb;
             for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
                 const int dcol = d0 + c * VEC;
                 const bool cvalid = dcol < D;
@@ -319,17 +241,8 @@ agg_kernel(const AggParams p)
                 const OffT col_off = (OffT)(cvalid ? dcol : d0) * (OffT)sizeof(float);
                 VT acc = vzero<VEC>();
 
-                int id_next = 0;
-                if (sb + lane < se) id_next = __builtin_nontemporal_load(p.col + sb + lane);
-                for (int t = sb; t < se; t += kWave) {
-                    const int nv = se - t < kWave ? se - t : kWave;
-                    const int id = id_next;
-                    // software prefetch of the next 64 column ids
-                    if (t + kWave + lane < se) id_next = __builtin_nontemporal_load(p.col + t + kWave + lane);
-                    float dgn = 0.f;
-                    if constexpr (MODE == MODE_GCN) {
-                        if (lane < nv) dgn = p.deg_col[id];
-                    }
+                // gathers `nv` neighbor rows whose ids sit in lanes 0..nv-1 of `id`
+                auto gather_tile = [&](const int id, const float dgn, const int nv) {
 #pragma unroll 1
                     for (int b = 0; b < nv; b += U * RPI) {
                         VT v[U];
@@ -366,6 +279,47 @@ agg_kernel(const AggParams p)
                             }
                         }
                     }
+                };
+
+                if constexpr (PHASED) {
+                    // consume the run from its cursor while the ids stay below this phase's bound
+                    // (ids of a CSR row are sorted, so that is one contiguous piece; if they are not,
+                    // every edge is still consumed exactly once, only in a less local phase)
+                    const bool last_phase = p.phase + 1 >= p.num_phases;
+                    int t = sb;
+                    while (t < se) {
+                        const int nvalid = se - t < kWave ? se - t : kWave;
+                        int id = 0x7fffffff;
+                        if (lane < nvalid) id = __builtin_nontemporal_load(p.col + t + lane);
+                        int take = nvalid;
+                        if (!last_phase) {
+                            const unsigned long long below = __ballot(lane < nvalid && id < p.phase_hi);
+                            take = below == ~0ull ? kWave : __builtin_ctzll(~below);
+                        }
+                        float dgn = 0.f;
+                        if constexpr (MODE == MODE_GCN) {
+                            if (lane < take) dgn = p.deg_col[id];
+                        }
+                        gather_tile(id, dgn, take);
+                        t += take;
+                        if (take < nvalid) break;  // reached the phase boundary inside this tile
+                    }
+                    consumed_end = t;
+                    if (consumed_end == sb) break;  // nothing of this run in this phase: no flush
+                } else {
+                    int id_next = 0;
+                    if (sb + lane < se) id_next = __builtin_nontemporal_load(p.col + sb + lane);
+                    for (int t = sb; t < se; t += kWave) {
+                        const int nv = se - t < kWave ? se - t : kWave;
+                        const int id = id_next;
+                        // software prefetch of the next 64 column ids
+                        if (t + kWave + lane < se) id_next = __builtin_nontemporal_load(p.col + t + kWave + lane);
+                        float dgn = 0.f;
+                        if constexpr (MODE == MODE_GCN) {
+                            if (lane < nv) dgn = p.deg_col[id];
+                        }
+                        gather_tile(id, dgn, nv);
+                    }
                 }
 
                 // fold the RPI slots; every slot then holds the row's partial sum
@@ -388,6 +342,12 @@ agg_kernel(const AggParams p)
                     }
                 }
             }
+            if constexpr (PHASED) {
+                if (lane == js) new_cur = consumed_end;
+            }
+        }
+        if constexpr (PHASED) {
+            if (is_start && p.phase + 1 < p.num_phases) p.cursor[g0 + lane] = new_cur;
         }
     }
 }
@@ -402,7 +362,7 @@ struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
     int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
-    std::map<hipStream_t, Workspace> ws;  // split tables of the column-phased schedule, per stream
+    std::map<hipStream_t, Workspace> ws;  // run cursors of the column-phased schedule, per stream
 };
 constexpr int kFlagSlots = 1024;
 constexpr int kMaxDevices = 64;
@@ -456,22 +416,33 @@ int get_workspace(DeviceState *ds, hipStream_t stream, size_t bytes, void **out)
     return GNNA_OK;
 }
 
-// Number of column phases.  The gather is bound by the L2-miss path once X is larger than
-// one XCD's 4 MiB L2; restricting a launch to a slice of X that fits makes it L2-resident
-// (measured on MI355X with ids folded into one slice, Reddit-like D=64: 59.6 MB slice 2.81 ms,
-// 7.45 MB 1.58 ms, 3.7 MB 1.34 ms per full pass).  Each extra phase costs a launch, a pass over
-// the chunk descriptors and a read-modify-write of the touched output rows; with the current
-// wave-per-run kernel that overhead (0.14-0.24 ms per phase on the Reddit-like graph) eats the
-// gain beyond ~4 phases (tools/sweep.py --phases: 1/2/4/8/16 phases -> 2.84/2.79/2.58/3.30/5.15 ms),
-// so the automatic choice stays at a single pass and phases are opt-in (gnna_tuning.column_phases).
-int choose_phases(int requested, size_t x_bytes, int64_t num_parts, int part_size)
+// Number of column phases.  The gather is bound by the L2-miss path once X is larger than the
+// caches; restricting a launch to a slice of X makes the slice cache resident (MI355X, Reddit-like
+// D=64, ids folded into one slice: 59.6 MB slice 2.81 ms, 7.45 MB 1.58 ms, 3.7 MB 1.34 ms per full
+// pass).  Each extra phase costs a launch, a pass over the chunk descriptors and a
+// read-modify-write of the touched output rows, so the measured optimum is about one phase per
+// 15 MB of X (tools/sweep.py --phases, Reddit-like: D=16/32/64/128/256 -> 2/2/4/8/16 phases,
+// +12/+17/+49/+64/+60 %), capped by the work per row and phase (products-like, average degree 50:
+// 2 phases +5 %, 4 phases -21 %) and useless -- harmful -- when the ids of a row are already
+// local (community-ordered variant: 1.38 ms single pass, 2.5 ms in 2 phases).  Locality and degree
+// cannot be seen from here without a device round trip, so the automatic mode acts only on the
+// hints the Decider supplies (gnna_tuning.avg_degree / nonlocal_ids); without hints: one pass.
+thread_local int t_last_phases = 1;
+
+int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size)
 {
-    (void)x_bytes;
-    if (requested <= 1) return 1;
-    if (part_size > 65535) return 1;  // split table stores 16-bit counts
-    int b = std::min(requested, 16);
+    int b = 1;
+    if (tune.column_phases >= 1) {
+        b = std::min(tune.column_phases, 16);
+    } else if (tune.nonlocal_ids == 1 && tune.avg_degree > 0) {
+        const size_t per_phase = (size_t)15 << 20;
+        b = (int)std::min<size_t>(8, (x_bytes + per_phase / 2) / per_phase);
+        b = std::min(b, tune.avg_degree / 50);
+        const int64_t est_edges = std::min<int64_t>(num_parts * (int64_t)part_size, num_parts * (int64_t)tune.avg_degree);
+        while (b > 1 && est_edges / b < ((int64_t)4 << 20)) b--;
+    }
     while (b > 1 && num_parts / b < 64) b--;
-    return b;
+    return std::max(b, 1);
 }
 
 // ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------
@@ -631,36 +602,23 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
 
     const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
     const size_t x_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
-    const int phases = choose_phases(tune.column_phases, x_bytes, num_parts, partSize);
+    const int phases = choose_phases(tune, x_bytes, num_parts, partSize);
+    t_last_phases = phases;
     AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
-    p.cum = nullptr; p.phase = 0; p.num_phases = 1;
+    p.cursor = nullptr; p.phase = 0; p.num_phases = 1; p.phase_hi = 0x7fffffff;
     p.acc_in = accumulate_into_out ? 1 : 0;
+    int64_t width = num_in_rows;
     if (phases > 1) {
         void *ws = nullptr;
-        rc = get_workspace(ds, stream, (size_t)(phases - 1) * (size_t)num_parts * sizeof(uint16_t), &ws);
+        rc = get_workspace(ds, stream, (size_t)num_parts * sizeof(int32_t), &ws);
         if (rc != GNNA_OK) return rc;
-        const int width = (int)((num_in_rows + phases - 1) / phases);
-        const int sw = partSize <= 16 ? 16 : (partSize <= 32 ? 32 : 64);
-        const int gpw = kWave / sw;
-        int64_t sblocks = (num_parts + (int64_t)gpw * kWavesPerBlock - 1) / ((int64_t)gpw * kWavesPerBlock);
-        sblocks = std::max<int64_t>(1, std::min<int64_t>(sblocks, (int64_t)ds->num_cus * 16));
-        uint16_t *cum = static_cast<uint16_t *>(ws);
-        if (sw == 16)
-            hipLaunchKernelGGL(split_kernel<16>, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, column_index,
-                               part_pointers, part2Node, num_parts, phases, width, cum, flag, seq);
-        else if (sw == 32)
-            hipLaunchKernelGGL(split_kernel<32>, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, column_index,
-                               part_pointers, part2Node, num_parts, phases, width, cum, flag, seq);
-        else
-            hipLaunchKernelGGL(split_kernel<64>, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, column_index,
-                               part_pointers, part2Node, num_parts, phases, width, cum, flag, seq);
-        hipError_t es = hipGetLastError();
-        if (es != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "split launch: %s", hipGetErrorString(es));
-        p.cum = cum;
+        p.cursor = static_cast<int32_t *>(ws);
         p.num_phases = phases;
+        width = (num_in_rows + phases - 1) / phases;
     }
     for (int ph = 0; ph < phases; ph++) {
         p.phase = ph;
+        p.phase_hi = (int32_t)std::min<int64_t>((int64_t)(ph + 1) * width, 0x7fffffff);
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
@@ -715,6 +673,8 @@ int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const i
     return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
                       part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0);
 }
+
+int gnna_last_num_phases(void) { return t_last_phases; }
 
 int gnna_profile_begin(int max_calls)
 {

@@ -129,9 +129,11 @@ class inputProperty(object):
         self.partPtr = None
         self.part2Node = None
 
-        # libgnna scheduler knobs chosen by the mi355x policy (None = library default)
+        # libgnna scheduler knobs / graph hints chosen by the mi355x policy (None = library default)
         self.groups_per_chunk = None
         self.loads_in_flight = None
+        self.avg_degree_hint = None
+        self.nonlocal_ids_hint = None
 
     # ------------------------------------------------------------------ decider
     def decider(self):
@@ -189,15 +191,20 @@ class inputProperty(object):
         self.warpPerBlock_input = WAVES_PER_BLOCK
         self.warpPerBlock_hidden = WAVES_PER_BLOCK
         # work item = groups_per_chunk consecutive groups per wavefront: keep >= ~8 work
-        # items per wavefront slot for balance, and ~16 groups so that most rows are
+        # items per wavefront slot for balance, and ~16-32 groups so that most rows are
         # wholly owned by one wavefront (plain stores instead of atomics)
         est_parts = self.num_nodes * max(1.0, self.avgNodeDegree / self.partSize)
         slots = NUM_CUS * 32
-        g = 16
+        g = 32 if self.avgNodeDegree >= 128 else 16
         while g > 1 and est_parts / g < slots * 8:
             g //= 2
         self.groups_per_chunk = g
         self.loads_in_flight = 4
+        # graph hints for libgnna's column-phased schedule (gnna_tuning.avg_degree / nonlocal_ids):
+        # it pays only when a row's source ids are scattered over the whole id range.  A random
+        # labelling has avgEdgeSpan ~ N/3; community orderings are far below N/8.
+        self.avg_degree_hint = max(1, int(self.avgNodeDegree))
+        self.nonlocal_ids_hint = 1 if self.avgEdgeSpan > self.num_nodes / 8.0 else 0
 
     # ------------------------------------------------------------------ per-layer switches
     def set_input(self):
@@ -215,12 +222,17 @@ class inputProperty(object):
         return self
 
     def apply_tuning(self):
-        """Push the scheduler knobs chosen by the mi355x policy into libgnna."""
-        if self.groups_per_chunk is None and self.loads_in_flight is None:
+        """Push the scheduler knobs and graph hints chosen by the mi355x policy into libgnna."""
+        if self.groups_per_chunk is None and self.loads_in_flight is None and self.avg_degree_hint is None:
             return
         from . import _lib
+        nonlocal_ids = self.nonlocal_ids_hint
+        if nonlocal_ids is not None and self.reorder_status:
+            nonlocal_ids = 0   # the graph has just been renumbered for locality
         _lib.set_tuning(groups_per_chunk=self.groups_per_chunk or -1,
-                        loads_in_flight=self.loads_in_flight or -1)
+                        loads_in_flight=self.loads_in_flight or -1,
+                        avg_degree=-1 if self.avg_degree_hint is None else self.avg_degree_hint,
+                        nonlocal_ids=-1 if nonlocal_ids is None else nonlocal_ids)
 
     def print_param(self):
         if self.verbose_flag:

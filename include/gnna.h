@@ -146,12 +146,19 @@ typedef struct gnna_tuning {
                              0: one wavefront per work item (hardware scheduled)          */
     int xcd_remap;        /* 1: consecutive work items stay on one XCD's L2; 0: off       */
     int trust_canonical;  /* 1: skip the partition validation pass (build_part output)    */
-    int column_phases;    /* 0: automatic; 1: single pass; 2..16: gather X in that many
-                             source-id ranges, one launch each (L2-resident slices)        */
+    int column_phases;    /* 1: single pass; 2..16: gather X in that many source-id ranges, one
+                             launch each (cache-resident slices); 0: automatic from the size
+                             of X and the two graph hints below (single pass without hints) */
+    int avg_degree;       /* hint: average edges per destination row (0 = unknown)           */
+    int nonlocal_ids;     /* hint: 1 = source ids of a row are scattered over the whole id
+                             range (no community ordering), 0 = unknown / locality-ordered  */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
 GNNA_API void gnna_get_tuning(gnna_tuning *t);
+
+/* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
+GNNA_API int gnna_last_num_phases(void);
 
 /* ---- kernel timing (HIP events on the caller's stream; used by bench.py) ---------------
  * Between gnna_profile_begin() and gnna_profile_end() every aggregation call records HIP

@@ -94,7 +94,8 @@ def test_tuning_roundtrip():
     try:
         _lib.set_tuning(8, 4, 2, 0, 1)
         assert _lib.get_tuning() == dict(groups_per_chunk=8, loads_in_flight=4, blocks_per_cu=2,
-                                         xcd_remap=0, trust_canonical=1, column_phases=0)
+                                         xcd_remap=0, trust_canonical=1, column_phases=0, avg_degree=0,
+                                         nonlocal_ids=0)
         _lib.set_tuning(column_phases=8)
         assert _lib.get_tuning()["column_phases"] == 8
         _lib.set_tuning(groups_per_chunk=32)      # others keep their values
@@ -150,7 +151,12 @@ def test_decider_mi355x_policy_is_sane():
         ip.decider()
         assert 16 <= ip.partSize <= 64 and ip.partSize & (ip.partSize - 1) == 0
         assert ip.dimWorker_hidden == decider.lanes_per_row(h) and 4 <= ip.dimWorker_hidden <= 64
-        assert ip.warpPerBlock_hidden == 4 and 1 <= ip.groups_per_chunk <= 16
+        assert ip.warpPerBlock_hidden == 4 and 1 <= ip.groups_per_chunk <= 32
+        assert ip.avg_degree_hint == max(1, int(e / n)) and ip.nonlocal_ids_hint == 1   # span n/3: scattered ids
+    local = dict(num_nodes=100000, num_edges=5000000, avg_edgeSpan=300.0, input_dim=64)
+    ip = decider.inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=64, dataset_obj=_DS(local), manual_mode=False)
+    ip.decider()
+    assert ip.nonlocal_ids_hint == 0            # community-ordered ids: never phase
     assert decider.lanes_per_row(64) == 16 and decider.lanes_per_row(16) == 4
     assert decider.lanes_per_row(41) == 64 and decider.lanes_per_row(100) == 32
     assert decider.choose_part_size(492, 64) == 64 and decider.choose_part_size(3.9, 16) == 16

@@ -238,9 +238,9 @@ def test_column_phased_schedule_matches_single_pass(phases, partSize, dim):
         _lib.reset_tuning()
 
 
-def test_column_phases_fall_back_on_unsorted_columns():
+def test_column_phases_stay_correct_on_unsorted_columns():
     """Column ids shuffled inside every row (legal for the reference kernels, never produced by
-    its loader): the split pre-pass must detect it and phase 0 alone must aggregate everything."""
+    its loader): every edge is still consumed exactly once, only in a less local phase."""
     g, X, pp, p2n = make_case(600, 30000, 64, 16, seed=77, kind="powerlaw")
     ci = g.column_index.clone()
     gen = torch.Generator().manual_seed(1)
@@ -334,3 +334,28 @@ def test_randomised_configurations():
                             what=f"case {k}: n={n} e={e} dim={dim} ps={ps} {kind} tuning={_lib.get_tuning()}")
     finally:
         _lib.reset_tuning()
+
+
+def test_automatic_phase_selection_follows_the_hints():
+    """column_phases = 0: phases only with the Decider's hints (scattered ids, high degree, big X)."""
+    g = graph.make_config_graph("reddit-like", device="cuda", scale=0.25)
+    pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+    ppd, p2nd = pp.cuda(), p2n.cuda()
+    X = torch.randn(g.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    try:
+        y1 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        assert _lib.last_num_phases() == 1                     # no hints: single pass
+        _lib.set_tuning(avg_degree=int(g.nnz / g.num_nodes), nonlocal_ids=1)
+        y2 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        assert _lib.last_num_phases() == 4                     # X = 59.6 MB -> 4 phases
+        _lib.set_tuning(nonlocal_ids=0)
+        _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        assert _lib.last_num_phases() == 1                     # locality-ordered ids: never
+        _lib.set_tuning(avg_degree=40, nonlocal_ids=1)
+        _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        assert _lib.last_num_phases() == 1                     # low-degree rows: not worth it
+    finally:
+        _lib.reset_tuning()
+    scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double()
+    err = (y1.double() - y2.double()).abs()
+    assert bool((err <= 1e-5 * scale.clamp(min=1.0)).all())   # two fp32 summation orders

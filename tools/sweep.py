@@ -40,10 +40,20 @@ def main():
     ap.add_argument("--phases", default="0")
     ap.add_argument("--mode", default="sag")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--sources-mult", type=int, default=1,
+                    help="destination shard of a graph with this many times more source nodes (rect kernel)")
     args = ap.parse_args()
     ints = lambda s: [int(v) for v in s.split(",")]
     dev = torch.device("cuda:0")
-    g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
+    if args.sources_mult > 1:
+        c = graph.CONFIGS[args.config]
+        n = int(c["num_nodes"] * args.scale)
+        rp, ci = graph.powerlaw_shard(n, n * args.sources_mult, int(c["num_edges"] * args.scale * c.get("oversample", 1.0)),
+                                      c["max_degree"], seed=c["seed"], device=dev)
+        g = graph.CSRGraph(n, rp, ci, graph.degrees_from_rowptr(rp), int(ci.numel()), ci.numel() / n, 0.0)
+    else:
+        g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
+    n_src = g.num_nodes * args.sources_mult
     rp_cpu = g.row_pointers.cpu()
     print(f"# graph {args.config}: N={g.num_nodes} nnz={g.nnz}", flush=True)
     for ps in ints(args.ps):
@@ -51,13 +61,15 @@ def main():
         ppd, p2nd = pp.to(dev), p2n.to(dev)
         P = p2n.numel()
         for D in ints(args.dims):
-            X = torch.randn(g.num_nodes, D, device=dev)
-            out = torch.empty_like(X)
+            X = torch.randn(n_src, D, device=dev)
+            out = torch.empty(g.num_nodes, D, device=dev)
             bytes_ = g.nnz * (4 * D + 4) + g.num_nodes * (4 * D + 4) + P * 8
             for G, U, bpc, xcd, trust, ph in itertools.product(ints(args.G), ints(args.U), ints(args.bpc),
                                                                ints(args.xcd), ints(args.trust), ints(args.phases)):
                 _lib.set_tuning(G, U, bpc, xcd, trust, ph)
-                if args.mode == "sag":
+                if args.sources_mult > 1:
+                    fn = lambda: _lib.agg_rect(0, X, g.column_index, ppd, p2nd, g.num_nodes, ps, out=out)
+                elif args.mode == "sag":
                     fn = lambda: _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
                 elif args.mode == "gcn":
                     fn = lambda: _lib.agg_gcn(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
