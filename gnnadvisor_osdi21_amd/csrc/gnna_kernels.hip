@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <mutex>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "gnna.h"
@@ -81,6 +82,7 @@ struct AggParams {
     int32_t num_phases;
     int32_t phase_hi;
     int32_t acc_in;  // 1: add to the existing contents of Y instead of overwriting (no zero-fill)
+    const float *row_scale;  // MODE_GIN only: optional per-destination-row factor on top of eps
 };
 
 // ---- wave-level helpers ----------------------------------------------------------------
@@ -160,6 +162,30 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
     }
 }
 
+// ---- GCN pre-scaling: Xs[j, :] = deg[j] * X[j, :] -------------------------------------------
+// Lets the degree-weighted aggregation run as an unweighted gather of Xs with one multiply by
+// deg[i] at the flush (deg_i * sum_j deg_j x_j), instead of one extra 4-byte gather plus a
+// broadcast and a multiply per edge.
+__global__ void __launch_bounds__(kBlock)
+scale_rows_kernel(const float *__restrict__ X, const float *__restrict__ deg, float *__restrict__ Xs,
+                  int64_t rows, int D)
+{
+    const size_t total = (size_t)rows * (size_t)D;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if ((D & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xs)) & 15) == 0) {
+        const size_t n4 = total >> 2;
+        const int d4 = D >> 2;
+        for (size_t i = tid; i < n4; i += nthreads) {
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X) + i);
+            reinterpret_cast<f32x4 *>(Xs)[i] = v * deg[i / d4];
+        }
+    } else {
+        for (size_t i = tid; i < total; i += nthreads) Xs[i] = X[i] * deg[i / D];
+    }
+}
+
 // ---- main kernel --------------------------------------------------------------------------
 
 template <int VEC, int LPR, int MODE, int U, bool WIDE, bool PHASED>
@@ -232,6 +258,10 @@ agg_kernel(const AggParams p)
 
             float row_deg = 1.f;
             if constexpr (MODE == MODE_GCN) row_deg = p.deg_row[row];
+            float row_scale = p.eps;
+            if constexpr (MODE == MODE_GIN) {
+                if (p.row_scale) row_scale *= p.row_scale[row];
+            }
 
             int consumed_end = sb;
             for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
@@ -326,7 +356,7 @@ agg_kernel(const AggParams p)
 #pragma unroll
                 for (int k = 0; k < VEC; k++) {
                     float s = slot_reduce<LPR>(vget<VEC>(acc, k));
-                    if constexpr (MODE == MODE_GIN) s *= p.eps;
+                    if constexpr (MODE == MODE_GIN) s *= row_scale;
                     vset<VEC>(acc, k, s);
                 }
 
@@ -362,7 +392,7 @@ struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
     int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
-    std::map<hipStream_t, Workspace> ws;  // run cursors of the column-phased schedule, per stream
+    std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
 };
 constexpr int kFlagSlots = 1024;
 constexpr int kMaxDevices = 64;
@@ -399,10 +429,10 @@ int get_device_state(DeviceState **out)
 // Grow-only scratch buffer for `stream` (work on one stream is ordered, so one buffer per
 // stream is enough).  hipFree of the old buffer synchronises the device, which makes the
 // replacement safe; steady state performs no allocation.
-int get_workspace(DeviceState *ds, hipStream_t stream, size_t bytes, void **out)
+int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out)
 {
     std::lock_guard<std::mutex> lock(g_dev_mutex);
-    Workspace &w = ds->ws[stream];
+    Workspace &w = ds->ws[std::make_pair(stream, slot)];
     if (w.bytes < bytes) {
         if (w.ptr) (void)hipFree(w.ptr);
         w.ptr = nullptr;
@@ -602,6 +632,28 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
 
     const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
     const size_t x_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
+
+    // GCN: pre-scale the source rows once when every source row is gathered many times
+    p.row_scale = nullptr;
+    if (mode == MODE_GCN) {
+        const int64_t est_edges = num_parts * (int64_t)(tune.avg_degree > 0 ? std::min(partSize, tune.avg_degree) : partSize / 2 + 1);
+        const bool prescale = tune.gcn_prescale == 1 || (tune.gcn_prescale == 0 && est_edges >= 32 * num_in_rows);
+        if (prescale) {
+            void *xs = nullptr;
+            rc = get_workspace(ds, stream, 1, x_bytes, &xs);
+            if (rc != GNNA_OK) return rc;
+            int64_t sblocks = (int64_t)((x_bytes / 16 + kBlock - 1) / kBlock);
+            sblocks = std::max<int64_t>(1, std::min<int64_t>(sblocks, (int64_t)ds->num_cus * 8));
+            hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, input, degrees_in,
+                               static_cast<float *>(xs), num_in_rows, dim);
+            hipError_t es = hipGetLastError();
+            if (es != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "prescale launch: %s", hipGetErrorString(es));
+            p.X = static_cast<const float *>(xs);
+            p.row_scale = degrees;
+            p.eps = 1.f;
+            mode = MODE_GIN;  // unweighted gather + per-row factor at the flush
+        }
+    }
     const int phases = choose_phases(tune, x_bytes, num_parts, partSize);
     t_last_phases = phases;
     AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
@@ -610,7 +662,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     int64_t width = num_in_rows;
     if (phases > 1) {
         void *ws = nullptr;
-        rc = get_workspace(ds, stream, (size_t)num_parts * sizeof(int32_t), &ws);
+        rc = get_workspace(ds, stream, 0, (size_t)num_parts * sizeof(int32_t), &ws);
         if (rc != GNNA_OK) return rc;
         p.cursor = static_cast<int32_t *>(ws);
         p.num_phases = phases;

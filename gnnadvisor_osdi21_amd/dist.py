@@ -71,6 +71,13 @@ def _default_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_
                          degrees_out, degrees_in, epsilon, out, accumulate)
 
 
+def _default_hints(avg_degree: float, nonlocal_ids: bool) -> None:
+    """Tell libgnna what kind of CSR the next aggregation call works on (enables its
+    column-phased schedule for high-degree parts whose sources are scattered)."""
+    from . import _lib
+    _lib.set_tuning(avg_degree=max(1, int(avg_degree)), nonlocal_ids=1 if nonlocal_ids else 0)
+
+
 def split_local_remote(local_row_pointers: torch.Tensor, column_index: torch.Tensor, lo: int, hi: int):
     """Split a shard's CSR (global column ids) into the part whose sources lie in [lo, hi)
     (returned with ids rebased to the local block) and the rest (ids unchanged).
@@ -105,7 +112,8 @@ class ShardedAggregator:
     def __init__(self, local_row_pointers: torch.Tensor, column_index: torch.Tensor,
                  bounds: Sequence[int], partSize: int = 32, *, group=None, device=None,
                  aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None,
-                 overlap: bool = True, force_overlap: bool = False):
+                 overlap: bool = True, force_overlap: bool = False,
+                 hint_fn: Optional[Callable] = None, scattered_sources: bool = True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -116,6 +124,9 @@ class ShardedAggregator:
         self.rows_per_rank = max(1, max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world)))
         self.partSize = int(partSize)
         self.device = torch.device(device) if device is not None else column_index.device
+        # hints are only meaningful for the real kernel; an injected aggregate_fn gets none
+        self.hint_fn = hint_fn if hint_fn is not None else (_default_hints if aggregate_fn is None else None)
+        self.scattered_sources = bool(scattered_sources)
         self.aggregate_fn = aggregate_fn or _default_aggregate
         if build_part_fn is None:
             from . import _lib
@@ -134,9 +145,12 @@ class ShardedAggregator:
                                                         column_index.to(self.device), lo, hi)
             pp_l, p2n_l = build_part_fn(self.partSize, rp_l.cpu().contiguous())
             pp_r, p2n_r = build_part_fn(self.partSize, rp_r.cpu().contiguous())
+            self.avg_degree_local = ci_l.numel() / max(1, self.n_local)
+            self.avg_degree_remote = ci_r.numel() / max(1, self.n_local)
             self.local_part = (ci_l.contiguous(), pp_l.to(self.device), p2n_l.to(self.device))
             self.remote_part = (remap_columns_to_padded(ci_r, self.bounds, self.rows_per_rank).contiguous(),
                                 pp_r.to(self.device), p2n_r.to(self.device))
+        self.avg_degree_all = column_index.numel() / max(1, self.n_local)
         self._gather_buf: Optional[torch.Tensor] = None
         self._pad_buf: Optional[torch.Tensor] = None
         self._deg_all: Optional[torch.Tensor] = None
@@ -192,16 +206,22 @@ class ShardedAggregator:
             deg_in = self._deg_all
         if not self.overlap:
             X_all = self.gather_features(X_local)
+            if self.hint_fn:
+                self.hint_fn(self.avg_degree_all, self.scattered_sources)
             return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
                                      self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
         # overlapped: remote blocks travel while the local-source edges are aggregated
         X_all, work = self.gather_features(X_local, async_op=True)
         ci_l, pp_l, p2n_l = self.local_part
+        if self.hint_fn:
+            self.hint_fn(self.avg_degree_local, self.scattered_sources)
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
                                 degrees_local, degrees_local, epsilon, out)
         if work is not None:
             work.wait()
         ci_r, pp_r, p2n_r = self.remote_part
+        if self.hint_fn:
+            self.hint_fn(self.avg_degree_remote, self.scattered_sources)
         return self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
                                  degrees_local, deg_in, epsilon, out, accumulate=True)
 

@@ -152,6 +152,10 @@ typedef struct gnna_tuning {
     int avg_degree;       /* hint: average edges per destination row (0 = unknown)           */
     int nonlocal_ids;     /* hint: 1 = source ids of a row are scattered over the whole id
                              range (no community ordering), 0 = unknown / locality-ordered  */
+    int gcn_prescale;     /* gnna_agg_gcn_f32: 1 = scale the source rows by their degree norm
+                             once (library workspace) and gather unweighted, 2 = per-edge
+                             coefficients as the reference computes them, 0 = automatic
+                             (pre-scale when a source row is gathered >= ~32 times)          */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */

@@ -359,3 +359,17 @@ def test_automatic_phase_selection_follows_the_hints():
     scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double()
     err = (y1.double() - y2.double()).abs()
     assert bool((err <= 1e-5 * scale.clamp(min=1.0)).all())   # two fp32 summation orders
+
+
+@pytest.mark.parametrize("prescale", [1, 2])
+@pytest.mark.parametrize("dim,partSize,phases", [(64, 32, 1), (7, 4, 1), (100, 16, 3), (256, 64, 1)])
+def test_gcn_prescaled_and_per_edge_forms_agree_with_the_oracle(prescale, dim, partSize, phases):
+    """gnna_agg_gcn_f32 has two arithmetic forms: per-edge coefficients round(deg_i*deg_j)*x as the
+    reference computes them (gcn_prescale=2), and rows pre-scaled by deg_j with one multiply by
+    deg_i at the flush (gcn_prescale=1).  Both must satisfy the same bound against the oracle."""
+    g, X, pp, p2n = make_case(1200, 60000, dim, partSize, seed=dim * 3 + prescale, kind="powerlaw")
+    try:
+        _lib.set_tuning(column_phases=phases, gcn_prescale=prescale)
+        check_all_modes(g, X, pp, p2n, partSize, what=f"prescale={prescale} dim={dim} ps={partSize} ph={phases}")
+    finally:
+        _lib.reset_tuning()

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--xcd", default="1")
     ap.add_argument("--trust", default="0")
     ap.add_argument("--phases", default="0")
+    ap.add_argument("--prescale", default="0")
     ap.add_argument("--mode", default="sag")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--sources-mult", type=int, default=1,
@@ -64,9 +65,10 @@ def main():
             X = torch.randn(n_src, D, device=dev)
             out = torch.empty(g.num_nodes, D, device=dev)
             bytes_ = g.nnz * (4 * D + 4) + g.num_nodes * (4 * D + 4) + P * 8
-            for G, U, bpc, xcd, trust, ph in itertools.product(ints(args.G), ints(args.U), ints(args.bpc),
-                                                               ints(args.xcd), ints(args.trust), ints(args.phases)):
-                _lib.set_tuning(G, U, bpc, xcd, trust, ph)
+            for G, U, bpc, xcd, trust, ph, pre in itertools.product(ints(args.G), ints(args.U), ints(args.bpc),
+                                                                    ints(args.xcd), ints(args.trust), ints(args.phases),
+                                                                    ints(args.prescale)):
+                _lib.set_tuning(G, U, bpc, xcd, trust, ph, gcn_prescale=pre)
                 if args.sources_mult > 1:
                     fn = lambda: _lib.agg_rect(0, X, g.column_index, ppd, p2nd, g.num_nodes, ps, out=out)
                 elif args.mode == "sag":
@@ -77,7 +79,7 @@ def main():
                     fn = lambda: _lib.agg_gin(X, g.row_pointers, g.column_index, 0.5, ppd, p2nd, ps, 32, 4, out=out)
                 r = time_cfg(fn, args.steps)
                 ms = r["main_ms"]
-                print(json.dumps(dict(ps=ps, D=D, G=G, U=U, bpc=bpc, xcd=xcd, trust=trust, ph=ph, P=P,
+                print(json.dumps(dict(ps=ps, D=D, G=G, U=U, bpc=bpc, xcd=xcd, trust=trust, ph=ph, pre=pre, P=P,
                                       ms=round(ms, 4), pro_ms=round(r["prologue_ms"], 4),
                                       Gedges=round(g.nnz / ms / 1e6, 2),
                                       TBs=round(bytes_ / ms / 1e9, 3))), flush=True)
