@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgnna.so")
+LIB_PATH = os.environ.get("GNNA_LIB") or os.path.join(_HERE, "csrc", "libgnna.so")  # GNNA_LIB: A/B builds
 
 GNNA_OK = 0
 

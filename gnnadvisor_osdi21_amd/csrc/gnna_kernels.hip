@@ -51,10 +51,15 @@ constexpr int kXcds = 8;
 
 enum { MODE_SAG = 0, MODE_GCN = 1, MODE_GIN = 2 };
 
+// T: register type; M: the same vector as it sits in memory.  Feature rows are only 4-byte
+// aligned in general (row stride = D floats, D arbitrary), and gfx950 global_load/store_dwordx4
+// need no more than dword alignment, so M is declared with alignment 4.
 template <int VEC> struct VecOf;
-template <> struct VecOf<1> { typedef float T; };
-template <> struct VecOf<2> { typedef float T __attribute__((ext_vector_type(2))); };
-template <> struct VecOf<4> { typedef float T __attribute__((ext_vector_type(4))); };
+template <> struct VecOf<1> { typedef float T; typedef float M; };
+template <> struct VecOf<4> {
+    typedef float T __attribute__((ext_vector_type(4)));
+    typedef T M __attribute__((aligned(4)));
+};
 
 struct AggParams {
     const float *X;
@@ -193,6 +198,7 @@ __global__ void __launch_bounds__(kBlock)
 agg_kernel(const AggParams p)
 {
     typedef typename VecOf<VEC>::T VT;
+    typedef typename VecOf<VEC>::M MT;
     // byte offsets into X: 32-bit (SGPR base + VGPR offset addressing) unless X exceeds 4 GiB
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
     constexpr int RPI = kWave / LPR;  // neighbor rows per wave-wide load
@@ -265,9 +271,15 @@ agg_kernel(const AggParams p)
 
             int consumed_end = sb;
             for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
-                const int dcol = d0 + c * VEC;
-                const bool cvalid = dcol < D;
-                // lanes past the end of a ragged row re-read piece 0 (same cache line, never stored)
+                // lane c owns the VEC floats starting at `dcol`.  When D is not a multiple of VEC the
+                // last piece is shifted back to end exactly at D: it overlaps its predecessor by
+                // `shift` floats, which both lanes compute identically (so plain stores may
+                // overlap) and which only the predecessor adds atomically.
+                const int piece = d0 + c * VEC;
+                const bool cvalid = piece < D;
+                int dcol = piece, shift = 0;
+                if (VEC > 1 && piece + VEC > D && cvalid) { dcol = D - VEC; shift = piece - dcol; }
+                // lanes past the end of the row re-read piece 0 (same cache line, never stored)
                 const OffT col_off = (OffT)(cvalid ? dcol : d0) * (OffT)sizeof(float);
                 VT acc = vzero<VEC>();
 
@@ -284,13 +296,13 @@ agg_kernel(const AggParams p)
                             // full batch: U unpredicated wave-wide row loads back to back
 #pragma unroll
                             for (int u = 0; u < U; u++)
-                                v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
+                                v[u] = *reinterpret_cast<const MT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
                         } else {
 #pragma unroll
                             for (int u = 0; u < U; u++) {
                                 v[u] = vzero<VEC>();
                                 if (b + u * RPI + slot < nv)
-                                    v[u] = *reinterpret_cast<const VT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
+                                    v[u] = *reinterpret_cast<const MT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
                             }
                         }
                         if constexpr (MODE == MODE_GCN) {
@@ -364,11 +376,12 @@ agg_kernel(const AggParams p)
                     float *dst = p.Y + (size_t)row * D + dcol;
                     if (!use_atomic) {
                         // earlier phases' partial (streamed: keep the X slice resident in L2)
-                        if (accumulate) acc += __builtin_nontemporal_load(reinterpret_cast<const VT *>(dst));
-                        __builtin_nontemporal_store(acc, reinterpret_cast<VT *>(dst));
+                        if (accumulate) acc += __builtin_nontemporal_load(reinterpret_cast<const MT *>(dst));
+                        __builtin_nontemporal_store(acc, reinterpret_cast<MT *>(dst));
                     } else {
 #pragma unroll
-                        for (int k = 0; k < VEC; k++) unsafeAtomicAdd(dst + k, vget<VEC>(acc, k));
+                        for (int k = 0; k < VEC; k++)
+                            if (k >= shift) unsafeAtomicAdd(dst + k, vget<VEC>(acc, k));
                     }
                 }
             }
@@ -536,11 +549,8 @@ AggKernel pick_lpr(int lpr, int u, bool wide, bool phased)
 template <int MODE>
 AggKernel pick_vec(int vec, int lpr, int u, bool wide, bool phased)
 {
-    switch (vec) {
-    case 4: return pick_lpr<4, MODE>(lpr, u, wide, phased);
-    case 2: return pick_lpr<2, MODE>(lpr, u, wide, phased);
-    default: return pick_lpr<1, MODE>(lpr, u, wide, phased);
-    }
+    if (vec == 4) return pick_lpr<4, MODE>(lpr, u, wide, phased);
+    return pick_u<1, 4, MODE>(u, wide, phased);  // rows narrower than 4 floats: one lane per float
 }
 
 AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide, bool phased)
@@ -606,13 +616,12 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     if (num_parts == 0) return GNNA_OK;
     if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 1), stream);
 
-    // vector width / lane layout
-    const uintptr_t align_bits = reinterpret_cast<uintptr_t>(input) | reinterpret_cast<uintptr_t>(out);
-    int vec = 1;
-    if (dim % 4 == 0 && (align_bits & 15) == 0) vec = 4;
-    else if (dim % 2 == 0 && (align_bits & 7) == 0) vec = 2;
+    // vector width / lane layout: one lane per 4 consecutive floats of a row (dword-aligned
+    // dwordx4 accesses, ragged tail handled by the shifted last piece), LPR lanes per row
+    const int vec = dim >= 4 ? 4 : 1;
+    const int pieces = (dim + vec - 1) / vec;
     int lpr = 4;
-    while (lpr < 64 && lpr * vec < dim) lpr <<= 1;
+    while (lpr < 64 && lpr < pieces) lpr <<= 1;
 
     AggParams p;
     p.X = input; p.col = column_index; p.deg_row = degrees; p.deg_col = degrees_in; p.pp = part_pointers; p.p2n = part2Node;

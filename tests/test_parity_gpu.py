@@ -157,7 +157,7 @@ def test_non_canonical_partition_is_still_correct():
     assert_close_f64(ys, oracle.sag(Xn, ci2.numpy(), pp2.numpy(), p2n2.numpy()), what="shuffled sag vs oracle")
 
 
-def test_unaligned_views_take_the_scalar_path():
+def test_dword_aligned_views():
     g, X, pp, p2n = make_case(200, 5000, 64, 16, seed=21)
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     buf = torch.zeros(X.numel() + 1, device="cuda")
