@@ -252,6 +252,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "agg_kernel<4,16,SAG>", "kernel_ms": kern_ms,
+                         "kernel_launches_per_step": _lib.last_num_phases(),
+                         "kernel_ms_per_launch": kern_ms / max(1, _lib.last_num_phases()),
                          "prologue_ms": prof["prologue_ms"], "algorithmic_bytes": alg_bytes,
                          "model": "gather: nnz*(4D+4) + N*(4D+4) + P*8",
                          "compulsory_GBs": compulsory_bytes(nnz_local, n_local, n_src, D) / (kern_ms * 1e-3) / 1e9

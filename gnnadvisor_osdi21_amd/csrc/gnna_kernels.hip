@@ -27,6 +27,11 @@
 //   * a prologue kernel zero-fills `out` and checks that the partition is canonical
 //     (part2Node and partPtr non-decreasing); if it is not, every group is flushed with
 //     atomics, which is correct for any partition.
+//   * column phases (PHASED): the kernel is launched once per source-id range so that the
+//     gathered slice of X stays cache resident; every run keeps a cursor between launches.
+//   * degree-weighted (GCN) aggregation either applies round(deg_i*deg_j) per edge like the
+//     reference, or gathers rows pre-scaled by scale_rows_kernel and multiplies the row sum
+//     by deg_i at the flush.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
