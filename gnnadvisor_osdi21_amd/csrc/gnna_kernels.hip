@@ -111,12 +111,19 @@ __device__ __forceinline__ float fold_xor32(float v)
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// DPP row rotation by N lanes inside each 16-lane row (pure VALU, folds into the add).
+template <int N>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+
 // Sum over the 64/LPR lanes that share lane % LPR; result in every lane.
 template <int LPR>
 __device__ __forceinline__ float slot_reduce(float v)
 {
-    if constexpr (LPR <= 4) v += __shfl_xor(v, 4);
-    if constexpr (LPR <= 8) v += __shfl_xor(v, 8);
+    if constexpr (LPR <= 8) v += row_ror<8>(v);   // strides 8 and 4 stay inside a 16-lane DPP row
+    if constexpr (LPR <= 4) v += row_ror<4>(v);
     if constexpr (LPR <= 16) v = fold_xor16(v);
     if constexpr (LPR <= 32) v = fold_xor32(v);
     return v;
@@ -290,6 +297,19 @@ agg_kernel(const AggParams p)
 
                 // gathers `nv` neighbor rows whose ids sit in lanes 0..nv-1 of `id`
                 auto gather_tile = [&](const int id, const float dgn, const int nv) {
+                    if (nv <= RPI) {
+                        // short run (low-degree rows): one wave-wide load covers it
+                        const int nid = __shfl(id, slot);
+                        VT v0 = vzero<VEC>();
+                        if (slot < nv) v0 = *reinterpret_cast<const MT *>(xbase + (OffT)((OffT)nid * row_bytes + col_off));
+                        if constexpr (MODE == MODE_GCN) {
+                            VT tmp = v0 * (row_deg * __shfl(dgn, slot));
+                            acc += tmp;
+                        } else {
+                            acc += v0;
+                        }
+                        return;
+                    }
 #pragma unroll 1
                     for (int b = 0; b < nv; b += U * RPI) {
                         VT v[U];
