@@ -373,3 +373,29 @@ def test_gcn_prescaled_and_per_edge_forms_agree_with_the_oracle(prescale, dim, p
         check_all_modes(g, X, pp, p2n, partSize, what=f"prescale={prescale} dim={dim} ps={partSize} ph={phases}")
     finally:
         _lib.reset_tuning()
+
+
+def test_concurrent_streams_do_not_share_scratch():
+    """Two graphs aggregated back-to-back on two HIP streams with the column-phased schedule
+    (per-stream cursor workspace, per-call validation flag): results must not interfere."""
+    cases = []
+    for seed, n, e in ((1, 4000, 300000), (2, 2500, 150000)):
+        g, X, pp, p2n = make_case(n, e, 64, 16, seed=seed, kind="powerlaw")
+        ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+        cases.append((dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n), ref))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    try:
+        _lib.set_tuning(column_phases=4)
+        torch.cuda.synchronize()
+        for rep in range(6):
+            for k in (0, 1):
+                with torch.cuda.stream(streams[k]):
+                    a, _ = cases[k]
+                    outs[k].append(_lib.sag(*a, 16, 32, 4))
+        torch.cuda.synchronize()
+    finally:
+        _lib.reset_tuning()
+    for k in (0, 1):
+        for y in outs[k]:
+            assert_close_f64(y.cpu().numpy(), cases[k][1], what=f"stream {k}")
