@@ -177,6 +177,7 @@ CONFIGS = {
     "citeseer-like": dict(num_nodes=3327, num_edges=9104, max_degree=99, feat=3703, hidden=16, classes=6, seed=2),
     "reddit-like": dict(num_nodes=232965, num_edges=114615892, max_degree=21657, feat=602, hidden=64, classes=41, seed=3, oversample=1.0825),
     "products-like": dict(num_nodes=2449029, num_edges=123718280, max_degree=17481, feat=100, hidden=64, classes=47, seed=4, oversample=1.0235),
+    "papers100M-like": dict(num_nodes=111059956, num_edges=1615685872, max_degree=50000, feat=128, hidden=128, classes=172, seed=5, oversample=1.0),
     "amazon0505-like": dict(num_nodes=410236, num_edges=4878874, max_degree=2760, feat=96, hidden=16, classes=22, seed=6, oversample=1.019),
 }
 
