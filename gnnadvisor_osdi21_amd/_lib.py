@@ -40,7 +40,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases")
+           "gnna_last_num_phases", "gnna_sddmm_f32")
 
 
 def load() -> ctypes.CDLL:
@@ -86,6 +86,9 @@ def load() -> ctypes.CDLL:
     L.gnna_reorder_rcm_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p]
     L.gnna_last_num_phases.restype = ctypes.c_int
+    L.gnna_sddmm_f32.restype = ctypes.c_int
+    L.gnna_sddmm_f32.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                                        ctypes.c_int, ctypes.c_void_p]
     L.gnna_profile_begin.restype = ctypes.c_int
     L.gnna_profile_begin.argtypes = [ctypes.c_int]
     L.gnna_profile_end.restype = ctypes.c_int
@@ -254,4 +257,21 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
                                         part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
                                         int(num_out_rows), X.shape[1], part2Node.numel(), int(partSize),
                                         1 if accumulate else 0, _stream(X.device)))
+    return out
+
+
+def sddmm(dst_feat, src_feat, column_index, part_pointers, part2Node, partSize=32, out=None):
+    """edge_out[e] = <dst_feat[row(e)], src_feat[column_index[e]]> over the neighbor-group partition
+    (build-defined extension, see include/gnna.h)."""
+    if not dst_feat.is_cuda:
+        raise GnnaError("sddmm needs device tensors: there is no CPU path in libgnna")
+    assert dst_feat.dtype == torch.float32 and src_feat.dtype == torch.float32
+    assert dst_feat.is_contiguous() and src_feat.is_contiguous() and dst_feat.shape[1] == src_feat.shape[1]
+    if out is None:
+        out = torch.zeros(column_index.numel(), dtype=torch.float32, device=dst_feat.device)
+    with torch.cuda.device(dst_feat.device):
+        _check(load().gnna_sddmm_f32(dst_feat.data_ptr(), src_feat.data_ptr(), column_index.data_ptr(),
+                                     part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
+                                     dst_feat.shape[0], src_feat.shape[0], dst_feat.shape[1], part2Node.numel(),
+                                     int(partSize), _stream(dst_feat.device)))
     return out

@@ -136,6 +136,17 @@ GNNA_API int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows
                       float *out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
                       int accumulate, void *stream);
 
+/* SDDMM over the same neighbor-group partition -- a build-defined extension: the reference
+ * contains no SDDMM kernel, BASELINE.json's north star asks for one.
+ *   edge_out[e] = < dst_feat[part2Node[p], :], src_feat[column_index[e], :] >
+ * for every group p and every e in [part_pointers[p], part_pointers[p+1]); edge_out is indexed like
+ * column_index.  dim >= 4.  Parity is defined by the dense formula only (no reference behaviour).
+ */
+GNNA_API int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const int32_t *column_index,
+                   const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
+                   int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
+                   void *stream);
+
 /* ---- scheduling knobs (not part of the reference API; used by the tuner and bench) ----
  * Any field <= 0 (or < 0 where 0 is meaningful) keeps the built-in choice.
  */

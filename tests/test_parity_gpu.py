@@ -399,3 +399,27 @@ def test_concurrent_streams_do_not_share_scratch():
     for k in (0, 1):
         for y in outs[k]:
             assert_close_f64(y.cpu().numpy(), cases[k][1], what=f"stream {k}")
+
+
+@pytest.mark.parametrize("dim", [4, 5, 7, 16, 32, 41, 64, 100, 128, 256, 300])
+@pytest.mark.parametrize("partSize", [1, 32])
+def test_sddmm_extension_matches_dense_formula(dim, partSize):
+    """Build-defined SDDMM over the neighbor-group partition (not in the reference; parity =
+    the dense fp64 formula): edge_out[e] = <A[row(e)], B[col(e)]>."""
+    g, _, pp, p2n = make_case(700, 20000, dim, partSize, seed=dim + partSize, kind="powerlaw")
+    gen = torch.Generator().manual_seed(dim)
+    A = torch.randn(g.num_nodes, dim, generator=gen)
+    B = torch.randn(g.num_nodes, dim, generator=gen)
+    out = _lib.sddmm(A.cuda(), B.cuda(), g.column_index.cuda(), pp.cuda(), p2n.cuda(), partSize)
+    ref = oracle.np_sddmm(A.numpy(), B.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+    rows = np.repeat(np.arange(g.num_nodes), np.diff(g.row_pointers.numpy()))
+    scale = np.einsum("ed,ed->e", np.abs(A.numpy().astype(np.float64))[rows],
+                      np.abs(B.numpy().astype(np.float64))[g.column_index.numpy()])
+    assert_close_f64(out.cpu().numpy(), ref, what=f"sddmm dim={dim} ps={partSize}", scale=scale, rtol=1e-5)
+    # rectangular: destination and source sides of different height
+    A2 = A[:300].contiguous()
+    rp2 = g.row_pointers[:301]
+    pp2, p2n2 = _lib.build_part(partSize, rp2.contiguous())
+    ci2 = g.column_index[: int(rp2[-1])].contiguous()
+    out2 = _lib.sddmm(A2.cuda(), B.cuda(), ci2.cuda(), pp2.cuda(), p2n2.cuda(), partSize)
+    assert_close_f64(out2.cpu().numpy(), ref[: int(rp2[-1])], what="sddmm rect", scale=scale[: int(rp2[-1])], rtol=1e-5)

@@ -14,10 +14,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnnadvisor_osdi21_amd import _lib, graph  # noqa: E402
 
 
-def time_cfg(fn, steps=10, warmup=3):
+def time_cfg(fn, steps=10, warmup=3, events=False):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if events:   # kernels without library-side event hooks (sddmm): torch events on the current stream
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return dict(main_ms=a.elapsed_time(b) / steps, prologue_ms=0.0, calls=steps)
     _lib.profile_begin(steps)
     for _ in range(steps):
         fn()
@@ -73,11 +81,14 @@ def main():
                     fn = lambda: _lib.agg_rect(0, X, g.column_index, ppd, p2nd, g.num_nodes, ps, out=out)
                 elif args.mode == "sag":
                     fn = lambda: _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
+                elif args.mode == "sddmm":
+                    eo = torch.empty(g.nnz, device=dev)
+                    fn = lambda: _lib.sddmm(X, X, g.column_index, ppd, p2nd, ps, out=eo)
                 elif args.mode == "gcn":
                     fn = lambda: _lib.agg_gcn(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
                 else:
                     fn = lambda: _lib.agg_gin(X, g.row_pointers, g.column_index, 0.5, ppd, p2nd, ps, 32, 4, out=out)
-                r = time_cfg(fn, args.steps)
+                r = time_cfg(fn, args.steps, events=(args.mode == "sddmm"))
                 ms = r["main_ms"]
                 print(json.dumps(dict(ps=ps, D=D, G=G, U=U, bpc=bpc, xcd=xcd, trust=trust, ph=ph, pre=pre, P=P,
                                       ms=round(ms, 4), pro_ms=round(r["prologue_ms"], 4),
