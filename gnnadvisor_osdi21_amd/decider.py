@@ -202,9 +202,12 @@ class inputProperty(object):
         self.loads_in_flight = 4
         # graph hints for libgnna's column-phased schedule (gnna_tuning.avg_degree / nonlocal_ids):
         # it pays only when a row's source ids are scattered over the whole id range.  A random
-        # labelling has avgEdgeSpan ~ N/3; community orderings are far below N/8.
+        # labelling has avgEdgeSpan ~ N/3.  Measured on Reddit-like graphs with a fraction f of
+        # window-local edges (span ~ (1-f) N/3): f = 0 -> 4 phases +49 %, f = 0.25 -> +13 % (2 phases) /
+        # 0 % (4), f = 0.5 -> -11 % / -42 %, f = 0.75 -> -39 % / -66 %; so only (nearly) random
+        # labellings qualify: span > 0.28 N.
         self.avg_degree_hint = max(1, int(self.avgNodeDegree))
-        self.nonlocal_ids_hint = 1 if self.avgEdgeSpan > self.num_nodes / 8.0 else 0
+        self.nonlocal_ids_hint = 1 if self.avgEdgeSpan > 0.28 * self.num_nodes else 0
 
     # ------------------------------------------------------------------ per-layer switches
     def set_input(self):
