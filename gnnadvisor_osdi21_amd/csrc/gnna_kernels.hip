@@ -291,8 +291,9 @@ agg_kernel(const AggParams p)
                 const bool cvalid = piece < D;
                 int dcol = piece, shift = 0;
                 if (VEC > 1 && piece + VEC > D && cvalid) { dcol = D - VEC; shift = piece - dcol; }
-                // lanes past the end of the row re-read piece 0 (same cache line, never stored)
-                const OffT col_off = (OffT)(cvalid ? dcol : d0) * (OffT)sizeof(float);
+                // lanes past the end of the row re-read this sweep's first piece (same cache lines, never
+                // stored); min() keeps that read inside the row when the first piece is the shifted one
+                const OffT col_off = (OffT)(cvalid ? dcol : (d0 + VEC <= D ? d0 : D - VEC)) * (OffT)sizeof(float);
                 VT acc = vzero<VEC>();
 
                 // gathers `nv` neighbor rows whose ids sit in lanes 0..nv-1 of `id`
@@ -401,7 +402,16 @@ agg_kernel(const AggParams p)
                     float *dst = p.Y + (size_t)row * D + dcol;
                     if (!use_atomic) {
                         // earlier phases' partial (streamed: keep the X slice resident in L2)
-                        if (accumulate) acc += __builtin_nontemporal_load(reinterpret_cast<const MT *>(dst));
+                        if (accumulate) {
+                            const VT prev = __builtin_nontemporal_load(reinterpret_cast<const MT *>(dst));
+#pragma unroll
+                            for (int k = 0; k < VEC; k++) {
+                                // a shifted first piece of a later dimension sweep overlaps floats that the
+                                // previous sweep has already read-modify-written: keep those as they are
+                                const bool done = VEC > 1 && c == 0 && k < shift;
+                                vset<VEC>(acc, k, done ? vget<VEC>(prev, k) : vget<VEC>(acc, k) + vget<VEC>(prev, k));
+                            }
+                        }
                         __builtin_nontemporal_store(acc, reinterpret_cast<MT *>(dst));
                     } else {
 #pragma unroll
@@ -495,7 +505,7 @@ sddmm_kernel(const SddmmParams p)
                 const bool cvalid = piece < D;
                 int dcol = piece, shift = 0;
                 if (piece + VEC > D && cvalid) { dcol = D - VEC; shift = piece - dcol; }
-                const OffT col_off = (OffT)(cvalid ? dcol : d0) * (OffT)sizeof(float);
+                const OffT col_off = (OffT)(cvalid ? dcol : (d0 + VEC <= D ? d0 : D - VEC)) * (OffT)sizeof(float);
                 // destination row piece; components that overlap the previous piece (ragged D) and
                 // lanes past the row end are zeroed so that they do not contribute to the dot product
                 VT a = vzero<VEC>();

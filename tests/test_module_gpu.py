@@ -206,7 +206,12 @@ def test_rect_accumulate_local_plus_remote_equals_whole():
     including shards with no remote or no local edges (num_parts == 0 with accumulate)."""
     from gnnadvisor_osdi21_amd.dist import remap_columns_to_padded, shard_csr, split_local_remote
     g = graph.powerlaw_graph(900, 30000, 200, seed=33)
-    D, ps = 64, 8
+    _check_local_plus_remote(g, 64, 8)
+    _check_local_plus_remote(g, 257, 8)      # two dimension sweeps with a shifted (ragged) last piece
+
+
+def _check_local_plus_remote(g, D, ps):
+    from gnnadvisor_osdi21_amd.dist import shard_csr, split_local_remote
     X = torch.randn(g.num_nodes, D, generator=torch.Generator().manual_seed(5))
     full = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
     full_gin = oracle.csr_f64(2, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy(), None, 0.5)
