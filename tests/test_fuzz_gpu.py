@@ -1,0 +1,110 @@
+"""Seeded randomised sweeps over the less-travelled entry points (rectangular / accumulate,
+SDDMM, the torch module's forward/backward).  GNNA_TEST_CASES / GNNA_TEST_SEED scale them up for
+soak runs; the defaults keep the suite fast."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib, graph, load_extension
+from util import assert_close_f64
+
+pytestmark = pytest.mark.gpu
+CASES = int(os.environ.get("GNNA_TEST_CASES", "12"))
+SEED = int(os.environ.get("GNNA_TEST_SEED", "7"))
+DIMS = [1, 3, 4, 6, 16, 31, 64, 100, 129, 256, 257, 300]
+
+
+def _rand_tuning(rng):
+    _lib.set_tuning(int(rng.integers(1, 64)), int(rng.choice([4, 8, 16])), int(rng.choice([0, 0, 2])),
+                    int(rng.integers(0, 2)), 0, int(rng.choice([1, 1, 2, 3, 7])), gcn_prescale=int(rng.choice([0, 1, 2])))
+
+
+def test_rect_accumulate_random():
+    """out = A_loc X_loc (overwrite) then += A_rem X_all (accumulate), random splits, phases, widths."""
+    from gnnadvisor_osdi21_amd.dist import shard_csr, split_local_remote
+    rng = np.random.default_rng(SEED)
+    try:
+        for k in range(CASES):
+            n = int(rng.integers(2, 900)); e = int(rng.integers(0, 30 * n)); D = int(rng.choice(DIMS))
+            ps = int(rng.choice([1, 3, 8, 32, 64])); mode = int(rng.choice([0, 1, 2])); eps = float(rng.uniform(-1, 2))
+            g = graph.uniform_graph(n, e, seed=SEED * 1000 + k)
+            lo = int(rng.integers(0, n)); hi = int(rng.integers(lo + 1, n + 1))
+            X = torch.randn(n, D, generator=torch.Generator().manual_seed(k))
+            ref = oracle.csr_f64(mode, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), eps)[lo:hi]
+            scale = oracle.csr_f64(mode, np.abs(X.numpy()), g.row_pointers.numpy(), g.column_index.numpy(),
+                                   g.degrees.numpy(), abs(eps))[lo:hi]
+            rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+            rp_l, ci_l, rp_r, ci_r = split_local_remote(rp, ci, lo, hi)
+            pp_l, p2n_l = _lib.build_part(ps, rp_l); pp_r, p2n_r = _lib.build_part(ps, rp_r)
+            Xd = X.cuda(); degd = g.degrees.cuda()
+            out = torch.full((hi - lo, D), float("nan"), device="cuda")
+            _rand_tuning(rng)
+            _lib.agg_rect(mode, Xd[lo:hi].contiguous(), ci_l.cuda(), pp_l.cuda(), p2n_l.cuda(), hi - lo, ps,
+                          degrees_out=degd[lo:hi].contiguous(), degrees_in=degd[lo:hi].contiguous(), epsilon=eps, out=out)
+            _rand_tuning(rng)
+            _lib.agg_rect(mode, Xd, ci_r.cuda(), pp_r.cuda(), p2n_r.cuda(), hi - lo, ps,
+                          degrees_out=degd[lo:hi].contiguous(), degrees_in=degd, epsilon=eps, out=out, accumulate=True)
+            assert_close_f64(out.cpu().numpy(), ref, scale=scale,
+                             what=f"case {k}: n={n} e={e} D={D} ps={ps} mode={mode} [{lo},{hi}) {_lib.get_tuning()}")
+    finally:
+        _lib.reset_tuning()
+
+
+def test_sddmm_random():
+    rng = np.random.default_rng(SEED + 1)
+    try:
+        for k in range(CASES):
+            n = int(rng.integers(1, 700)); e = int(rng.integers(0, 30 * n)); D = int(rng.choice([d for d in DIMS if d >= 4]))
+            ps = int(rng.choice([1, 4, 32, 100]))
+            g = graph.uniform_graph(n, e, seed=SEED * 2000 + k)
+            gen = torch.Generator().manual_seed(k)
+            A = torch.randn(n, D, generator=gen); B = torch.randn(n, D, generator=gen)
+            pp, p2n = _lib.build_part(ps, g.row_pointers)
+            _lib.set_tuning(groups_per_chunk=int(rng.integers(1, 64)))
+            out = _lib.sddmm(A.cuda(), B.cuda(), g.column_index.cuda(), pp.cuda(), p2n.cuda(), ps)
+            ref = oracle.np_sddmm(A.numpy(), B.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+            rows = np.repeat(np.arange(n), np.diff(g.row_pointers.numpy()))
+            scale = np.einsum("ed,ed->e", np.abs(A.numpy().astype(np.float64))[rows],
+                              np.abs(B.numpy().astype(np.float64))[g.column_index.numpy()])
+            assert_close_f64(out.cpu().numpy(), ref, scale=scale, rtol=1e-5, what=f"sddmm case {k}: n={n} e={e} D={D} ps={ps}")
+    finally:
+        _lib.reset_tuning()
+
+
+def test_module_forward_backward_random():
+    GNNA = load_extension()
+    rng = np.random.default_rng(SEED + 2)
+    try:
+        for k in range(max(4, CASES // 2)):
+            n = int(rng.integers(2, 600)); e = int(rng.integers(0, 25 * n))
+            fin = int(rng.choice([3, 16, 50, 129])); fout = int(rng.choice([1, 7, 16, 41, 64]))
+            ps = int(rng.choice([2, 16, 32]))
+            g = graph.uniform_graph(n, e, seed=SEED * 3000 + k)
+            gen = torch.Generator().manual_seed(k)
+            X = torch.randn(n, fin, generator=gen); W = torch.randn(fin, fout, generator=gen) * 0.3
+            dY = torch.randn(n, fout, generator=gen)
+            pp, p2n = GNNA.build_part(ps, g.row_pointers)
+            a = [t.cuda() for t in (g.row_pointers, g.column_index, g.degrees, pp, p2n)]
+            ci, deg, ppn, p2nn = g.column_index.numpy(), g.degrees.numpy(), pp.numpy(), p2n.numpy()
+            _rand_tuning(rng)
+            y = GNNA.forward(X.cuda(), W.cuda(), *a, ps, 32, 4)[0].cpu().numpy()
+            ry = oracle.np_forward(X.numpy(), W.numpy(), ci, deg, ppn, p2nn)
+            np.testing.assert_allclose(y, ry, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ry).max()), err_msg=f"fwd case {k}")
+            dX, dW = GNNA.backward(dY.cuda(), X.cuda(), W.cuda(), *a, ps, 32, 4)
+            rdX, rdW = oracle.np_backward(dY.numpy(), X.numpy(), W.numpy(), ci, deg, ppn, p2nn)
+            np.testing.assert_allclose(dX.cpu().numpy(), rdX, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdX).max()))
+            np.testing.assert_allclose(dW.cpu().numpy(), rdW, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdW).max()))
+            ag = [a[0], a[1], 0.5, a[3], a[4]]
+            yo, t = GNNA.forward_gin(X.cuda(), W.cuda(), *ag, ps, 32, 4)
+            ryo, rt = oracle.np_forward_gin(X.numpy(), W.numpy(), ci, 0.5, ppn, p2nn)
+            np.testing.assert_allclose(t.cpu().numpy(), rt, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rt).max()))
+            np.testing.assert_allclose(yo.cpu().numpy(), ryo, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ryo).max()))
+            dXg, dWg = GNNA.backward_gin(dY.cuda(), t, W.cuda(), *ag, ps, 32, 4)
+            rdXg, rdWg = oracle.np_backward_gin(dY.numpy(), rt, W.numpy(), ci, 0.5, ppn, p2nn)
+            np.testing.assert_allclose(dXg.cpu().numpy(), rdXg, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdXg).max()))
+            np.testing.assert_allclose(dWg.cpu().numpy(), rdWg, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdWg).max()))
+    finally:
+        _lib.reset_tuning()
