@@ -390,33 +390,72 @@ agg_kernel(const AggParams p)
                     }
                 }
 
-                // fold the RPI slots; every slot then holds the row's partial sum
-#pragma unroll
-                for (int k = 0; k < VEC; k++) {
-                    float s = slot_reduce<LPR>(vget<VEC>(acc, k));
-                    if constexpr (MODE == MODE_GIN) s *= row_scale;
-                    vset<VEC>(acc, k, s);
-                }
-
-                if (slot == 0 && cvalid) {
-                    float *dst = p.Y + (size_t)row * D + dcol;
-                    if (!use_atomic) {
-                        // earlier phases' partial (streamed: keep the X slice resident in L2)
-                        if (accumulate) {
-                            const VT prev = __builtin_nontemporal_load(reinterpret_cast<const MT *>(dst));
-#pragma unroll
-                            for (int k = 0; k < VEC; k++) {
-                                // a shifted first piece of a later dimension sweep overlaps floats that the
-                                // previous sweep has already read-modify-written: keep those as they are
-                                const bool done = VEC > 1 && c == 0 && k < shift;
-                                vset<VEC>(acc, k, done ? vget<VEC>(prev, k) : vget<VEC>(acc, k) + vget<VEC>(prev, k));
+                if constexpr (VEC == 4 && LPR <= 16) {
+                    // Fold the RPI slots as a reduce-scatter: instead of summing all four components
+                    // across the slots (8 lane swaps), the halves / rows exchange the components they
+                    // do not keep.  permlane32_swap(x, z) leaves {x_lo, z_lo} | {x_hi, z_hi}: their
+                    // sum holds x (lanes 0-31) and z (lanes 32-63) folded over lane, lane+32; the
+                    // same for (y, w); permlane16_swap of the two results then leaves row r of the
+                    // wave with component r.  3 swaps + 3 adds, and every lane ends with ONE float:
+                    // component lane>>4 of piece lane%LPR (narrow rows: the slots sharing a 16-lane
+                    // row are folded with DPP rotations afterwards).
+                    float px, qy;
+                    {
+                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[2]), false, false);
+                        px = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                        r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[1]), __float_as_uint(acc[3]), false, false);
+                        qy = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    }
+                    float val;
+                    {
+                        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(px), __float_as_uint(qy), false, false);
+                        val = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                    }
+                    if constexpr (LPR <= 8) val += row_ror<8>(val);
+                    if constexpr (LPR <= 4) val += row_ror<4>(val);
+                    if constexpr (MODE == MODE_GIN) val *= row_scale;
+                    const int k = lane >> 4;  // component held by this lane
+                    if ((lane & 15) < LPR && cvalid) {
+                        float *dst = p.Y + (size_t)row * D + dcol + k;
+                        if (!use_atomic) {
+                            if (accumulate) {
+                                // earlier phases' partial (streamed: keep the X slice resident in L2); a shifted
+                                // first piece of a later dimension sweep overlaps floats that the previous sweep
+                                // has already read-modify-written: keep those as they are
+                                const float prev = __builtin_nontemporal_load(dst);
+                                val = (c == 0 && k < shift) ? prev : val + prev;
                             }
+                            __builtin_nontemporal_store(val, dst);
+                        } else if (k >= shift) {
+                            unsafeAtomicAdd(dst, val);
                         }
-                        __builtin_nontemporal_store(acc, reinterpret_cast<MT *>(dst));
-                    } else {
+                    }
+                } else {
+                    // fold the RPI slots; every slot then holds the row's partial sum
 #pragma unroll
-                        for (int k = 0; k < VEC; k++)
-                            if (k >= shift) unsafeAtomicAdd(dst + k, vget<VEC>(acc, k));
+                    for (int k = 0; k < VEC; k++) {
+                        float s = slot_reduce<LPR>(vget<VEC>(acc, k));
+                        if constexpr (MODE == MODE_GIN) s *= row_scale;
+                        vset<VEC>(acc, k, s);
+                    }
+
+                    if (slot == 0 && cvalid) {
+                        float *dst = p.Y + (size_t)row * D + dcol;
+                        if (!use_atomic) {
+                            if (accumulate) {
+                                const VT prev = __builtin_nontemporal_load(reinterpret_cast<const MT *>(dst));
+#pragma unroll
+                                for (int k = 0; k < VEC; k++) {
+                                    const bool done = VEC > 1 && c == 0 && k < shift;
+                                    vset<VEC>(acc, k, done ? vget<VEC>(prev, k) : vget<VEC>(acc, k) + vget<VEC>(prev, k));
+                                }
+                            }
+                            __builtin_nontemporal_store(acc, reinterpret_cast<MT *>(dst));
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < VEC; k++)
+                                if (k >= shift) unsafeAtomicAdd(dst + k, vget<VEC>(acc, k));
+                        }
                     }
                 }
             }
