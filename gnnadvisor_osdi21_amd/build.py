@@ -26,8 +26,9 @@ EXT = os.path.join(PKG, "GNNAdvisor.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-LIB_SOURCES = [os.path.join(CSRC, "gnna_kernels.hip"), os.path.join(CSRC, "gnna_host.cpp")]
-LIB_DEPS = LIB_SOURCES + [os.path.join(CSRC, "gnna_internal.h"), os.path.join(INCLUDE, "gnna.h")]
+LIB_SOURCES = [os.path.join(CSRC, f) for f in ("gnna_agg.hip", "gnna_sddmm.hip", "gnna_runtime.hip", "gnna_host.cpp")]
+LIB_DEPS = LIB_SOURCES + [os.path.join(CSRC, "gnna_internal.h"), os.path.join(CSRC, "gnna_device.h"),
+                           os.path.join(INCLUDE, "gnna.h")]
 EXT_SOURCES = [os.path.join(CSRC, "gnna_torch.cpp")]
 EXT_DEPS = EXT_SOURCES + [os.path.join(INCLUDE, "gnna.h")]
 

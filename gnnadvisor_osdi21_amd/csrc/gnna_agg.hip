@@ -1,4 +1,4 @@
-// gnna_kernels.hip -- CDNA4 (gfx950) neighbor-group aggregation kernels + C-ABI launchers.
+// gnna_agg.hip -- CDNA4 (gfx950) neighbor-group aggregation kernels + C-ABI launchers.
 //
 // Replaces the five CUDA kernels of the reference (GNNAdvisor/GNNConv/GNNAdvisor_kernel.cu:
 // SAG :186-259, GCN fwd :324-415, GCN bwd :478-552, GIN fwd :620-689, GIN bwd :749-814) with
@@ -27,44 +27,18 @@
 //   * a prologue kernel zero-fills `out` and checks that the partition is canonical
 //     (part2Node and partPtr non-decreasing); if it is not, every group is flushed with
 //     atomics, which is correct for any partition.
-//   * column phases (PHASED): the kernel is launched once per source-id range so that the
-//     gathered slice of X stays cache resident; every run keeps a cursor between launches.
-//   * degree-weighted (GCN) aggregation either applies round(deg_i*deg_j) per edge like the
-//     reference, or gathers rows pre-scaled by scale_rows_kernel and multiplies the row sum
-//     by deg_i at the flush.
-#include <hip/hip_runtime.h>
+//   * column phases (PHASED): the kernel is launched once per source-id range so that the#include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
-#include <map>
 #include <cstdint>
 #include <cstdio>
-#include <mutex>
-#include <type_traits>
-#include <utility>
-#include <vector>
 
 #include "gnna.h"
+#include "gnna_device.h"
 #include "gnna_internal.h"
 
+namespace gnna {
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kBlock = 256;
-constexpr int kWavesPerBlock = kBlock / kWave;
-constexpr int kXcds = 8;
-
-enum { MODE_SAG = 0, MODE_GCN = 1, MODE_GIN = 2 };
-
-// T: register type; M: the same vector as it sits in memory.  Feature rows are only 4-byte
-// aligned in general (row stride = D floats, D arbitrary), and gfx950 global_load/store_dwordx4
-// need no more than dword alignment, so M is declared with alignment 4.
-template <int VEC> struct VecOf;
-template <> struct VecOf<1> { typedef float T; typedef float M; };
-template <> struct VecOf<4> {
-    typedef float T __attribute__((ext_vector_type(4)));
-    typedef T M __attribute__((aligned(4)));
-};
 
 struct AggParams {
     const float *X;
@@ -94,60 +68,6 @@ struct AggParams {
     int32_t acc_in;  // 1: add to the existing contents of Y instead of overwriting (no zero-fill)
     const float *row_scale;  // MODE_GIN only: optional per-destination-row factor on top of eps
 };
-
-// ---- wave-level helpers ----------------------------------------------------------------
-
-__device__ __forceinline__ float fold_xor16(float v)
-{
-    unsigned u = __float_as_uint(v);
-    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-__device__ __forceinline__ float fold_xor32(float v)
-{
-    unsigned u = __float_as_uint(v);
-    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-// DPP row rotation by N lanes inside each 16-lane row (pure VALU, folds into the add).
-template <int N>
-__device__ __forceinline__ float row_ror(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
-}
-
-// Sum over the 64/LPR lanes that share lane % LPR; result in every lane.
-template <int LPR>
-__device__ __forceinline__ float slot_reduce(float v)
-{
-    if constexpr (LPR <= 8) v += row_ror<8>(v);   // strides 8 and 4 stay inside a 16-lane DPP row
-    if constexpr (LPR <= 4) v += row_ror<4>(v);
-    if constexpr (LPR <= 16) v = fold_xor16(v);
-    if constexpr (LPR <= 32) v = fold_xor32(v);
-    return v;
-}
-
-template <int VEC>
-__device__ __forceinline__ typename VecOf<VEC>::T vzero()
-{
-    typename VecOf<VEC>::T z;
-    if constexpr (VEC == 1) z = 0.f; else z = (typename VecOf<VEC>::T)(0.f);
-    return z;
-}
-
-template <int VEC>
-__device__ __forceinline__ float vget(const typename VecOf<VEC>::T &v, int k)
-{
-    if constexpr (VEC == 1) return v; else return v[k];
-}
-
-template <int VEC>
-__device__ __forceinline__ void vset(typename VecOf<VEC>::T &v, int k, float x)
-{
-    if constexpr (VEC == 1) v = x; else v[k] = x;
-}
 
 // ---- prologue: zero-fill + partition validation ------------------------------------------
 
@@ -469,186 +389,7 @@ agg_kernel(const AggParams p)
     }
 }
 
-// ---- SDDMM over the neighbor-group partition (build-defined extension) -------------------------
-// edge_out[e] = < dst_feat[row(e), :], src_feat[colidx[e], :] >  for every edge e of the partition.
-// The reference has no SDDMM kernel (SURVEY.md "three things" #1); BASELINE's north star asks
-// for one over the same partition, so this follows the aggregation kernel's shape: a wavefront
-// owns a chunk of groups, a run keeps the destination row's piece in registers, source rows are
-// gathered RPI per wave-wide load, and the LPR lanes of a slot fold their 4-float partial dot
-// products with DPP (quad_perm / row_half_mirror / row_mirror) and permlane swaps.
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-
-// Sum over the LPR consecutive lanes of a slot; result in every lane of the slot.
-template <int LPR>
-__device__ __forceinline__ float lane_group_sum(float v)
-{
-    v += dpp_move<0xB1>(v);                          // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);                          // quad_perm [2,3,0,1]
-    if constexpr (LPR >= 8) v += dpp_move<0x141>(v);  // row_half_mirror: the other quad of the 8
-    if constexpr (LPR >= 16) v += dpp_move<0x140>(v); // row_mirror: the other half of the 16
-    if constexpr (LPR >= 32) v = fold_xor16(v);
-    if constexpr (LPR >= 64) v = fold_xor32(v);
-    return v;
-}
-
-struct SddmmParams {
-    const float *A;       // [n_out, D] destination-side features
-    const float *B;       // [n_in, D] source-side features
-    const int32_t *col;
-    const int32_t *pp;
-    const int32_t *p2n;
-    float *out;           // [nnz]
-    int64_t P;
-    int64_t num_chunks;
-    int32_t D;
-    int32_t G;
-};
-
-template <int LPR, int U, bool WIDE>
-__global__ void __launch_bounds__(kBlock)
-sddmm_kernel(const SddmmParams p)
-{
-    constexpr int VEC = 4;
-    constexpr int RPI = kWave / LPR;
-    typedef typename VecOf<VEC>::T VT;
-    typedef typename VecOf<VEC>::M MT;
-    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
-    static_assert(U * RPI <= kWave, "a batch must fit one 64-edge id tile");
-
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int slot = lane / LPR;
-    const int c = lane % LPR;
-    const int D = p.D;
-    const int G = p.G;
-    const char *bbase = reinterpret_cast<const char *>(p.B);
-    const OffT row_bytes = (OffT)D * (OffT)sizeof(float);
-
-    for (int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wib; chunk < p.num_chunks;
-         chunk += (int64_t)gridDim.x * kWavesPerBlock) {
-        const int64_t g0 = chunk * G;
-        const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
-        const int my_row = lane < ng ? p.p2n[g0 + lane] : -1;
-        const int my_pp = lane <= ng ? p.pp[g0 + lane] : 0;
-        // every group is walked on its own: each edge is written exactly once, no flush to share
-        for (int j = 0; j < ng; j++) {
-            const int row = __builtin_amdgcn_readlane(my_row, j);
-            const int sb = __builtin_amdgcn_readlane(my_pp, j);
-            const int se = __builtin_amdgcn_readlane(my_pp, j + 1);
-            for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
-                const int piece = d0 + c * VEC;
-                const bool cvalid = piece < D;
-                int dcol = piece, shift = 0;
-                if (piece + VEC > D && cvalid) { dcol = D - VEC; shift = piece - dcol; }
-                const OffT col_off = (OffT)(cvalid ? dcol : (d0 + VEC <= D ? d0 : D - VEC)) * (OffT)sizeof(float);
-                // destination row piece; components that overlap the previous piece (ragged D) and
-                // lanes past the row end are zeroed so that they do not contribute to the dot product
-                VT a = vzero<VEC>();
-                if (cvalid) a = *reinterpret_cast<const MT *>(p.A + (size_t)row * D + dcol);
-#pragma unroll
-                for (int k = 0; k < VEC; k++)
-                    if (k < shift) a[k] = 0.f;
-                for (int t = sb; t < se; t += kWave) {
-                    const int nv = se - t < kWave ? se - t : kWave;
-                    int id = 0;
-                    if (lane < nv) id = __builtin_nontemporal_load(p.col + t + lane);
-#pragma unroll 1
-                    for (int b = 0; b < nv; b += U * RPI) {
-                        VT v[U];
-                        int nid[U];
-#pragma unroll
-                        for (int u = 0; u < U; u++) nid[u] = __shfl(id, b + u * RPI + slot);
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            v[u] = vzero<VEC>();
-                            if (b + u * RPI + slot < nv)
-                                v[u] = *reinterpret_cast<const MT *>(bbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            const VT prod = v[u] * a;
-                            float dot = lane_group_sum<LPR>((prod[0] + prod[1]) + (prod[2] + prod[3]));
-                            const int el = b + u * RPI + slot;
-                            if (c == 0 && el < nv) {
-                                float *dst = p.out + t + el;
-                                if (d0 > 0) dot += *dst;  // wider than one lane sweep: add to the earlier chunks
-                                *dst = dot;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- host side ------------------------------------------------------------------------------
-
-struct Workspace {
-    void *ptr = nullptr;
-    size_t bytes = 0;
-};
-struct DeviceState {
-    std::atomic<bool> init{false};
-    int num_cus = 256;
-    int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
-    std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
-};
-constexpr int kFlagSlots = 1024;
-constexpr int kMaxDevices = 64;
-DeviceState g_dev[kMaxDevices];
-std::mutex g_dev_mutex;
-std::atomic<uint32_t> g_seq{0};
-
-int get_device_state(DeviceState **out)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
-    if (dev < 0 || dev >= kMaxDevices) return gnna::fail(GNNA_ERR_UNSUPPORTED, "device ordinal %d", dev);
-    DeviceState &s = g_dev[dev];
-    if (!s.init.load(std::memory_order_acquire)) {
-        std::lock_guard<std::mutex> lock(g_dev_mutex);
-        if (!s.init.load(std::memory_order_relaxed)) {
-            hipDeviceProp_t prop;
-            e = hipGetDeviceProperties(&prop, dev);
-            if (e != hipSuccess)
-                return gnna::fail(GNNA_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
-            s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            e = hipMalloc(reinterpret_cast<void **>(&s.flags), kFlagSlots * sizeof(int32_t));
-            if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMalloc(flags): %s", hipGetErrorString(e));
-            e = hipMemset(s.flags, 0, kFlagSlots * sizeof(int32_t));
-            if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMemset(flags): %s", hipGetErrorString(e));
-            s.init.store(true, std::memory_order_release);
-        }
-    }
-    *out = &s;
-    return GNNA_OK;
-}
-
-// Grow-only scratch buffer for `stream` (work on one stream is ordered, so one buffer per
-// stream is enough).  hipFree of the old buffer synchronises the device, which makes the
-// replacement safe; steady state performs no allocation.
-int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out)
-{
-    std::lock_guard<std::mutex> lock(g_dev_mutex);
-    Workspace &w = ds->ws[std::make_pair(stream, slot)];
-    if (w.bytes < bytes) {
-        if (w.ptr) (void)hipFree(w.ptr);
-        w.ptr = nullptr;
-        w.bytes = 0;
-        const size_t want = bytes + bytes / 4;
-        hipError_t e = hipMalloc(&w.ptr, want);
-        if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipMalloc(workspace %zu B): %s", want, hipGetErrorString(e));
-        w.bytes = want;
-    }
-    *out = w.ptr;
-    return GNNA_OK;
-}
 
 // Number of column phases.  The gather is bound by the L2-miss path once X is larger than the
 // caches; restricting a launch to a slice of X makes the slice cache resident (MI355X, Reddit-like
@@ -678,22 +419,6 @@ int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, in
     while (b > 1 && num_parts / b < 64) b--;
     return std::max(b, 1);
 }
-
-// ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------
-struct ProfileState {
-    std::atomic<bool> on{false};
-    int max_calls = 0;
-    int calls = 0;
-    std::vector<hipEvent_t> ev;  // 3 per call: before prologue, between, after main
-};
-ProfileState g_prof;
-std::mutex g_prof_mutex;
-
-hipEvent_t prof_event(int call, int which)
-{
-    return g_prof.ev[(size_t)call * 3 + which];
-}
-
 typedef void (*AggKernel)(const AggParams);
 
 template <int VEC, int LPR, int MODE, int U>
@@ -759,19 +484,19 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
                int partSize, int dimWorker, int warpPerBlock, void *stream_v, bool accumulate_into_out = false)
 {
     if (num_nodes < 0 || dim < 0 || num_parts < 0 || num_in_rows < 0)
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "negative size (num_nodes=%lld dim=%d num_parts=%lld)",
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size (num_nodes=%lld dim=%d num_parts=%lld)",
                           (long long)num_nodes, dim, (long long)num_parts);
     if (partSize <= 0 || dimWorker <= 0 || warpPerBlock <= 0)
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT,
+        return fail(GNNA_ERR_INVALID_ARGUMENT,
                           "partSize, dimWorker and warpPerBlock must be positive (got %d, %d, %d)",
                           partSize, dimWorker, warpPerBlock);
     if (num_nodes == 0 || dim == 0) return GNNA_OK;
-    if (!out || !input) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null feature pointer");
+    if (!out || !input) return fail(GNNA_ERR_INVALID_ARGUMENT, "null feature pointer");
     if (num_parts > 0 && (!column_index || !part_pointers || !part2Node))
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null index pointer");
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "null index pointer");
     if (mode == MODE_GCN && (!degrees || !degrees_in))
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null degrees pointer");
-    if (out == input) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "out must not alias input");
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "null degrees pointer");
+    if (out == input) return fail(GNNA_ERR_INVALID_ARGUMENT, "out must not alias input");
 
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     DeviceState *ds = nullptr;
@@ -781,16 +506,10 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     gnna_tuning tune;
     gnna_get_tuning(&tune);
 
-    const uint32_t seq_u = g_seq.fetch_add(1) + 1;
-    const int32_t seq = (int32_t)(seq_u & 0x7fffffff) | 1;  // never 0
-    int32_t *flag = ds->flags + (seq_u % kFlagSlots);
-
-    int prof_call = -1;
-    if (g_prof.on) {
-        std::lock_guard<std::mutex> lock(g_prof_mutex);
-        if (g_prof.on && g_prof.calls < g_prof.max_calls && num_parts > 0) prof_call = g_prof.calls++;
-    }
-    if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 0), stream);
+    int32_t *flag = nullptr;
+    const int32_t seq = next_call_seq(ds, &flag);
+    const int prof_call = profile_acquire_call(num_parts > 0);
+    profile_record(prof_call, 0, stream);
 
     // prologue: zero-fill + validation
     const size_t n_floats = (size_t)num_nodes * (size_t)dim;
@@ -802,10 +521,10 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
                            part2Node, part_pointers, num_parts, flag, seq,
                            (num_parts > 0 && !tune.trust_canonical) ? 1 : 0, accumulate_into_out ? 0 : 1);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
     }
     if (num_parts == 0) return GNNA_OK;
-    if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 1), stream);
+    profile_record(prof_call, 1, stream);
 
     // vector width / lane layout: one lane per 4 consecutive floats of a row (dword-aligned
     // dwordx4 accesses, ragged tail handled by the shifted last piece), LPR lanes per row
@@ -847,7 +566,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, input, degrees_in,
                                static_cast<float *>(xs), num_in_rows, dim);
             hipError_t es = hipGetLastError();
-            if (es != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "prescale launch: %s", hipGetErrorString(es));
+            if (es != hipSuccess) return fail(GNNA_ERR_HIP, "prescale launch: %s", hipGetErrorString(es));
             p.X = static_cast<const float *>(xs);
             p.row_scale = degrees;
             p.eps = 1.f;
@@ -873,62 +592,16 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         p.phase_hi = (int32_t)std::min<int64_t>((int64_t)(ph + 1) * width, 0x7fffffff);
         hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
     }
-    if (prof_call >= 0) hipEventRecord(prof_event(prof_call, 2), stream);
-    return GNNA_OK;
-}
-
-typedef void (*SddmmKernel)(const SddmmParams);
-
-template <int LPR>
-SddmmKernel pick_sddmm(bool wide)
-{
-    constexpr int U = LPR < 4 ? LPR : 4;
-    return wide ? sddmm_kernel<LPR, U, true> : sddmm_kernel<LPR, U, false>;
-}
-
-int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *column_index,
-                 const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
-                 int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, void *stream_v)
-{
-    if (num_out_rows < 0 || num_in_rows < 0 || dim < 0 || num_parts < 0)
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "negative size");
-    if (num_parts == 0 || dim == 0) return GNNA_OK;
-    if (dim < 4) return gnna::fail(GNNA_ERR_UNSUPPORTED, "sddmm needs dim >= 4 (got %d)", dim);
-    if (!dst_feat || !src_feat || !column_index || !part_pointers || !part2Node || !edge_out)
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "null pointer");
-    DeviceState *ds = nullptr;
-    int rc = get_device_state(&ds);
-    if (rc != GNNA_OK) return rc;
-    gnna_tuning tune;
-    gnna_get_tuning(&tune);
-    const int pieces = (dim + 3) / 4;
-    int lpr = 4;
-    while (lpr < 64 && lpr < pieces) lpr <<= 1;
-    SddmmParams p;
-    p.A = dst_feat; p.B = src_feat; p.col = column_index; p.pp = part_pointers; p.p2n = part2Node;
-    p.out = edge_out; p.P = num_parts; p.D = dim;
-    p.G = std::max(1, std::min(tune.groups_per_chunk, 63));
-    p.num_chunks = (num_parts + p.G - 1) / p.G;
-    const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
-    SddmmKernel k;
-    switch (lpr) {
-    case 4: k = pick_sddmm<4>(wide); break;
-    case 8: k = pick_sddmm<8>(wide); break;
-    case 16: k = pick_sddmm<16>(wide); break;
-    case 32: k = pick_sddmm<32>(wide); break;
-    default: k = pick_sddmm<64>(wide); break;
-    }
-    int64_t grid = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    grid = std::max<int64_t>(1, std::min<int64_t>(grid, 0x7fffffff));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream_v), p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "sddmm launch: %s", hipGetErrorString(e));
+    profile_record(prof_call, 2, stream);
     return GNNA_OK;
 }
 
 }  // namespace
+}  // namespace gnna
+
+using namespace gnna;
 
 extern "C" {
 #pragma GCC visibility push(default)
@@ -970,65 +643,11 @@ int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const i
                       void *stream)
 {
     if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
     return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
                       part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0);
 }
-
-int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const int32_t *column_index,
-                   const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
-                   int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
-                   void *stream)
-{
-    if (partSize <= 0) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "partSize must be positive (got %d)", partSize);
-    return launch_sddmm(dst_feat, src_feat, column_index, part_pointers, part2Node, edge_out, num_out_rows,
-                        num_in_rows, dim, num_parts, stream);
-}
-
 int gnna_last_num_phases(void) { return t_last_phases; }
-
-int gnna_profile_begin(int max_calls)
-{
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    if (g_prof.on) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "profiling already active");
-    if (max_calls <= 0 || max_calls > (1 << 20))
-        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "max_calls out of range: %d", max_calls);
-    g_prof.ev.resize((size_t)max_calls * 3);
-    for (auto &e : g_prof.ev) {
-        hipError_t rc = hipEventCreate(&e);
-        if (rc != hipSuccess) return gnna::fail(GNNA_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc));
-    }
-    g_prof.max_calls = max_calls;
-    g_prof.calls = 0;
-    g_prof.on = true;
-    return GNNA_OK;
-}
-
-int gnna_profile_end(double *avg_main_ms, double *avg_prologue_ms, int *num_calls)
-{
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    if (!g_prof.on) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "profiling not active");
-    g_prof.on = false;
-    double main_ms = 0, pro_ms = 0;
-    int rc_out = GNNA_OK;
-    for (int c = 0; c < g_prof.calls; c++) {
-        hipError_t rc = hipEventSynchronize(prof_event(c, 2));
-        float a = 0, b = 0;
-        if (rc == hipSuccess) rc = hipEventElapsedTime(&a, prof_event(c, 0), prof_event(c, 1));
-        if (rc == hipSuccess) rc = hipEventElapsedTime(&b, prof_event(c, 1), prof_event(c, 2));
-        if (rc != hipSuccess) { rc_out = gnna::fail(GNNA_ERR_HIP, "profile events: %s", hipGetErrorString(rc)); break; }
-        pro_ms += a;
-        main_ms += b;
-    }
-    const int n = g_prof.calls;
-    for (auto &e : g_prof.ev) hipEventDestroy(e);
-    g_prof.ev.clear();
-    g_prof.calls = 0;
-    if (num_calls) *num_calls = n;
-    if (avg_main_ms) *avg_main_ms = n ? main_ms / n : 0.0;
-    if (avg_prologue_ms) *avg_prologue_ms = n ? pro_ms / n : 0.0;
-    return rc_out;
-}
 
 #pragma GCC visibility pop
 }  // extern "C"

@@ -1,0 +1,87 @@
+// gnna_device.h -- device-side building blocks shared by the kernels of libgnna.so
+// (lane layout constants, vector register/memory types, wave-level folds).
+#ifndef GNNA_DEVICE_H_
+#define GNNA_DEVICE_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+namespace gnna {
+
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kXcds = 8;
+
+enum { MODE_SAG = 0, MODE_GCN = 1, MODE_GIN = 2 };
+
+// T: register type; M: the same vector as it sits in memory.  Feature rows are only 4-byte
+// aligned in general (row stride = D floats, D arbitrary), and gfx950 global_load/store_dwordx4
+// need no more than dword alignment, so M is declared with alignment 4.
+template <int VEC> struct VecOf;
+template <> struct VecOf<1> { typedef float T; typedef float M; };
+template <> struct VecOf<4> {
+    typedef float T __attribute__((ext_vector_type(4)));
+    typedef T M __attribute__((aligned(4)));
+};
+
+// ---- wave-level helpers ----------------------------------------------------------------
+
+__device__ __forceinline__ float fold_xor16(float v)
+{
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float fold_xor32(float v)
+{
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// DPP row rotation by N lanes inside each 16-lane row (pure VALU, folds into the add).
+template <int N>
+__device__ __forceinline__ float row_ror(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
+
+// Sum over the 64/LPR lanes that share lane % LPR; result in every lane.
+template <int LPR>
+__device__ __forceinline__ float slot_reduce(float v)
+{
+    if constexpr (LPR <= 8) v += row_ror<8>(v);   // strides 8 and 4 stay inside a 16-lane DPP row
+    if constexpr (LPR <= 4) v += row_ror<4>(v);
+    if constexpr (LPR <= 16) v = fold_xor16(v);
+    if constexpr (LPR <= 32) v = fold_xor32(v);
+    return v;
+}
+
+template <int VEC>
+__device__ __forceinline__ typename VecOf<VEC>::T vzero()
+{
+    typename VecOf<VEC>::T z;
+    if constexpr (VEC == 1) z = 0.f; else z = (typename VecOf<VEC>::T)(0.f);
+    return z;
+}
+
+template <int VEC>
+__device__ __forceinline__ float vget(const typename VecOf<VEC>::T &v, int k)
+{
+    if constexpr (VEC == 1) return v; else return v[k];
+}
+
+template <int VEC>
+__device__ __forceinline__ void vset(typename VecOf<VEC>::T &v, int k, float x)
+{
+    if constexpr (VEC == 1) v = x; else v[k] = x;
+}
+
+}  // namespace gnna
+
+#endif  // GNNA_DEVICE_H_

@@ -2,11 +2,47 @@
 #ifndef GNNA_INTERNAL_H_
 #define GNNA_INTERNAL_H_
 
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <utility>
+
 #include "gnna.h"
 
 namespace gnna {
+
 // Records a formatted message for gnna_last_error() on this thread and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// ---- per-device runtime state (gnna_runtime.hip) -------------------------------------------------
+struct Workspace {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+struct DeviceState {
+    std::atomic<bool> init{false};
+    int num_cus = 256;
+    int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
+    std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
+};
+constexpr int kFlagSlots = 1024;
+
+// State of the current device (lazily created: CU count, flag ring).
+int get_device_state(DeviceState **out);
+// Grow-only scratch buffer `slot` of `stream`.
+int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out);
+// Fresh non-zero sequence number of an aggregation call and its slot in the flag ring.
+int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
+
+// ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------------
+// Returns the index of this call in the active profile (-1 when not profiling).
+int profile_acquire_call(bool has_work);
+// Records event `which` (0 before the prologue, 1 between, 2 after the aggregation) of call `call`.
+void profile_record(int call, int which, hipStream_t stream);
+
 }  // namespace gnna
 
 #endif

@@ -1,0 +1,199 @@
+// gnna_sddmm.hip -- SDDMM over the neighbor-group partition (build-defined extension of libgnna.so).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "gnna.h"
+#include "gnna_device.h"
+#include "gnna_internal.h"
+
+namespace gnna {
+namespace {
+
+// ---- SDDMM over the neighbor-group partition (build-defined extension) -------------------------
+// edge_out[e] = < dst_feat[row(e), :], src_feat[colidx[e], :] >  for every edge e of the partition.
+// The reference has no SDDMM kernel (SURVEY.md "three things" #1); BASELINE's north star asks
+// for one over the same partition, so this follows the aggregation kernel's shape: a wavefront
+// owns a chunk of groups, a run keeps the destination row's piece in registers, source rows are
+// gathered RPI per wave-wide load, and the LPR lanes of a slot fold their 4-float partial dot
+// products with DPP (quad_perm / row_half_mirror / row_mirror) and permlane swaps.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the LPR consecutive lanes of a slot; result in every lane of the slot.
+template <int LPR>
+__device__ __forceinline__ float lane_group_sum(float v)
+{
+    v += dpp_move<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);                          // quad_perm [2,3,0,1]
+    if constexpr (LPR >= 8) v += dpp_move<0x141>(v);  // row_half_mirror: the other quad of the 8
+    if constexpr (LPR >= 16) v += dpp_move<0x140>(v); // row_mirror: the other half of the 16
+    if constexpr (LPR >= 32) v = fold_xor16(v);
+    if constexpr (LPR >= 64) v = fold_xor32(v);
+    return v;
+}
+
+struct SddmmParams {
+    const float *A;       // [n_out, D] destination-side features
+    const float *B;       // [n_in, D] source-side features
+    const int32_t *col;
+    const int32_t *pp;
+    const int32_t *p2n;
+    float *out;           // [nnz]
+    int64_t P;
+    int64_t num_chunks;
+    int32_t D;
+    int32_t G;
+};
+
+template <int LPR, int U, bool WIDE>
+__global__ void __launch_bounds__(kBlock)
+sddmm_kernel(const SddmmParams p)
+{
+    constexpr int VEC = 4;
+    constexpr int RPI = kWave / LPR;
+    typedef typename VecOf<VEC>::T VT;
+    typedef typename VecOf<VEC>::M MT;
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
+    static_assert(U * RPI <= kWave, "a batch must fit one 64-edge id tile");
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int slot = lane / LPR;
+    const int c = lane % LPR;
+    const int D = p.D;
+    const int G = p.G;
+    const char *bbase = reinterpret_cast<const char *>(p.B);
+    const OffT row_bytes = (OffT)D * (OffT)sizeof(float);
+
+    for (int64_t chunk = (int64_t)blockIdx.x * kWavesPerBlock + wib; chunk < p.num_chunks;
+         chunk += (int64_t)gridDim.x * kWavesPerBlock) {
+        const int64_t g0 = chunk * G;
+        const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
+        const int my_row = lane < ng ? p.p2n[g0 + lane] : -1;
+        const int my_pp = lane <= ng ? p.pp[g0 + lane] : 0;
+        // every group is walked on its own: each edge is written exactly once, no flush to share
+        for (int j = 0; j < ng; j++) {
+            const int row = __builtin_amdgcn_readlane(my_row, j);
+            const int sb = __builtin_amdgcn_readlane(my_pp, j);
+            const int se = __builtin_amdgcn_readlane(my_pp, j + 1);
+            for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
+                const int piece = d0 + c * VEC;
+                const bool cvalid = piece < D;
+                int dcol = piece, shift = 0;
+                if (piece + VEC > D && cvalid) { dcol = D - VEC; shift = piece - dcol; }
+                const OffT col_off = (OffT)(cvalid ? dcol : (d0 + VEC <= D ? d0 : D - VEC)) * (OffT)sizeof(float);
+                // destination row piece; components that overlap the previous piece (ragged D) and
+                // lanes past the row end are zeroed so that they do not contribute to the dot product
+                VT a = vzero<VEC>();
+                if (cvalid) a = *reinterpret_cast<const MT *>(p.A + (size_t)row * D + dcol);
+#pragma unroll
+                for (int k = 0; k < VEC; k++)
+                    if (k < shift) a[k] = 0.f;
+                for (int t = sb; t < se; t += kWave) {
+                    const int nv = se - t < kWave ? se - t : kWave;
+                    int id = 0;
+                    if (lane < nv) id = __builtin_nontemporal_load(p.col + t + lane);
+#pragma unroll 1
+                    for (int b = 0; b < nv; b += U * RPI) {
+                        VT v[U];
+                        int nid[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) nid[u] = __shfl(id, b + u * RPI + slot);
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            v[u] = vzero<VEC>();
+                            if (b + u * RPI + slot < nv)
+                                v[u] = *reinterpret_cast<const MT *>(bbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const VT prod = v[u] * a;
+                            float dot = lane_group_sum<LPR>((prod[0] + prod[1]) + (prod[2] + prod[3]));
+                            const int el = b + u * RPI + slot;
+                            if (c == 0 && el < nv) {
+                                float *dst = p.out + t + el;
+                                if (d0 > 0) dot += *dst;  // wider than one lane sweep: add to the earlier chunks
+                                *dst = dot;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+typedef void (*SddmmKernel)(const SddmmParams);
+
+template <int LPR>
+SddmmKernel pick_sddmm(bool wide)
+{
+    constexpr int U = LPR < 4 ? LPR : 4;
+    return wide ? sddmm_kernel<LPR, U, true> : sddmm_kernel<LPR, U, false>;
+}
+
+int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *column_index,
+                 const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
+                 int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, void *stream_v)
+{
+    if (num_out_rows < 0 || num_in_rows < 0 || dim < 0 || num_parts < 0)
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size");
+    if (num_parts == 0 || dim == 0) return GNNA_OK;
+    if (dim < 4) return fail(GNNA_ERR_UNSUPPORTED, "sddmm needs dim >= 4 (got %d)", dim);
+    if (!dst_feat || !src_feat || !column_index || !part_pointers || !part2Node || !edge_out)
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "null pointer");
+    DeviceState *ds = nullptr;
+    int rc = get_device_state(&ds);
+    if (rc != GNNA_OK) return rc;
+    gnna_tuning tune;
+    gnna_get_tuning(&tune);
+    const int pieces = (dim + 3) / 4;
+    int lpr = 4;
+    while (lpr < 64 && lpr < pieces) lpr <<= 1;
+    SddmmParams p;
+    p.A = dst_feat; p.B = src_feat; p.col = column_index; p.pp = part_pointers; p.p2n = part2Node;
+    p.out = edge_out; p.P = num_parts; p.D = dim;
+    p.G = std::max(1, std::min(tune.groups_per_chunk, 63));
+    p.num_chunks = (num_parts + p.G - 1) / p.G;
+    const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
+    SddmmKernel k;
+    switch (lpr) {
+    case 4: k = pick_sddmm<4>(wide); break;
+    case 8: k = pick_sddmm<8>(wide); break;
+    case 16: k = pick_sddmm<16>(wide); break;
+    case 32: k = pick_sddmm<32>(wide); break;
+    default: k = pick_sddmm<64>(wide); break;
+    }
+    int64_t grid = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    grid = std::max<int64_t>(1, std::min<int64_t>(grid, 0x7fffffff));
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream_v), p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "sddmm launch: %s", hipGetErrorString(e));
+    return GNNA_OK;
+}
+
+}  // namespace
+}  // namespace gnna
+
+using namespace gnna;
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const int32_t *column_index,
+                   const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
+                   int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
+                   void *stream)
+{
+    if (partSize <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "partSize must be positive (got %d)", partSize);
+    return launch_sddmm(dst_feat, src_feat, column_index, part_pointers, part2Node, edge_out, num_out_rows,
+                        num_in_rows, dim, num_parts, stream);
+}
+
+#pragma GCC visibility pop
+}  // extern "C"
