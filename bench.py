@@ -105,6 +105,25 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
     }
 
 
+def other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz, steps: int = 10):
+    """edges/s of the GCN-weighted and GIN entries on the bench graph (same partition, same knobs)."""
+    import torch
+    res = {}
+    for name, fn in (("gcn_weighted", lambda: _lib.agg_gcn(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd,
+                                                           ps, 32, 4, out=out)),
+                     ("gin_eps", lambda: _lib.agg_gin(X, g.row_pointers, g.column_index, 0.5, ppd, p2nd,
+                                                      ps, 32, 4, out=out))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        res[name + "_edges_per_s"] = nnz * steps / (time.perf_counter() - t0)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -260,6 +279,9 @@ def main():
                          if kern_ms > 0 else 0.0,
                          "kernel_edges_per_s": nnz_local / (kern_ms * 1e-3) if kern_ms > 0 else 0.0},
         }
+        if not sharded:
+            # the weighted forms of the same kernel (a-2 GCN coefficients, a-4 GIN epsilon), outside the timed region
+            rec["other_modes"] = other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz_local)
         if not sharded and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), X.cpu(), pp, p2n, D)
         print(json.dumps(rec), flush=True)

@@ -424,3 +424,36 @@ def test_sddmm_extension_matches_dense_formula(dim, partSize):
     ci2 = g.column_index[: int(rp2[-1])].contiguous()
     out2 = _lib.sddmm(A2.cuda(), B.cuda(), ci2.cuda(), pp2.cuda(), p2n2.cuda(), partSize)
     assert_close_f64(out2.cpu().numpy(), ref[: int(rp2[-1])], what="sddmm rect", scale=scale[: int(rp2[-1])], rtol=1e-5)
+
+
+@pytest.mark.parametrize("phases,prescale", [(0, 0), (4, 0), (3, 1)])
+def test_hip_graph_capture_and_replay(phases, prescale):
+    """The launch path never synchronises and allocates scratch only on first use, so (after one
+    warm-up call) a forward can be captured into a HIP graph and replayed on new feature values."""
+    g, Xc, ppc, p2nc = make_case(3000, 300000, 64, 32, seed=31, kind="powerlaw")
+    rp, ci, deg = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy()
+    X, rpd, cid, degd, pp, p2n = dev(Xc, g.row_pointers, g.column_index, g.degrees, ppc, p2nc)
+    out_s, out_g = torch.empty_like(X), torch.empty_like(X)
+    try:
+        _lib.set_tuning(column_phases=phases, gcn_prescale=prescale)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):                     # warm-up on the capture stream: scratch gets allocated
+            _lib.sag(X, rpd, cid, degd, pp, p2n, 32, 32, 4, out=out_s)
+            _lib.agg_gcn(X, rpd, cid, degd, pp, p2n, 32, 32, 4, out=out_g)
+        side.synchronize()
+        hg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hg, stream=side):
+            _lib.sag(X, rpd, cid, degd, pp, p2n, 32, 32, 4, out=out_s)
+            _lib.agg_gcn(X, rpd, cid, degd, pp, p2n, 32, 32, 4, out=out_g)
+        for seed in (1, 2, 3):
+            X.copy_(torch.randn(X.shape, generator=torch.Generator().manual_seed(seed)))
+            out_s.fill_(float("nan")); out_g.fill_(float("nan"))
+            hg.replay()
+            torch.cuda.synchronize()
+            Xn = X.cpu().numpy()
+            assert_close_f64(out_s.cpu().numpy(), oracle.csr_f64(0, Xn, rp, ci, deg), what=f"graph sag {seed}",
+                             scale=oracle.csr_f64(0, np.abs(Xn), rp, ci, deg))
+            assert_close_f64(out_g.cpu().numpy(), oracle.csr_f64(1, Xn, rp, ci, deg), what=f"graph gcn {seed}",
+                             scale=oracle.csr_f64(1, np.abs(Xn), rp, ci, deg))
+    finally:
+        _lib.reset_tuning()
