@@ -94,6 +94,7 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
     oracle.sag_groups_slice(X, ci, ppn, p2nn, 0, g_end, out1)
     t1 = time.perf_counter() - t0
     e1 = int(ppn[g_end] - ppn[0])
+    libs = library_baselines(rp, ci, X, nnz, cores)
     return {
         "value": nnz / best, "unit": "edges/s", "cores": cores, "kind": "port",
         "sample": f"full graph ({nnz} edges, D={dim}), best of {reps} passes of the OpenMP row-parallel "
@@ -102,7 +103,45 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
         "gather_model_GBs": gather_model_bytes(nnz, len(rp) - 1, P, dim) / best / 1e9,
         "single_thread": {"value": e1 / t1, "unit": "edges/s", "cores": 1,
                           "sample": f"first {g_end} neighbor-groups ({e1} edges), scalar neighbor-group port"},
+        "libraries": libs,
     }
+
+
+def library_baselines(rp, ci, X, nnz, cores):
+    """SURVEY.md 8(d) baselines (i), (ii), (iv): scipy CSR @ X (one thread), torch.sparse_csr @ X
+    (all cores), DGL copy_u/sum if importable.  One bounded pass each on the same CSR and X."""
+    import numpy as np
+    import torch
+    res = {}
+    n = len(rp) - 1
+    try:
+        import scipy.sparse as sp
+        rows = min(n, max(1, n // 8))                       # ~1/8 of the rows: a few seconds on one thread
+        A = sp.csr_matrix((np.ones(int(rp[rows]), dtype=np.float32), ci[:int(rp[rows])], rp[:rows + 1]),
+                          shape=(rows, X.shape[0]))
+        t0 = time.perf_counter(); A @ X; t = time.perf_counter() - t0
+        res["scipy_csr_1thread"] = {"value": int(rp[rows]) / t, "unit": "edges/s", "cores": 1,
+                                    "sample": f"first {rows} rows ({int(rp[rows])} edges)"}
+    except Exception as exc:  # pragma: no cover
+        res["scipy_csr_1thread"] = f"unavailable: {exc}"
+    try:
+        import warnings
+        warnings.filterwarnings("ignore", message="Sparse CSR tensor support is in beta")
+        torch.set_num_threads(cores)
+        A = torch.sparse_csr_tensor(torch.from_numpy(rp.astype(np.int64)), torch.from_numpy(ci.astype(np.int64)),
+                                    torch.ones(nnz), size=(n, X.shape[0]))
+        Xt = torch.from_numpy(X)
+        A @ Xt
+        t0 = time.perf_counter(); A @ Xt; t = time.perf_counter() - t0
+        res["torch_sparse_csr"] = {"value": nnz / t, "unit": "edges/s", "cores": cores, "sample": "full graph, 2nd pass"}
+    except Exception as exc:  # pragma: no cover
+        res["torch_sparse_csr"] = f"unavailable: {exc}"
+    try:
+        import dgl  # noqa: F401
+        res["dgl_copy_u_sum"] = "importable but not timed"
+    except Exception:
+        res["dgl_copy_u_sum"] = "unavailable (dgl is not installed on this image)"
+    return res
 
 
 def other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz, steps: int = 10):
