@@ -227,3 +227,87 @@ class ShardedAggregator:
 
     def sag(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.aggregate(X_local, 0, out=out)
+
+    def gcn(self, X_local: torch.Tensor, degrees_local: torch.Tensor, out=None) -> torch.Tensor:
+        return self.aggregate(X_local, 1, degrees_local=degrees_local, out=out)
+
+    def gin(self, X_local: torch.Tensor, epsilon: float, out=None) -> torch.Tensor:
+        return self.aggregate(X_local, 2, epsilon=epsilon, out=out)
+
+
+# ---- sharded operator layer (SURVEY.md 8e "backward") ---------------------------------------
+# Counterparts of ops.GNNAFunction / ops.GNNAFunction_GIN for one destination-range shard.  The
+# dense update stays local (rows of X W only need the rank's own rows); the aggregation is the
+# sharded one above; A is symmetric (as the reference assumes, gnn_conv.py:57-78), so the
+# gradient aggregation uses the same shard; dW = X_local^T G_local is a partial sum over the
+# rank's rows and is all-reduced (a [Fin, Fout] fp32 payload: latency-, not bandwidth-bound).
+
+def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+class ShardedGCNFunction(torch.autograd.Function):
+    """Y_local = Â[local rows, :] (X W):  update -> all-gather -> aggregate."""
+
+    @staticmethod
+    def forward(ctx, X_local, weight, agg: "ShardedAggregator", degrees_local):
+        ctx.save_for_backward(X_local, weight)
+        ctx.agg, ctx.deg = agg, degrees_local
+        return agg.gcn(torch.mm(X_local, weight), degrees_local)
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X_local, weight = ctx.saved_tensors
+        G = ctx.agg.gcn(d_output.contiguous(), ctx.deg)          # Â dY, rows of this rank
+        d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
+        d_weight = _all_reduce_sum(torch.mm(X_local.t(), G), ctx.agg.group)
+        return d_input, d_weight, None, None
+
+
+class ShardedGINFunction(torch.autograd.Function):
+    """Y_local = (eps A[local rows, :] X) W:  all-gather -> aggregate -> update."""
+
+    @staticmethod
+    def forward(ctx, X_local, weight, agg: "ShardedAggregator", epsilon):
+        T = agg.gin(X_local, epsilon)
+        ctx.save_for_backward(T, weight)
+        ctx.agg, ctx.epsilon = agg, epsilon
+        return torch.mm(T, weight)
+
+    @staticmethod
+    def backward(ctx, d_output):
+        T, weight = ctx.saved_tensors
+        d_output = d_output.contiguous()
+        d_weight = _all_reduce_sum(torch.mm(T.t(), d_output), ctx.agg.group)
+        d_input = None
+        if ctx.needs_input_grad[0]:
+            d_input = ctx.agg.gin(torch.mm(d_output, weight.t()), ctx.epsilon)
+        return d_input, d_weight, None, None
+
+
+class _ShardedConv(torch.nn.Module):
+    """Weights are replicated: drawn like ops._NeighborConv, then broadcast from rank 0."""
+
+    def __init__(self, input_dim: int, output_dim: int, agg: ShardedAggregator, device=None):
+        super().__init__()
+        self.agg = agg
+        bound = 1.0 / (output_dim ** 0.5)
+        w = torch.empty(input_dim, output_dim, device=device or agg.device).uniform_(-bound, bound)
+        if dist.is_initialized() and dist.get_world_size(agg.group) > 1:
+            dist.broadcast(w, src=dist.get_global_rank(agg.group, 0) if agg.group is not None else 0,
+                           group=agg.group)
+        self.weights = torch.nn.Parameter(w)
+
+
+class ShardedGCNConv(_ShardedConv):
+    def forward(self, X_local: torch.Tensor, degrees_local: torch.Tensor) -> torch.Tensor:
+        return ShardedGCNFunction.apply(X_local, self.weights, self.agg, degrees_local)
+
+
+class ShardedGINConv(_ShardedConv):
+    eplison = 0.5                                               # reference spelling, gnn_conv.py:132
+
+    def forward(self, X_local: torch.Tensor) -> torch.Tensor:
+        return ShardedGINFunction.apply(X_local, self.weights, self.agg, self.eplison)

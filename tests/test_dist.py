@@ -126,3 +126,68 @@ def test_split_local_remote_partitions_every_edge():
         orig = sorted(ci[rp[r]:rp[r + 1]].tolist())
         got = sorted([v + 50 for v in ci_l[rp_l[r]:rp_l[r + 1]].tolist()] + ci_r[rp_r[r]:rp_r[r + 1]].tolist())
         assert orig == got
+
+
+def _train_worker(rank, world, port, n, e, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnadvisor_osdi21_amd.dist import ShardedGCNConv, ShardedGINConv
+        fin, hid, ncls = 9, 6, 4
+        g = graph.powerlaw_graph(n, e, 40, seed=11)
+        bounds = balanced_row_splits(g.row_pointers, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        agg = ShardedAggregator(rp, ci, bounds, 3, aggregate_fn=_oracle_aggregate,
+                                build_part_fn=_oracle_build_part, overlap=True)
+        torch.manual_seed(100 + rank)                      # different draws: the broadcast must align them
+        l1 = ShardedGCNConv(fin, hid, agg, device="cpu")
+        l2 = ShardedGINConv(hid, ncls, agg, device="cpu")
+        X = torch.randn(n, fin, generator=torch.Generator().manual_seed(5))
+        Xl = X[lo:hi].clone().requires_grad_(True)
+        deg = g.degrees[lo:hi].contiguous()
+        y = l2(torch.relu(l1(Xl, deg)))
+        # loss = sum over ALL nodes: each rank back-propagates its rows' share
+        loss_local = (y * torch.arange(1, ncls + 1, dtype=torch.float32)).sum()
+        loss_local.backward()
+
+        # single-process dense autograd of the same 2-layer net on the whole graph
+        A = torch.zeros(n, n, dtype=torch.float64)
+        rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+        A[rows, g.column_index.long()] = 1.0
+        d = g.degrees.double()
+        Ahat = A * d[:, None] * d[None, :]
+        W1 = l1.weights.detach().double().requires_grad_(True)
+        W2 = l2.weights.detach().double().requires_grad_(True)
+        Xd = X.double().requires_grad_(True)
+        yd = (0.5 * A @ torch.relu(Ahat @ (Xd @ W1))) @ W2
+        (yd * torch.arange(1, ncls + 1, dtype=torch.float64)).sum().backward()
+        ok = True
+        ok &= torch.allclose(y.double(), yd[lo:hi].detach(), rtol=1e-4, atol=1e-3)
+        ok &= torch.allclose(l1.weights.grad.double(), W1.grad, rtol=1e-4, atol=1e-2)
+        ok &= torch.allclose(l2.weights.grad.double(), W2.grad, rtol=1e-4, atol=1e-2)
+        ok &= torch.allclose(Xl.grad.double(), Xd.grad[lo:hi], rtol=1e-4, atol=1e-2)
+        # replicated weights stayed replicated
+        w_all = [torch.empty_like(l1.weights.data) for _ in range(world)]
+        dist.all_gather(w_all, l1.weights.data)
+        ok &= all(torch.equal(w_all[0], w) for w in w_all)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_layers_match_dense_autograd():
+    """GCN then GIN layer on a 2-way sharded graph (gloo): outputs, dX and the all-reduced dW equal
+    single-process dense autograd on the whole graph (A symmetric, as the reference assumes)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, 83, 900, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res

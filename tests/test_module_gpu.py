@@ -228,3 +228,32 @@ def _check_local_plus_remote(g, D, ps):
             _lib.agg_rect(mode, Xd, ci_r.cuda(), pp_r.cuda(), p2n_r.cuda(), hi - lo, ps, epsilon=eps, out=out,
                           accumulate=True)
             assert_close_f64(out.cpu().numpy(), ref[lo:hi], what=f"shard [{lo},{hi}) mode {mode}")
+
+
+def test_sharded_layers_on_one_gpu_equal_the_single_gpu_ops():
+    """world == 1 (no process group): the sharded GCN / GIN layers run the real kernel through
+    ShardedAggregator (forced local/remote split + accumulate) and must reproduce ops.GCNConv /
+    ops.GINConv outputs and gradients on the same graph and weights."""
+    from gnnadvisor_osdi21_amd import ops
+    from gnnadvisor_osdi21_amd.dist import ShardedAggregator, ShardedGCNConv, ShardedGINConv
+    g = graph.powerlaw_graph(800, 40000, 300, seed=17)
+    fin, hid, ncls, ps = 20, 16, 7, 32
+    info, _, _ = _info(g, fin, hid, partSize=ps)
+    agg = ShardedAggregator(g.row_pointers, g.column_index, [0, g.num_nodes], ps, device="cuda",
+                            force_overlap=True)
+    assert agg.overlap
+    torch.manual_seed(0)
+    s1, s2 = ShardedGCNConv(fin, hid, agg), ShardedGINConv(hid, ncls, agg)
+    r1, r2 = ops.GCNConv(fin, hid).cuda(), ops.GINConv(hid, ncls).cuda()
+    with torch.no_grad():
+        r1.weights.copy_(s1.weights); r2.weights.copy_(s2.weights)
+    X = torch.randn(g.num_nodes, fin, generator=torch.Generator().manual_seed(2)).cuda()
+    Xs, Xr = X.clone().requires_grad_(True), X.clone().requires_grad_(True)
+    ys = s2(torch.relu(s1(Xs, info.degrees)))
+    yr = r2(torch.relu(r1(Xr, info)), info)
+    wgt = torch.linspace(0.5, 1.5, ncls, device="cuda")
+    (ys * wgt).sum().backward(); (yr * wgt).sum().backward()
+    for a, b, what in ((ys, yr, "out"), (Xs.grad, Xr.grad, "dX"), (s1.weights.grad, r1.weights.grad, "dW1"),
+                       (s2.weights.grad, r2.weights.grad, "dW2")):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max())), (what, float((a - b).abs().max()))
