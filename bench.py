@@ -177,9 +177,17 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--locality", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-chunks", type=int, default=0,
+                    help="multi-GPU: pieces of the pipelined feature exchange (0 = automatic)")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the sharded (torch.distributed) path even with one rank")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: libraries that chat on fd 1 (RCCL prints a version banner
+    # there at init) are pointed at stderr, the result is written to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -248,7 +256,8 @@ def main():
         bounds = [i * n_local for i in range(world + 1)]
         # sources are drawn from all ranks' nodes with no locality: span ~ n_global / 3
         ps = decide(n_local, float(ci.numel()) / n_local, n_global / 3.0)
-        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist)
+        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
+                                pipeline_chunks=args.pipeline_chunks)
         nnz_local, n_src = agg.nnz_local, n_global
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         X = torch.randn(n_local, D, device=dev, generator=gen)
@@ -303,7 +312,8 @@ def main():
                                    + (f", scale={args.scale}" if args.scale != 1.0 else ""),
                        "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
                        "num_parts_per_gpu": P, "source_nodes": n_src,
-                       "parallelism": "single GPU" if world == 1 else f"dst-range shards x{world} + RCCL all-gather",
+                       "parallelism": "single GPU" if world == 1 else
+                       f"dst-range shards x{world} + RCCL all-gather in {agg.chunks} piece(s), overlapped",
                        "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
                        "column_phases_used": _lib.last_num_phases(),
                        "tuning": _lib.get_tuning()},
@@ -323,7 +333,8 @@ def main():
             rec["other_modes"] = other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz_local)
         if not sharded and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), X.cpu(), pp, p2n, D)
-        print(json.dumps(rec), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(rec) + "\n").encode())
 
     if sharded:
         dist.barrier()

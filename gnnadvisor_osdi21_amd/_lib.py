@@ -40,7 +40,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases", "gnna_sddmm_f32")
+           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32")
 
 
 def load() -> ctypes.CDLL:
@@ -75,6 +75,9 @@ def load() -> ctypes.CDLL:
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.gnna_agg_rect_windows_f32.restype = ctypes.c_int
+    L.gnna_agg_rect_windows_f32.argtypes = (L.gnna_agg_rect_f32.argtypes[:-1]
+                                            + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
     L.gnna_csr_from_edges_i32.restype = ctypes.c_int64
     L.gnna_csr_from_edges_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]
@@ -242,15 +245,26 @@ MODE_SAG, MODE_GCN, MODE_GIN = 0, 1, 2
 
 
 def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, partSize=32,
-             degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False):
+             degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False, windows=None):
     """Destination-shard aggregation: X is [num_in_rows, dim] (all sources), out is
-    [num_out_rows, dim]; column_index indexes X."""
+    [num_out_rows, dim]; column_index indexes X.  ``windows=(K, begin, end)`` aggregates only the
+    edges whose source lies in windows [begin, end) of K equal source windows
+    (gnna_agg_rect_windows_f32: calls in increasing window order on one stream)."""
     if not X.is_cuda:
         raise GnnaError("aggregation needs device tensors: there is no CPU path in libgnna")
     assert X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2
     if out is None:
         assert not accumulate, "accumulate needs an existing `out`"
         out = torch.empty(num_out_rows, X.shape[1], dtype=torch.float32, device=X.device)
+    if windows is not None:
+        K, wb, we = (int(v) for v in windows)
+        assert wb == 0 or out is not None
+        with torch.cuda.device(X.device):
+            _check(load().gnna_agg_rect_windows_f32(
+                int(mode), X.data_ptr(), X.shape[0], column_index.data_ptr(), _ptr(degrees_out), _ptr(degrees_in),
+                float(epsilon), part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(), int(num_out_rows),
+                X.shape[1], part2Node.numel(), int(partSize), 1 if accumulate else 0, K, wb, we, _stream(X.device)))
+        return out
     with torch.cuda.device(X.device):
         _check(load().gnna_agg_rect_f32(int(mode), X.data_ptr(), X.shape[0], column_index.data_ptr(),
                                         _ptr(degrees_out), _ptr(degrees_in), float(epsilon),

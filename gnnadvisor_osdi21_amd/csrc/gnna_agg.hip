@@ -481,7 +481,8 @@ AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide, bool phased)
 int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
                const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
                const int32_t *part2Node, float *out, int64_t num_nodes, int dim, int64_t num_parts,
-               int partSize, int dimWorker, int warpPerBlock, void *stream_v, bool accumulate_into_out = false)
+               int partSize, int dimWorker, int warpPerBlock, void *stream_v, bool accumulate_into_out = false,
+               int num_windows = 1, int win_begin = 0, int win_end = 1)
 {
     if (num_nodes < 0 || dim < 0 || num_parts < 0 || num_in_rows < 0)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size (num_nodes=%lld dim=%d num_parts=%lld)",
@@ -490,6 +491,9 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         return fail(GNNA_ERR_INVALID_ARGUMENT,
                           "partSize, dimWorker and warpPerBlock must be positive (got %d, %d, %d)",
                           partSize, dimWorker, warpPerBlock);
+    if (num_windows < 1 || num_windows > 16 || win_begin < 0 || win_end > num_windows || win_begin >= win_end)
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "bad source window range [%d, %d) of %d (at most 16 windows)",
+                    win_begin, win_end, num_windows);
     if (num_nodes == 0 || dim == 0) return GNNA_OK;
     if (!out || !input) return fail(GNNA_ERR_INVALID_ARGUMENT, "null feature pointer");
     if (num_parts > 0 && (!column_index || !part_pointers || !part2Node))
@@ -519,7 +523,8 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
         hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
                            part2Node, part_pointers, num_parts, flag, seq,
-                           (num_parts > 0 && !tune.trust_canonical) ? 1 : 0, accumulate_into_out ? 0 : 1);
+                           (num_parts > 0 && !tune.trust_canonical) ? 1 : 0,
+                           (accumulate_into_out || win_begin > 0) ? 0 : 1);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
     }
@@ -552,6 +557,8 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
     const size_t x_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
 
+    const int64_t window_rows = (num_in_rows + num_windows - 1) / num_windows;
+
     // GCN: pre-scale the source rows once when every source row is gathered many times
     p.row_scale = nullptr;
     if (mode == MODE_GCN) {
@@ -561,10 +568,15 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             void *xs = nullptr;
             rc = get_workspace(ds, stream, 1, x_bytes, &xs);
             if (rc != GNNA_OK) return rc;
-            int64_t sblocks = (int64_t)((x_bytes / 16 + kBlock - 1) / kBlock);
+            // (windowed calls scale the rows of their own windows only: later windows may not have arrived)
+            const int64_t r0 = std::min<int64_t>((int64_t)win_begin * window_rows, num_in_rows);
+            const int64_t r1 = std::min<int64_t>((int64_t)win_end * window_rows, num_in_rows);
+            const size_t s_bytes = (size_t)(r1 - r0) * (size_t)dim * sizeof(float);
+            int64_t sblocks = (int64_t)((s_bytes / 16 + kBlock - 1) / kBlock);
             sblocks = std::max<int64_t>(1, std::min<int64_t>(sblocks, (int64_t)ds->num_cus * 8));
-            hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, input, degrees_in,
-                               static_cast<float *>(xs), num_in_rows, dim);
+            hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)sblocks), dim3(kBlock), 0, stream,
+                               input + (size_t)r0 * dim, degrees_in + r0,
+                               static_cast<float *>(xs) + (size_t)r0 * dim, r1 - r0, dim);
             hipError_t es = hipGetLastError();
             if (es != hipSuccess) return fail(GNNA_ERR_HIP, "prescale launch: %s", hipGetErrorString(es));
             p.X = static_cast<const float *>(xs);
@@ -573,26 +585,33 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             mode = MODE_GIN;  // unweighted gather + per-row factor at the flush
         }
     }
-    const int phases = choose_phases(tune, x_bytes, num_parts, partSize);
+    // phases: `sub` launches per source window (one window == the whole source range unless the caller
+    // pipelines a chunked feature exchange); this call runs the launches of windows [win_begin, win_end)
+    const int total = choose_phases(tune, x_bytes, num_parts, partSize);
+    const int sub = std::max(1, (total + num_windows / 2) / num_windows);
+    const int phases = sub * num_windows;
     t_last_phases = phases;
     AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
     p.cursor = nullptr; p.phase = 0; p.num_phases = 1; p.phase_hi = 0x7fffffff;
     p.acc_in = accumulate_into_out ? 1 : 0;
-    int64_t width = num_in_rows;
     if (phases > 1) {
         void *ws = nullptr;
         rc = get_workspace(ds, stream, 0, (size_t)num_parts * sizeof(int32_t), &ws);
         if (rc != GNNA_OK) return rc;
         p.cursor = static_cast<int32_t *>(ws);
         p.num_phases = phases;
-        width = (num_in_rows + phases - 1) / phases;
     }
-    for (int ph = 0; ph < phases; ph++) {
-        p.phase = ph;
-        p.phase_hi = (int32_t)std::min<int64_t>((int64_t)(ph + 1) * width, 0x7fffffff);
-        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
+    const int64_t sub_rows = (window_rows + sub - 1) / sub;
+    for (int w = win_begin; w < win_end; w++) {
+        for (int j = 0; j < sub; j++) {
+            p.phase = w * sub + j;
+            const int64_t hi = std::min<int64_t>((int64_t)w * window_rows + (int64_t)(j + 1) * sub_rows,
+                                                 (int64_t)(w + 1) * window_rows);
+            p.phase_hi = (int32_t)std::min<int64_t>(hi, 0x7fffffff);
+            hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
+        }
     }
     profile_record(prof_call, 2, stream);
     return GNNA_OK;
@@ -647,6 +666,20 @@ int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const i
     return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
                       part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0);
 }
+
+int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
+                              const float *degrees_out, const float *degrees_in, float epsilon,
+                              const int32_t *part_pointers, const int32_t *part2Node, float *out,
+                              int64_t num_out_rows, int dim, int64_t num_parts, int partSize, int accumulate,
+                              int num_windows, int window_begin, int window_end, void *stream)
+{
+    if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
+                      part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0,
+                      num_windows, window_begin, window_end);
+}
+
 int gnna_last_num_phases(void) { return t_last_phases; }
 
 #pragma GCC visibility pop

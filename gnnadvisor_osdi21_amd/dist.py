@@ -52,23 +52,51 @@ def shard_csr(row_pointers: torch.Tensor, column_index: torch.Tensor, lo: int, h
     return local_rp, column_index[beg:end].contiguous()
 
 
-def remap_columns_to_padded(column_index: torch.Tensor, bounds: Sequence[int], rows_per_rank: int):
-    """Global node id -> position in the padded all-gather layout
-    (owner_rank * rows_per_rank + id - bounds[owner_rank])."""
+def remap_columns_to_padded(column_index: torch.Tensor, bounds: Sequence[int], rows_per_rank: int,
+                            chunks: int = 1):
+    """Global node id -> position in the padded all-gather layout.
+
+    chunks == 1: rank-major, owner_rank * rows_per_rank + (id - bounds[owner_rank]).
+    chunks == K > 1 (pipelined exchange): every rank's padded block is cut into K sub-blocks of
+    rows_per_rank / K rows and the buffer is sub-block-major -- position
+    k * (world * rows_k) + owner_rank * rows_k + offset_in_sub_block -- so that the k-th
+    all-gather (sub-block k of every rank) fills one contiguous slice of the buffer, which is
+    exactly source window k of ``gnna_agg_rect_windows_f32``."""
+    assert rows_per_rank % chunks == 0
     b = torch.as_tensor(list(bounds), dtype=torch.int64, device=column_index.device)
+    world = len(bounds) - 1
     ci = column_index.to(torch.int64)
     owner = torch.searchsorted(b[1:], ci, right=True)
-    out = owner * rows_per_rank + (ci - b[owner])
+    off = ci - b[owner]
+    if chunks == 1:
+        out = owner * rows_per_rank + off
+    else:
+        rows_k = rows_per_rank // chunks
+        k = torch.div(off, rows_k, rounding_mode="floor")
+        out = k * (world * rows_k) + owner * rows_k + (off - k * rows_k)
     if int(out.max()) >= 2**31 if out.numel() else False:
         raise ValueError("padded node id exceeds int32")
     return out.to(torch.int32)
 
 
+def sort_columns_within_rows(row_pointers: torch.Tensor, column_index: torch.Tensor) -> torch.Tensor:
+    """Column ids of every CSR row in increasing order (the order the windowed / phased schedule
+    consumes them in).  Needed after a remap that is not monotonic in the global id."""
+    rp = row_pointers.to(torch.int64)
+    n = rp.numel() - 1
+    if column_index.numel() == 0:
+        return column_index
+    rows = torch.repeat_interleave(torch.arange(n, device=rp.device), rp[1:] - rp[:-1])
+    span = int(column_index.max()) + 1
+    key = rows * span + column_index.to(torch.int64)
+    return (torch.sort(key).values - rows * span).to(column_index.dtype)
+
+
 def _default_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
-                       degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False):
+                       degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False, windows=None):
     from . import _lib
     return _lib.agg_rect(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
-                         degrees_out, degrees_in, epsilon, out, accumulate)
+                         degrees_out, degrees_in, epsilon, out, accumulate, windows=windows)
 
 
 def _default_hints(avg_degree: float, nonlocal_ids: bool) -> None:
@@ -113,7 +141,8 @@ class ShardedAggregator:
                  bounds: Sequence[int], partSize: int = 32, *, group=None, device=None,
                  aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None,
                  overlap: bool = True, force_overlap: bool = False,
-                 hint_fn: Optional[Callable] = None, scattered_sources: bool = True):
+                 hint_fn: Optional[Callable] = None, scattered_sources: bool = True,
+                 pipeline_chunks: int = 0):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -122,6 +151,16 @@ class ShardedAggregator:
         self.n_local = self.bounds[self.rank + 1] - self.bounds[self.rank]
         assert local_row_pointers.numel() == self.n_local + 1
         self.rows_per_rank = max(1, max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world)))
+        self.overlap = bool(overlap) and (self.world > 1 or force_overlap)
+        # pipelined exchange: K all-gathers of 1/K of every block, each aggregated on arrival
+        # (0 = automatic: 4 pieces once the remote part is big enough to keep every piece busy)
+        K = int(pipeline_chunks)
+        if K <= 0:
+            remote_edges = column_index.numel() * (self.world - 1) // max(1, self.world)
+            K = 4 if (self.world > 1 and remote_edges >= (16 << 20)) else 1
+        self.chunks = max(1, min(K, 16, self.rows_per_rank)) if self.overlap else 1
+        self.chunk_rows = (self.rows_per_rank + self.chunks - 1) // self.chunks
+        self.rows_per_rank = self.chunk_rows * self.chunks          # padded so the pieces are equal
         self.partSize = int(partSize)
         self.device = torch.device(device) if device is not None else column_index.device
         # hints are only meaningful for the real kernel; an injected aggregate_fn gets none
@@ -134,11 +173,12 @@ class ShardedAggregator:
         pp, p2n = build_part_fn(self.partSize, local_row_pointers.cpu().contiguous())
         self.row_pointers = local_row_pointers.to(self.device)
         self.column_index = remap_columns_to_padded(column_index.to(self.device), self.bounds,
-                                                    self.rows_per_rank)
+                                                    self.rows_per_rank, self.chunks)
+        if self.chunks > 1:
+            self.column_index = sort_columns_within_rows(self.row_pointers, self.column_index)
         self.part_pointers = pp.to(self.device)
         self.part2Node = p2n.to(self.device)
         # local-source / remote-source split for the overlapped schedule
-        self.overlap = bool(overlap) and (self.world > 1 or force_overlap)
         if self.overlap:
             lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
             rp_l, ci_l, rp_r, ci_r = split_local_remote(local_row_pointers.to(self.device),
@@ -148,8 +188,10 @@ class ShardedAggregator:
             self.avg_degree_local = ci_l.numel() / max(1, self.n_local)
             self.avg_degree_remote = ci_r.numel() / max(1, self.n_local)
             self.local_part = (ci_l.contiguous(), pp_l.to(self.device), p2n_l.to(self.device))
-            self.remote_part = (remap_columns_to_padded(ci_r, self.bounds, self.rows_per_rank).contiguous(),
-                                pp_r.to(self.device), p2n_r.to(self.device))
+            ci_r = remap_columns_to_padded(ci_r, self.bounds, self.rows_per_rank, self.chunks)
+            if self.chunks > 1:
+                ci_r = sort_columns_within_rows(rp_r, ci_r)
+            self.remote_part = (ci_r.contiguous(), pp_r.to(self.device), p2n_r.to(self.device))
         self.avg_degree_all = column_index.numel() / max(1, self.n_local)
         self._gather_buf: Optional[torch.Tensor] = None
         self._pad_buf: Optional[torch.Tensor] = None
@@ -180,17 +222,46 @@ class ShardedAggregator:
                                            async_op=async_op)
         return (self._gather_buf, work) if async_op else self._gather_buf
 
+    def gather_feature_chunks(self, X_local: torch.Tensor):
+        """Pipelined exchange: K asynchronous all-gathers, the k-th moving sub-block k of every rank's
+        (padded) block into slice k of the sub-block-major buffer.  -> (buffer, [work handles])."""
+        assert X_local.shape[0] == self.n_local
+        D, K, rk = X_local.shape[1], self.chunks, self.chunk_rows
+        src = X_local
+        if self.n_local != self.rows_per_rank:
+            if self._pad_buf is None or self._pad_buf.shape != (self.rows_per_rank, D):
+                self._pad_buf = torch.zeros(self.rows_per_rank, D, dtype=X_local.dtype, device=X_local.device)
+            self._pad_buf[: self.n_local].copy_(X_local)
+            src = self._pad_buf
+        if self.world == 1:
+            return src, [None] * K
+        shape = (self.world * self.rows_per_rank, D)
+        if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != X_local.device:
+            self._gather_buf = torch.empty(shape, dtype=X_local.dtype, device=X_local.device)
+        works = []
+        for k in range(K):
+            dst = self._gather_buf[k * self.world * rk: (k + 1) * self.world * rk]
+            works.append(dist.all_gather_into_tensor(dst, src[k * rk: (k + 1) * rk], group=self.group,
+                                                     async_op=True))
+        return self._gather_buf, works
+
     def prepare_degrees(self, degrees_local: torch.Tensor) -> torch.Tensor:
         """all-gather the per-node degree norms once (graph constant) into the padded layout."""
         assert degrees_local.numel() == self.n_local
-        if self.world == 1:
+        if self.world == 1 and self.chunks == 1:
             self._deg_all = degrees_local
+        elif self.world == 1:
+            pad = torch.ones(self.rows_per_rank, dtype=degrees_local.dtype, device=degrees_local.device)
+            pad[: self.n_local] = degrees_local
+            self._deg_all = pad
         else:
             pad = torch.ones(self.rows_per_rank, dtype=degrees_local.dtype, device=degrees_local.device)
             pad[: self.n_local] = degrees_local
             buf = torch.empty(self.world * self.rows_per_rank, dtype=degrees_local.dtype,
                               device=degrees_local.device)
             dist.all_gather_into_tensor(buf, pad, group=self.group)
+            if self.chunks > 1:                                   # rank-major -> sub-block-major
+                buf = buf.view(self.world, self.chunks, self.chunk_rows).permute(1, 0, 2).reshape(-1).contiguous()
             self._deg_all = buf
         self._deg_src = degrees_local
         return self._deg_all
@@ -210,6 +281,8 @@ class ShardedAggregator:
                 self.hint_fn(self.avg_degree_all, self.scattered_sources)
             return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
                                      self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
+        if self.chunks > 1:
+            return self._aggregate_pipelined(X_local, mode, degrees_local, deg_in, epsilon, out)
         # overlapped: remote blocks travel while the local-source edges are aggregated
         X_all, work = self.gather_features(X_local, async_op=True)
         ci_l, pp_l, p2n_l = self.local_part
@@ -224,6 +297,26 @@ class ShardedAggregator:
             self.hint_fn(self.avg_degree_remote, self.scattered_sources)
         return self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
                                  degrees_local, deg_in, epsilon, out, accumulate=True)
+
+    def _aggregate_pipelined(self, X_local, mode, degrees_local, deg_in, epsilon, out):
+        """K-piece exchange: all pieces are put in flight at once; the local-source edges are
+        aggregated meanwhile, then source window k of the remote part as soon as piece k is there."""
+        X_all, works = self.gather_feature_chunks(X_local)
+        ci_l, pp_l, p2n_l = self.local_part
+        if self.hint_fn:
+            self.hint_fn(self.avg_degree_local, self.scattered_sources)
+        out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
+                                degrees_local, degrees_local, epsilon, out)
+        ci_r, pp_r, p2n_r = self.remote_part
+        if self.hint_fn:
+            self.hint_fn(self.avg_degree_remote, self.scattered_sources)
+        for k, work in enumerate(works):
+            if work is not None:
+                work.wait()
+            out = self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
+                                    degrees_local, deg_in, epsilon, out, accumulate=True,
+                                    windows=(self.chunks, k, k + 1))
+        return out
 
     def sag(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.aggregate(X_local, 0, out=out)

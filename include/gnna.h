@@ -136,6 +136,24 @@ GNNA_API int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows
                       float *out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
                       int accumulate, void *stream);
 
+/* Windowed form of gnna_agg_rect_f32, for pipelining the aggregation with a chunked feature
+ * exchange (multi-GPU: the all-gather is issued in `num_windows` pieces and each piece is
+ * aggregated as soon as it has arrived).  The source rows are cut into `num_windows` (1..16) equal
+ * windows of ceil(num_in_rows / num_windows) rows; this call aggregates the edges whose source
+ * lies in windows [window_begin, window_end) and must only read those rows of `input`.
+ * Contract: the calls of one aggregation are issued on one stream in increasing window order,
+ * starting at window 0 and ending at window num_windows-1, with identical other arguments and no
+ * other libgnna aggregation on that stream in between (per-run cursors live in the stream's
+ * scratch).  The first call overwrites `out` unless accumulate != 0; later calls add.  Column
+ * ids need not be sorted; an id below the current windows that was skipped earlier is consumed
+ * by a later call, and the last window consumes everything that is left.
+ */
+GNNA_API int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows,
+                      const int32_t *column_index, const float *degrees_out, const float *degrees_in,
+                      float epsilon, const int32_t *part_pointers, const int32_t *part2Node,
+                      float *out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
+                      int accumulate, int num_windows, int window_begin, int window_end, void *stream);
+
 /* SDDMM over the same neighbor-group partition -- a build-defined extension: the reference
  * contains no SDDMM kernel, BASELINE.json's north star asks for one.
  *   edge_out[e] = < dst_feat[part2Node[p], :], src_feat[column_index[e], :] >

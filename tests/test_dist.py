@@ -18,13 +18,21 @@ from gnnadvisor_osdi21_amd.dist import (ShardedAggregator, balanced_row_splits, 
 
 
 def _oracle_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_out_rows, partSize,
-                      degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False):
+                      degrees_out=None, degrees_in=None, epsilon=1.0, out=None, accumulate=False, windows=None):
     X = X_all.numpy(); ci = column_index.numpy(); pp = part_pointers.numpy(); p2n = part2Node.numpy()
     dim = X.shape[1]
     Y = np.zeros((num_out_rows, dim), dtype=np.float32)
+    lo_id, hi_id = 0, X.shape[0]
+    if windows is not None:                     # (K, begin, end): only sources inside these windows
+        K, wb, we = windows
+        wrows = (X.shape[0] + K - 1) // K
+        lo_id, hi_id = wb * wrows, we * wrows
+        accumulate = accumulate or wb > 0
     for p in range(len(p2n)):
         r = p2n[p]
         for e in range(pp[p], pp[p + 1]):
+            if not (lo_id <= ci[e] < hi_id):
+                continue
             c = 1.0
             if mode == 1:
                 c = np.float32(degrees_out[r].item()) * np.float32(degrees_in[ci[e]].item())
@@ -47,7 +55,7 @@ def _oracle_build_part(ps, rp):
     return torch.from_numpy(pp), torch.from_numpy(p2n)
 
 
-def _worker(rank, world, port, n, e, dim, seed, q, overlap=True):
+def _worker(rank, world, port, n, e, dim, seed, q, overlap=True, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -58,8 +66,8 @@ def _worker(rank, world, port, n, e, dim, seed, q, overlap=True):
         rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
         X = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1))
         agg = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate,
-                                build_part_fn=_oracle_build_part, overlap=overlap)
-        assert agg.overlap == overlap
+                                build_part_fn=_oracle_build_part, overlap=overlap, pipeline_chunks=chunks)
+        assert agg.overlap == overlap and agg.chunks == (chunks if overlap else 1)
         if overlap:
             assert agg.local_part[0].numel() + agg.remote_part[0].numel() == ci.numel()
             assert bool((agg.local_part[0] >= 0).all()) and bool((agg.local_part[0] < hi - lo).all())
@@ -81,12 +89,13 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n,e,overlap", [(101, 1500, True), (64, 40, True), (101, 1500, False)])
-def test_two_rank_sharded_aggregation_matches_single_graph(n, e, overlap):
+@pytest.mark.parametrize("n,e,overlap,chunks", [(101, 1500, True, 1), (64, 40, True, 1), (101, 1500, False, 1),
+                                                 (101, 1500, True, 3), (64, 40, True, 4)])
+def test_two_rank_sharded_aggregation_matches_single_graph(n, e, overlap, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, e, 12, 7, q, overlap)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, e, 12, 7, q, overlap, chunks)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]
@@ -140,7 +149,7 @@ def _train_worker(rank, world, port, n, e, q):
         lo, hi = bounds[rank], bounds[rank + 1]
         rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
         agg = ShardedAggregator(rp, ci, bounds, 3, aggregate_fn=_oracle_aggregate,
-                                build_part_fn=_oracle_build_part, overlap=True)
+                                build_part_fn=_oracle_build_part, overlap=True, pipeline_chunks=2)
         torch.manual_seed(100 + rank)                      # different draws: the broadcast must align them
         l1 = ShardedGCNConv(fin, hid, agg, device="cpu")
         l2 = ShardedGINConv(hid, ncls, agg, device="cpu")

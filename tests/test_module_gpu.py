@@ -230,7 +230,8 @@ def _check_local_plus_remote(g, D, ps):
             assert_close_f64(out.cpu().numpy(), ref[lo:hi], what=f"shard [{lo},{hi}) mode {mode}")
 
 
-def test_sharded_layers_on_one_gpu_equal_the_single_gpu_ops():
+@pytest.mark.parametrize("chunks", [0, 3])
+def test_sharded_layers_on_one_gpu_equal_the_single_gpu_ops(chunks):
     """world == 1 (no process group): the sharded GCN / GIN layers run the real kernel through
     ShardedAggregator (forced local/remote split + accumulate) and must reproduce ops.GCNConv /
     ops.GINConv outputs and gradients on the same graph and weights."""
@@ -240,8 +241,8 @@ def test_sharded_layers_on_one_gpu_equal_the_single_gpu_ops():
     fin, hid, ncls, ps = 20, 16, 7, 32
     info, _, _ = _info(g, fin, hid, partSize=ps)
     agg = ShardedAggregator(g.row_pointers, g.column_index, [0, g.num_nodes], ps, device="cuda",
-                            force_overlap=True)
-    assert agg.overlap
+                            force_overlap=True, pipeline_chunks=chunks)
+    assert agg.overlap and agg.chunks == max(1, chunks)
     torch.manual_seed(0)
     s1, s2 = ShardedGCNConv(fin, hid, agg), ShardedGINConv(hid, ncls, agg)
     r1, r2 = ops.GCNConv(fin, hid).cuda(), ops.GINConv(hid, ncls).cuda()

@@ -457,3 +457,61 @@ def test_hip_graph_capture_and_replay(phases, prescale):
                              scale=oracle.csr_f64(1, np.abs(Xn), rp, ci, deg))
     finally:
         _lib.reset_tuning()
+
+
+@pytest.mark.parametrize("K,dim,partSize,sorted_ids", [(2, 64, 32, True), (4, 64, 16, True), (3, 41, 8, True),
+                                                         (4, 64, 32, False), (16, 16, 4, True), (4, 257, 32, True)])
+def test_windowed_calls_pipeline_with_arriving_source_rows(K, dim, partSize, sorted_ids):
+    """gnna_agg_rect_windows_f32: the source rows arrive window by window (rows that have not arrived
+    hold NaN); one call per window, in order, must reproduce the one-shot aggregation in all three
+    modes, with and without accumulate, for sorted and shuffled column ids."""
+    g, Xc, ppc, p2nc = make_case(3000, 200000, dim, partSize, seed=K * 100 + dim, kind="powerlaw")
+    rp, deg = g.row_pointers.numpy(), g.degrees.numpy()
+    ci_t = g.column_index.clone()
+    if not sorted_ids:                                     # shuffle the ids inside every row
+        gen = torch.Generator().manual_seed(9)
+        rows = torch.repeat_interleave(torch.arange(g.num_nodes), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+        order = torch.argsort(rows.double() + torch.rand(ci_t.numel(), generator=gen, dtype=torch.float64) * 0.5)
+        ci_t = ci_t[order].contiguous()
+    ci = ci_t.numpy()
+    n = g.num_nodes
+    wrows = (n + K - 1) // K
+    X, cid, degd, pp, p2n = dev(Xc, ci_t, g.degrees, ppc, p2nc)
+    Xn = Xc.numpy()
+    base = torch.randn(n, dim, generator=torch.Generator().manual_seed(4))
+    for mode, eps, prescale in ((0, 1.0, 0), (1, 1.0, -1), (1, 1.0, 1), (2, 0.5, 0)):
+        ref = oracle.csr_f64(mode, Xn, rp, ci, deg, eps)
+        scale = oracle.csr_f64(mode, np.abs(Xn), rp, ci, deg, abs(eps))
+        for accumulate in (False, True):
+            try:
+                _lib.set_tuning(gcn_prescale=prescale)
+                live = torch.full_like(X, float("nan"))
+                out = base.clone().cuda() if accumulate else torch.full((n, dim), float("nan"), device="cuda")
+                for k in range(K):
+                    lo, hi = min(k * wrows, n), min((k + 1) * wrows, n)
+                    live[lo:hi] = X[lo:hi]
+                    _lib.agg_rect(mode, live, cid, pp, p2n, n, partSize, degrees_out=degd, degrees_in=degd,
+                                  epsilon=eps, out=out, accumulate=accumulate, windows=(K, k, k + 1))
+                assert _lib.last_num_phases() % K == 0
+            finally:
+                _lib.reset_tuning()
+            want = ref + (base.double().numpy() if accumulate else 0.0)
+            assert_close_f64(out.cpu().numpy(), want, what=f"windows K={K} mode={mode} acc={accumulate}",
+                             scale=scale + (np.abs(base.numpy()) if accumulate else 0.0))
+    # several windows per call, with sub-phases inside every window
+    try:
+        _lib.set_tuning(column_phases=2 * K)
+        out = torch.empty(n, dim, device="cuda")
+        half = max(1, K // 2)
+        _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 0, half))
+        if half < K:
+            _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, half, K))
+        assert _lib.last_num_phases() == 2 * K if 2 * K <= 16 else True
+    finally:
+        _lib.reset_tuning()
+    assert_close_f64(out.cpu().numpy(), oracle.csr_f64(0, Xn, rp, ci, deg), what="grouped windows",
+                     scale=oracle.csr_f64(0, np.abs(Xn), rp, ci, deg))
+    with pytest.raises(_lib.GnnaError):
+        _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 1, 1))
+    with pytest.raises(_lib.GnnaError):
+        _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(17, 0, 1))
