@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-chunks", type=int, default=0,
                     help="multi-GPU: pieces of the pipelined feature exchange (0 = automatic)")
+    ap.add_argument("--backend", default="nccl", help="debug: 'gloo' runs the N-rank path without RCCL")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="debug: take the sharded (torch.distributed) path even with one rank")
     args = ap.parse_args()
@@ -198,6 +200,8 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     sharded = world > 1 or args.force_dist
@@ -206,7 +210,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from gnnadvisor_osdi21_amd import _lib, graph
     from gnnadvisor_osdi21_amd.dist import ShardedAggregator
@@ -276,7 +283,7 @@ def main():
     for _ in range(args.warmup):
         step()
     sync_all()
-    _lib.profile_begin(args.steps)
+    _lib.profile_begin(args.steps * 32)                    # a sharded step is several library calls
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -285,6 +292,9 @@ def main():
     prof = _lib.profile_end()
 
     # max over ranks, total edges over ranks
+    calls_per_step = prof["calls"] / max(1, args.steps)
+    prof["main_ms"] *= calls_per_step                      # per-call averages -> per step
+    prof["prologue_ms"] *= calls_per_step
     stats = torch.tensor([elapsed, float(nnz_local), prof["main_ms"], float(P)], dtype=torch.float64, device=dev)
     if sharded:
         mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -320,8 +330,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "agg_kernel<4,16,SAG>", "kernel_ms": kern_ms,
-                         "kernel_launches_per_step": _lib.last_num_phases(),
-                         "kernel_ms_per_launch": kern_ms / max(1, _lib.last_num_phases()),
+                         "library_calls_per_step": calls_per_step,
+                         "kernel_launches_per_step": _lib.last_num_phases() if calls_per_step == 1 else None,
+                         "kernel_ms_per_launch": kern_ms / max(1, _lib.last_num_phases()) if calls_per_step == 1 else None,
                          "prologue_ms": prof["prologue_ms"], "algorithmic_bytes": alg_bytes,
                          "model": "gather: nnz*(4D+4) + N*(4D+4) + P*8",
                          "compulsory_GBs": compulsory_bytes(nnz_local, n_local, n_src, D) / (kern_ms * 1e-3) / 1e9

@@ -1,0 +1,95 @@
+"""Two ranks sharing the one GPU of the test box (gloo moves the device tensors): the whole
+multi-rank path of gnnadvisor_osdi21_amd/dist.py -- sharding, padded / sub-block-major layouts,
+asynchronous (optionally K-piece) all-gather, local + windowed remote aggregation -- with the
+real HIP kernels as the local aggregation, checked against the oracle on the full graph.
+(RCCL itself needs one GPU per rank; `bench.py --gpus N` covers it on a multi-GPU node.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, chunks, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import oracle
+        from gnnadvisor_osdi21_amd import _lib, graph
+        from gnnadvisor_osdi21_amd.dist import (ShardedAggregator, ShardedGCNConv, ShardedGINConv,
+                                                balanced_row_splits, shard_csr)
+        torch.cuda.set_device(0)
+        n, e, D, ps = 5000, 400000, 64, 32
+        g = graph.powerlaw_graph(n, e, 1500, seed=5)
+        bounds = balanced_row_splits(g.row_pointers, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        agg = ShardedAggregator(rp, ci, bounds, ps, device="cuda", pipeline_chunks=chunks)
+        assert agg.overlap and agg.chunks == chunks
+        X = torch.randn(n, D, generator=torch.Generator().manual_seed(8))
+        Xl = X[lo:hi].contiguous().cuda()
+        degl = g.degrees[lo:hi].contiguous().cuda()
+        rpn, cin, degn, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), X.numpy()
+        ok, worst = True, 0.0
+        for rep in range(3):                                    # buffers are reused from step to step
+            for mode, eps in ((0, 1.0), (1, 1.0), (2, 0.5)):
+                y = agg.aggregate(Xl, mode, degrees_local=degl, epsilon=eps)
+                ref = oracle.csr_f64(mode, Xn, rpn, cin, degn, eps)[lo:hi]
+                scale = np.maximum(1.0, oracle.csr_f64(mode, np.abs(Xn), rpn, cin, degn, eps)[lo:hi])
+                err = float((np.abs(y.cpu().numpy() - ref) / scale).max())
+                worst = max(worst, err)
+                ok &= err <= 1e-4
+        # one training step of the sharded layers against the single-GPU op layer on the whole graph
+        from gnnadvisor_osdi21_amd import ops
+        l1, l2 = ShardedGCNConv(12, 8, agg), ShardedGINConv(8, 5, agg)
+        F = torch.randn(n, 12, generator=torch.Generator().manual_seed(3))
+        Fl = F[lo:hi].contiguous().cuda().requires_grad_(True)
+        yl = l2(torch.relu(l1(Fl, degl)))
+        wgt = torch.linspace(0.5, 1.5, 5, device="cuda")
+        (yl * wgt).sum().backward()
+
+        class Info:
+            pass
+        info = Info()
+        pp, p2n = _lib.build_part(ps, g.row_pointers)
+        info.row_pointers, info.column_index, info.degrees = g.row_pointers.cuda(), g.column_index.cuda(), g.degrees.cuda()
+        info.partPtr, info.part2Node, info.partSize, info.dimWorker, info.warpPerBlock = pp.cuda(), p2n.cuda(), ps, 32, 4
+        _lib.reset_tuning()
+        r1, r2 = ops.GCNConv(12, 8).cuda(), ops.GINConv(8, 5).cuda()
+        with torch.no_grad():
+            r1.weights.copy_(l1.weights); r2.weights.copy_(l2.weights)
+        Fr = F.cuda().requires_grad_(True)
+        (r2(torch.relu(r1(Fr, info)), info) * wgt).sum().backward()
+        for a, b in ((Fl.grad, Fr.grad[lo:hi]), (l1.weights.grad, r1.weights.grad), (l2.weights.grad, r2.weights.grad)):
+            ok &= bool(torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max())))
+        q.put((rank, bool(ok), worst))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [1, 3])
+def test_two_ranks_sharing_the_gpu(chunks):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunks, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
