@@ -66,3 +66,18 @@ def test_loss_decreases_with_rabbit_and_auto_decider(capsys):
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0] and all(torch.isfinite(torch.tensor(losses)))
+
+
+@pytest.mark.parametrize("model,hidden", [("gcn", 16), ("gin", 64)])
+def test_hip_graph_epochs_train_like_eager_epochs(capsys, model, hidden):
+    """--hip_graph True records one epoch (forward, backward, Adam) and replays it: same final loss
+    as the eager loop from the same seed, same metric line."""
+    argv = ["--synthetic", "cora-like", "--dim", "96", "--hidden", str(hidden), "--classes", "7", "--model", model,
+            "--num_epoches", "12", "--manual_mode", "False", "--verbose_mode", "True"]
+    finals = []
+    for graph_flag in ("False", "True"):
+        torch.manual_seed(1234)
+        out = _run(capsys, argv + ["--hip_graph", graph_flag])
+        assert re.search(r"Time \(ms\): (\d+\.\d{3})", out)
+        finals.append(float(re.search(r"# final loss: (-?\d+\.\d+|nan|inf)", out).group(1)))
+    assert finals[0] == finals[0] and abs(finals[0] - finals[1]) <= 1e-3 * max(1.0, abs(finals[0])), finals
