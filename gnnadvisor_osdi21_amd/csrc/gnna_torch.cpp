@@ -201,6 +201,26 @@ std::vector<torch::Tensor> spmm_backward(torch::Tensor d_output, torch::Tensor X
                               partSize, dimWorker, warpPerBlock);
 }
 
+// Extension (not in the reference module): the weight gradient alone, for a first layer whose
+// input needs no gradient -- skips the [N, Fout] x [Fout, Fin] GEMM and the N x Fin write of d_input.
+std::vector<torch::Tensor> spmm_backward_weight(torch::Tensor d_output, torch::Tensor X,
+                                                torch::Tensor row_pointers, torch::Tensor column_index,
+                                                torch::Tensor degrees, torch::Tensor part_pointers,
+                                                torch::Tensor part2Node, int partSize, int dimWorker,
+                                                int warpPerBlock)
+{
+    CHECK_INPUT(d_output);
+    CHECK_INPUT(X);
+    CHECK_INPUT(row_pointers);
+    CHECK_INPUT(column_index);
+    CHECK_INPUT(degrees);
+    CHECK_INPUT(part_pointers);
+    CHECK_INPUT(part2Node);
+    auto d_input_prime = aggregate(AGG_GCN, d_output, row_pointers, column_index, &degrees, 1.f,
+                                   part_pointers, part2Node, partSize, dimWorker, warpPerBlock);
+    return {torch::mm(X.transpose(0, 1), d_input_prime)};
+}
+
 std::vector<torch::Tensor> spmm_forward_gin(torch::Tensor input, torch::Tensor weight,
                                             torch::Tensor row_pointers, torch::Tensor column_index,
                                             float epsilon, torch::Tensor part_pointers,
@@ -258,6 +278,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("SAG", &SAG, "GNNAdvisor base Scatter-and-Gather Kernel (HIP, gfx950)");
     m.def("forward", &spmm_forward, "GNNAdvisor forward (HIP, gfx950)");
     m.def("backward", &spmm_backward, "GNNAdvisor backward (HIP, gfx950)");
+    m.def("backward_weight", &spmm_backward_weight, "GNNAdvisor backward, d_weight only (extension)");
     m.def("forward_gin", &spmm_forward_gin, "GNNAdvisor forward GIN (HIP, gfx950)");
     m.def("backward_gin", &spmm_backward_gin, "GNNAdvisor backward GIN (HIP, gfx950)");
     m.def("build_part", &build_part, "GNNAdvisor neighbor-group partitioner (CPU)");

@@ -53,6 +53,9 @@ class GNNAFunction(Function):
     @staticmethod
     def backward(ctx, d_output):
         X, weight = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            # first layer: the features need no gradient (the reference computes and drops d_input)
+            return None, GNNA.backward_weight(d_output.contiguous(), X, *ctx.graph, *ctx.knobs)[0], None
         d_input, d_weight = GNNA.backward(d_output.contiguous(), X, weight, *ctx.graph, *ctx.knobs)
         return d_input, d_weight, None
 
@@ -73,6 +76,10 @@ class GNNAFunction_GIN(Function):
     def backward(ctx, d_output):
         X_agg, weight = ctx.saved_tensors
         rp, ci, pp, p2n = ctx.graph
+        if not ctx.needs_input_grad[0]:
+            # first layer: d_weight = T^T dY needs no aggregation at all; the reference aggregates
+            # dY W^T at the input width (F = 602 on Reddit) and drops the result
+            return None, torch.mm(X_agg.t(), d_output.contiguous()), None, None
         d_input, d_weight = GNNA.backward_gin(d_output.contiguous(), X_agg, weight, rp, ci,
                                               ctx.eplison, pp, p2n, *ctx.knobs)
         return d_input, d_weight, None, None

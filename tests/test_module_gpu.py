@@ -258,3 +258,21 @@ def test_sharded_layers_on_one_gpu_equal_the_single_gpu_ops(chunks):
                        (s2.weights.grad, r2.weights.grad, "dW2")):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max())), (what, float((a - b).abs().max()))
+
+
+def test_first_layer_shortcut_gives_the_same_weight_gradient():
+    """When the layer input needs no gradient the ops skip d_input (GCN: one GEMM less; GIN: no
+    backward aggregation at all); d_weight must equal the full backward's."""
+    from gnnadvisor_osdi21_amd import ops
+    g = graph.powerlaw_graph(900, 30000, 200, seed=41)
+    info, _, _ = _info(g, 24, 16)
+    X = torch.randn(g.num_nodes, 24, generator=torch.Generator().manual_seed(6)).cuda()
+    for conv in (ops.GCNConv(24, 16).cuda(), ops.GINConv(24, 16).cuda()):
+        grads = []
+        for needs in (True, False):
+            conv.zero_grad()
+            x = X.clone().requires_grad_(needs)
+            (conv(x, info) ** 2).sum().backward()
+            grads.append(conv.weights.grad.clone())
+            assert (x.grad is not None) == needs
+        assert torch.allclose(grads[0], grads[1], rtol=1e-5, atol=1e-5 * float(grads[0].abs().max()))
