@@ -167,6 +167,21 @@ torch::Tensor SAG(torch::Tensor input, torch::Tensor row_pointers, torch::Tensor
                     dimWorker, warpPerBlock);
 }
 
+// Extension (not in the reference module): the epsilon-scaled aggregation of forward_gin /
+// backward_gin on its own, eps * A * input -- lets the op layer run a GIN layer update-first.
+torch::Tensor aggregate_gin(torch::Tensor input, torch::Tensor row_pointers, torch::Tensor column_index,
+                            float epsilon, torch::Tensor part_pointers, torch::Tensor part2Node,
+                            int partSize, int dimWorker, int warpPerBlock)
+{
+    CHECK_INPUT(input);
+    CHECK_INPUT(row_pointers);
+    CHECK_INPUT(column_index);
+    CHECK_INPUT(part_pointers);
+    CHECK_INPUT(part2Node);
+    return aggregate(AGG_GIN, input, row_pointers, column_index, nullptr, epsilon, part_pointers, part2Node,
+                     partSize, dimWorker, warpPerBlock);
+}
+
 std::vector<torch::Tensor> spmm_forward(torch::Tensor input, torch::Tensor weight, torch::Tensor row_pointers,
                                         torch::Tensor column_index, torch::Tensor degrees,
                                         torch::Tensor part_pointers, torch::Tensor part2Node, int partSize,
@@ -278,6 +293,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("SAG", &SAG, "GNNAdvisor base Scatter-and-Gather Kernel (HIP, gfx950)");
     m.def("forward", &spmm_forward, "GNNAdvisor forward (HIP, gfx950)");
     m.def("backward", &spmm_backward, "GNNAdvisor backward (HIP, gfx950)");
+    m.def("aggregate_gin", &aggregate_gin, "eps * A * input (extension)");
     m.def("backward_weight", &spmm_backward_weight, "GNNAdvisor backward, d_weight only (extension)");
     m.def("forward_gin", &spmm_forward_gin, "GNNAdvisor forward GIN (HIP, gfx950)");
     m.def("backward_gin", &spmm_backward_gin, "GNNAdvisor backward GIN (HIP, gfx950)");

@@ -85,6 +85,33 @@ class GNNAFunction_GIN(Function):
         return d_input, d_weight, None, None
 
 
+def _row_units(width: int) -> int:
+    """Cost of aggregating one neighbor row of `width` floats, in 64-float wavefront sweeps."""
+    return (int(width) + 63) // 64
+
+
+class GNNAFunction_GIN_UpdateFirst(Function):
+    """The same GIN layer, Y = (eps A X) W, evaluated as eps A (X W): identical function (the
+    layer's "MLP" is one linear map, so it commutes with the neighbor sum; only the fp32
+    association differs), but both aggregations -- forward on X W, backward on dY -- run at the
+    output width.  Chosen by GINConv when the layer narrows (Reddit layer 1: 602 -> 64)."""
+
+    @staticmethod
+    def forward(ctx, X, weight, inputInfo, eplison):
+        rp, ci, _deg, pp, p2n = _graph_args(inputInfo)
+        ctx.graph, ctx.knobs, ctx.eplison = (rp, ci, pp, p2n), _knobs(inputInfo), eplison
+        ctx.save_for_backward(X, weight)
+        return GNNA.aggregate_gin(torch.mm(X, weight), rp, ci, eplison, pp, p2n, *ctx.knobs)
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X, weight = ctx.saved_tensors
+        rp, ci, pp, p2n = ctx.graph
+        G = GNNA.aggregate_gin(d_output.contiguous(), rp, ci, ctx.eplison, pp, p2n, *ctx.knobs)   # A symmetric
+        d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
+        return d_input, torch.mm(X.t(), G), None, None
+
+
 class _NeighborConv(Module):
     """Shared parameter handling of the two convolution modules."""
 
@@ -107,9 +134,22 @@ class GCNConv(_NeighborConv):
 
 
 class GINConv(_NeighborConv):
-    def __init__(self, input_dim, output_dim):
+    def __init__(self, input_dim, output_dim, update_first="auto"):
+        """update_first: False = the reference's order (aggregate at the input width, then X W);
+        True = update first; "auto" = whichever aggregates fewer 64-float sweeps per neighbor."""
         self.eplison = 0.5
+        self.update_first = update_first
         super().__init__(input_dim, output_dim)
 
+    def _use_update_first(self, X) -> bool:
+        if self.update_first != "auto":
+            return bool(self.update_first)
+        fin, fout = _row_units(self.weights.size(0)), _row_units(self.weights.size(1))
+        # aggregate-first: forward at Fin, plus backward at Fin when the input needs a gradient;
+        # update-first: forward and backward at Fout
+        needs_dx = X.requires_grad and torch.is_grad_enabled()
+        return 2 * fout < (2 * fin if needs_dx else fin)
+
     def forward(self, X, inputInfo):
-        return GNNAFunction_GIN.apply(X, self.weights, inputInfo, self.eplison)
+        fn = GNNAFunction_GIN_UpdateFirst if self._use_update_first(X) else GNNAFunction_GIN
+        return fn.apply(X, self.weights, inputInfo, self.eplison)
