@@ -26,7 +26,8 @@ class Tuning(ctypes.Structure):
     _fields_ = [("groups_per_chunk", ctypes.c_int), ("loads_in_flight", ctypes.c_int),
                 ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
                 ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int),
-                ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int)]
+                ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
+                ("pad_rows", ctypes.c_int)]
 
 
 _lib = None
@@ -115,9 +116,10 @@ def _stream(device: torch.device) -> int:
 
 
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
-               trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1) -> None:
+               trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
+               pad_rows=-1) -> None:
     t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
-               avg_degree, nonlocal_ids, gcn_prescale)
+               avg_degree, nonlocal_ids, gcn_prescale, pad_rows)
     load().gnna_set_tuning(ctypes.byref(t))
 
 

@@ -185,6 +185,10 @@ typedef struct gnna_tuning {
                              once (library workspace) and gather unweighted, 2 = per-edge
                              coefficients as the reference computes them, 0 = automatic
                              (pre-scale when a source row is gathered >= ~32 times)          */
+    int pad_rows;         /* 1 = gather from a staged copy of the source rows whose row stride is
+                             padded to a 128-byte-line-friendly size when the width calls for
+                             it (e.g. 41 -> 48, 56 -> 64 floats), 2 = never, 0 = automatic (when
+                             a source row is gathered >= ~32 times)                           */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */

@@ -515,3 +515,36 @@ def test_windowed_calls_pipeline_with_arriving_source_rows(K, dim, partSize, sor
         _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 1, 1))
     with pytest.raises(_lib.GnnaError):
         _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(17, 0, 1))
+
+
+@pytest.mark.parametrize("dim", [3, 5, 7, 22, 41, 47, 56, 60, 100, 172])
+@pytest.mark.parametrize("pad", [1, 2])
+def test_padded_row_staging_does_not_change_results(dim, pad):
+    """gnna_tuning.pad_rows: gathering from a staged copy of X with a line-friendly row stride
+    (41 -> 48 floats ...) against gathering from X itself -- all modes, phases, accumulate."""
+    g, Xc, ppc, p2nc = make_case(1500, 90000, dim, 16, seed=dim, kind="powerlaw")
+    rp, ci, deg, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), Xc.numpy()
+    X, rpd, cid, degd, pp, p2n = dev(Xc, g.row_pointers, g.column_index, g.degrees, ppc, p2nc)
+    n = g.num_nodes
+    try:
+        for phases in (1, 3):
+            _lib.set_tuning(pad_rows=pad, column_phases=phases)
+            for mode, eps, fn in ((0, 1.0, lambda o: _lib.sag(X, rpd, cid, degd, pp, p2n, 16, 32, 4, out=o)),
+                                  (1, 1.0, lambda o: _lib.agg_gcn(X, rpd, cid, degd, pp, p2n, 16, 32, 4, out=o)),
+                                  (2, 0.5, lambda o: _lib.agg_gin(X, rpd, cid, 0.5, pp, p2n, 16, 32, 4, out=o))):
+                out = torch.full((n, dim), float("nan"), device="cuda")
+                fn(out)
+                assert_close_f64(out.cpu().numpy(), oracle.csr_f64(mode, Xn, rp, ci, deg, eps),
+                                 what=f"pad={pad} D={dim} mode={mode} phases={phases}",
+                                 scale=oracle.csr_f64(mode, np.abs(Xn), rp, ci, deg, eps))
+        base = torch.randn(n, dim, generator=torch.Generator().manual_seed(2))
+        out = base.clone().cuda()
+        _lib.set_tuning(pad_rows=pad, column_phases=0)
+        for k in range(2):
+            _lib.agg_rect(1, X, cid, pp, p2n, n, 16, degrees_out=degd, degrees_in=degd, out=out, accumulate=True,
+                          windows=(2, k, k + 1))
+        assert_close_f64(out.cpu().numpy(), oracle.csr_f64(1, Xn, rp, ci, deg) + base.double().numpy(),
+                         what=f"pad={pad} D={dim} windows+accumulate",
+                         scale=oracle.csr_f64(1, np.abs(Xn), rp, ci, deg) + np.abs(base.numpy()))
+    finally:
+        _lib.reset_tuning()
