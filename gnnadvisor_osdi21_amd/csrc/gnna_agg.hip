@@ -451,8 +451,11 @@ int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, in
     if (tune.column_phases >= 1) {
         b = std::min(tune.column_phases, 16);
     } else if (tune.nonlocal_ids == 1 && tune.avg_degree > 0) {
-        const size_t per_phase = (size_t)15 << 20;
+        // measured optimum on the Reddit-like graph, D = 16 / 32 / 40 / 48 / 64 / 96 / 128:
+        // 2 / 2 / 3 / 3-4 / 4 / 5 / 8 phases, i.e. one phase per ~14 MB of X, two from 12 MB on
+        const size_t per_phase = 14000000;
         b = (int)std::min<size_t>(8, (x_bytes + per_phase / 2) / per_phase);
+        if (b < 2 && x_bytes >= 12000000) b = 2;
         b = std::min(b, tune.avg_degree / 50);
         const int64_t est_edges = std::min<int64_t>(num_parts * (int64_t)part_size, num_parts * (int64_t)tune.avg_degree);
         while (b > 1 && est_edges / b < ((int64_t)4 << 20)) b--;
