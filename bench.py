@@ -329,6 +329,9 @@ def main():
                        "tuning": _lib.get_tuning()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # fabric-side rate of the measured traffic (L2 <-> Infinity Cache / HBM) over the same kernel time
+                         "traffic_GBs": traffic / (kern_ms * 1e-3) / 1e9 if traffic and kern_ms > 0 else None,
+                         "traffic_frac": traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and kern_ms > 0 else None,
                          "kernel": "agg_kernel<4,16,SAG>", "kernel_ms": kern_ms,
                          "library_calls_per_step": calls_per_step,
                          "kernel_launches_per_step": _lib.last_num_phases() if calls_per_step == 1 else None,
