@@ -41,7 +41,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32")
+           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints")
 
 
 def load() -> ctypes.CDLL:
@@ -125,6 +125,17 @@ def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_re
 
 def reset_tuning() -> None:
     load().gnna_set_tuning(None)
+
+
+def set_graph_hints(column_index, avg_degree: float, nonlocal_ids: bool) -> None:
+    """Per-graph hints (keyed by the device address of `column_index`): average edges per destination
+    row and whether the source ids of a row are scattered over the whole id range.  avg_degree <= 0
+    forgets the graph; column_index None forgets all."""
+    L = load()
+    L.gnna_set_graph_hints.restype = ctypes.c_int
+    L.gnna_set_graph_hints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    ptr = None if column_index is None else column_index.data_ptr()
+    _check(L.gnna_set_graph_hints(ptr, int(avg_degree), 1 if nonlocal_ids else 0))
 
 
 def get_tuning() -> dict:

@@ -31,6 +31,17 @@ gnna_tuning g_tuning = kDefaultTuning;
 std::mutex g_tuning_mutex;
 std::once_flag g_env_once;
 
+// per-graph hints (gnna_set_graph_hints): a small table keyed by the graph's column_index pointer
+struct GraphHint {
+    const void *key = nullptr;
+    int avg_degree = 0;
+    int nonlocal_ids = 0;
+    uint64_t stamp = 0;
+};
+constexpr int kMaxGraphHints = 64;
+GraphHint g_hints[kMaxGraphHints];
+uint64_t g_hint_clock = 0;
+
 void apply_env()
 {
     const char *s = std::getenv("GNNA_TUNE");
@@ -59,6 +70,20 @@ void apply_env()
 }  // namespace
 
 namespace gnna {
+void apply_graph_hints(const void *column_index, gnna_tuning *tune)
+{
+    if (!column_index) return;
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    for (auto &h : g_hints) {
+        if (h.key == column_index) {
+            tune->avg_degree = h.avg_degree;
+            tune->nonlocal_ids = h.nonlocal_ids;
+            h.stamp = ++g_hint_clock;
+            return;
+        }
+    }
+}
+
 int fail(int code, const char *fmt, ...)
 {
     va_list ap;
@@ -109,6 +134,34 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->nonlocal_ids >= 0) g_tuning.nonlocal_ids = t->nonlocal_ids;
     if (t->gcn_prescale >= 0) g_tuning.gcn_prescale = t->gcn_prescale;
     if (t->pad_rows >= 0) g_tuning.pad_rows = t->pad_rows;
+}
+
+int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids)
+{
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    if (!column_index) {  // forget everything
+        for (auto &h : g_hints) h = GraphHint();
+        return GNNA_OK;
+    }
+    GraphHint *slot = nullptr;
+    for (auto &h : g_hints)
+        if (h.key == column_index) slot = &h;
+    if (avg_degree <= 0) {  // forget this graph
+        if (slot) *slot = GraphHint();
+        return GNNA_OK;
+    }
+    if (!slot) {  // free entry, else the least recently used one
+        slot = &g_hints[0];
+        for (auto &h : g_hints) {
+            if (!h.key) { slot = &h; break; }
+            if (h.stamp < slot->stamp) slot = &h;
+        }
+    }
+    slot->key = column_index;
+    slot->avg_degree = avg_degree;
+    slot->nonlocal_ids = nonlocal_ids ? 1 : 0;
+    slot->stamp = ++g_hint_clock;
+    return GNNA_OK;
 }
 
 void gnna_get_tuning(gnna_tuning *t)

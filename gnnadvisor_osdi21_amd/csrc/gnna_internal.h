@@ -17,6 +17,10 @@ namespace gnna {
 // Records a formatted message for gnna_last_error() on this thread and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Per-graph hints registered with gnna_set_graph_hints(), keyed by the column_index pointer of the
+// call; overrides tune->avg_degree / nonlocal_ids when there is an entry.  (gnna_host.cpp)
+void apply_graph_hints(const void *column_index, gnna_tuning *tune);
+
 // ---- per-device runtime state (gnna_runtime.hip) -------------------------------------------------
 struct Workspace {
     void *ptr = nullptr;

@@ -225,7 +225,9 @@ class inputProperty(object):
         return self
 
     def apply_tuning(self):
-        """Push the scheduler knobs and graph hints chosen by the mi355x policy into libgnna."""
+        """Push the scheduler knobs and graph hints chosen by the mi355x policy into libgnna.
+        The hints are registered for this graph (keyed by its device column_index array) when the
+        CSR already lives on the GPU, otherwise as process-wide defaults."""
         if self.groups_per_chunk is None and self.loads_in_flight is None and self.avg_degree_hint is None:
             return
         from . import _lib
@@ -233,9 +235,14 @@ class inputProperty(object):
         if nonlocal_ids is not None and self.reorder_status:
             nonlocal_ids = 0   # the graph has just been renumbered for locality
         _lib.set_tuning(groups_per_chunk=self.groups_per_chunk or -1,
-                        loads_in_flight=self.loads_in_flight or -1,
-                        avg_degree=-1 if self.avg_degree_hint is None else self.avg_degree_hint,
-                        nonlocal_ids=-1 if nonlocal_ids is None else nonlocal_ids)
+                        loads_in_flight=self.loads_in_flight or -1)
+        if self.avg_degree_hint is None:
+            return
+        ci = self.column_index
+        if ci is not None and getattr(ci, "is_cuda", False):
+            _lib.set_graph_hints(ci, self.avg_degree_hint, bool(nonlocal_ids))
+        else:
+            _lib.set_tuning(avg_degree=self.avg_degree_hint, nonlocal_ids=-1 if nonlocal_ids is None else nonlocal_ids)
 
     def print_param(self):
         if self.verbose_flag:

@@ -99,11 +99,12 @@ def _default_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_
                          degrees_out, degrees_in, epsilon, out, accumulate, windows=windows)
 
 
-def _default_hints(avg_degree: float, nonlocal_ids: bool) -> None:
-    """Tell libgnna what kind of CSR the next aggregation call works on (enables its
-    column-phased schedule for high-degree parts whose sources are scattered)."""
+def _default_hints(column_index: torch.Tensor, avg_degree: float, nonlocal_ids: bool) -> None:
+    """Tell libgnna what kind of CSR this column_index array belongs to (enables its column-phased
+    schedule for high-degree parts whose sources are scattered).  Registered once per part."""
     from . import _lib
-    _lib.set_tuning(avg_degree=max(1, int(avg_degree)), nonlocal_ids=1 if nonlocal_ids else 0)
+    if column_index.is_cuda and column_index.numel():
+        _lib.set_graph_hints(column_index, max(1, int(avg_degree)), nonlocal_ids)
 
 
 def split_local_remote(local_row_pointers: torch.Tensor, column_index: torch.Tensor, lo: int, hi: int):
@@ -193,6 +194,11 @@ class ShardedAggregator:
                 ci_r = sort_columns_within_rows(rp_r, ci_r)
             self.remote_part = (ci_r.contiguous(), pp_r.to(self.device), p2n_r.to(self.device))
         self.avg_degree_all = column_index.numel() / max(1, self.n_local)
+        if self.hint_fn:
+            self.hint_fn(self.column_index, self.avg_degree_all, self.scattered_sources)
+            if self.overlap:
+                self.hint_fn(self.local_part[0], self.avg_degree_local, self.scattered_sources)
+                self.hint_fn(self.remote_part[0], self.avg_degree_remote, self.scattered_sources)
         self._gather_buf: Optional[torch.Tensor] = None
         self._pad_buf: Optional[torch.Tensor] = None
         self._deg_all: Optional[torch.Tensor] = None
@@ -277,8 +283,6 @@ class ShardedAggregator:
             deg_in = self._deg_all
         if not self.overlap:
             X_all = self.gather_features(X_local)
-            if self.hint_fn:
-                self.hint_fn(self.avg_degree_all, self.scattered_sources)
             return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
                                      self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
         if self.chunks > 1:
@@ -286,15 +290,11 @@ class ShardedAggregator:
         # overlapped: remote blocks travel while the local-source edges are aggregated
         X_all, work = self.gather_features(X_local, async_op=True)
         ci_l, pp_l, p2n_l = self.local_part
-        if self.hint_fn:
-            self.hint_fn(self.avg_degree_local, self.scattered_sources)
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
                                 degrees_local, degrees_local, epsilon, out)
         if work is not None:
             work.wait()
         ci_r, pp_r, p2n_r = self.remote_part
-        if self.hint_fn:
-            self.hint_fn(self.avg_degree_remote, self.scattered_sources)
         return self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
                                  degrees_local, deg_in, epsilon, out, accumulate=True)
 
@@ -303,13 +303,9 @@ class ShardedAggregator:
         aggregated meanwhile, then source window k of the remote part as soon as piece k is there."""
         X_all, works = self.gather_feature_chunks(X_local)
         ci_l, pp_l, p2n_l = self.local_part
-        if self.hint_fn:
-            self.hint_fn(self.avg_degree_local, self.scattered_sources)
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
                                 degrees_local, degrees_local, epsilon, out)
         ci_r, pp_r, p2n_r = self.remote_part
-        if self.hint_fn:
-            self.hint_fn(self.avg_degree_remote, self.scattered_sources)
         for k, work in enumerate(works):
             if work is not None:
                 work.wait()

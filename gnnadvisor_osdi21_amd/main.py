@@ -93,7 +93,6 @@ def main(argv=None):
         inputInfo.print_param()
         print()
         print('----------------------------')
-    inputInfo.apply_tuning()
 
     # ---- neighbor partitioning -----------------------------------------------------------------
     start = time.perf_counter()
@@ -104,6 +103,7 @@ def main(argv=None):
     inputInfo.column_index = inputInfo.column_index.to(device)
     inputInfo.partPtr = partPtr.int().to(device)
     inputInfo.part2Node = part2Node.int().to(device)
+    inputInfo.apply_tuning()      # scheduler knobs + this graph's hints (keyed by the device column_index)
     degrees = inputInfo.degrees
 
     # ---- single-SpMM verification / profiling (GNNA_main.py:116-137) -------------------------------

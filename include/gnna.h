@@ -194,6 +194,13 @@ typedef struct gnna_tuning {
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
 GNNA_API void gnna_get_tuning(gnna_tuning *t);
 
+/* Per-graph form of the two hints: remembers (avg_degree, nonlocal_ids) for the graph whose
+ * column_index array starts at this device address; aggregation calls on that array use them
+ * instead of the process-wide gnna_tuning values.  avg_degree <= 0 forgets the graph,
+ * column_index == NULL forgets all graphs.  At most 64 graphs are remembered (least recently used
+ * is replaced).  A stale entry can only cost performance, never correctness. */
+GNNA_API int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids);
+
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
 GNNA_API int gnna_last_num_phases(void);
 

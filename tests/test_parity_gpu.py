@@ -548,3 +548,36 @@ def test_padded_row_staging_does_not_change_results(dim, pad):
                          scale=oracle.csr_f64(1, np.abs(Xn), rp, ci, deg) + np.abs(base.numpy()))
     finally:
         _lib.reset_tuning()
+
+
+def test_per_graph_hints_are_keyed_by_the_column_index_array():
+    """gnna_set_graph_hints: two graphs alive at once get their own schedule; forgetting a graph
+    falls back to the process-wide hints; results never depend on the hints."""
+    g1 = graph.make_config_graph("reddit-like", device="cuda", scale=0.25)
+    g2 = graph.make_config_graph("reddit-like", device="cuda", scale=0.2)
+    parts = []
+    for g in (g1, g2):
+        pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+        parts.append((pp.cuda(), p2n.cuda()))
+    X1 = torch.randn(g1.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    X2 = torch.randn(g2.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    run1 = lambda: _lib.sag(X1, g1.row_pointers, g1.column_index, g1.degrees, *parts[0], 64, 32, 4)
+    run2 = lambda: _lib.sag(X2, g2.row_pointers, g2.column_index, g2.degrees, *parts[1], 64, 32, 4)
+    try:
+        y1 = run1(); assert _lib.last_num_phases() == 1
+        _lib.set_graph_hints(g1.column_index, g1.nnz / g1.num_nodes, True)
+        y1h = run1(); assert _lib.last_num_phases() == 4       # 59.6 MB of X, scattered ids, degree ~490
+        run2(); assert _lib.last_num_phases() == 1             # the other graph is unaffected
+        _lib.set_graph_hints(g2.column_index, 40, True)
+        _lib.set_tuning(avg_degree=500, nonlocal_ids=1)        # process-wide hints lose against per-graph ones
+        run2(); assert _lib.last_num_phases() == 1
+        _lib.set_graph_hints(g2.column_index, 0, False)        # forget g2 -> process-wide hints apply
+        run2(); assert _lib.last_num_phases() >= 2
+        _lib.set_graph_hints(None, 0, False)                   # forget everything
+        _lib.reset_tuning()
+        run1(); assert _lib.last_num_phases() == 1
+    finally:
+        _lib.set_graph_hints(None, 0, False)
+        _lib.reset_tuning()
+    scale = _lib.sag(X1.abs(), g1.row_pointers, g1.column_index, g1.degrees, *parts[0], 64, 32, 4).double()
+    assert bool(((y1.double() - y1h.double()).abs() <= 1e-5 * scale.clamp(min=1.0)).all())
