@@ -41,7 +41,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints")
+           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32")
 
 
 def load() -> ctypes.CDLL:
@@ -284,6 +284,25 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
                                         part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
                                         int(num_out_rows), X.shape[1], part2Node.numel(), int(partSize),
                                         1 if accumulate else 0, _stream(X.device)))
+    return out
+
+
+def xtg(X, G, out=None):
+    """dW[K, N] = X^T G for X [M, K], G [M, N] (fp32, MFMA): the weight gradient of the dense update."""
+    if not X.is_cuda:
+        raise GnnaError("xtg needs device tensors: there is no CPU path in libgnna")
+    assert X.dtype == torch.float32 and G.dtype == torch.float32 and X.dim() == 2 and G.dim() == 2
+    assert X.shape[0] == G.shape[0]
+    X, G = X.contiguous(), G.contiguous()
+    if out is None:
+        out = torch.empty(X.shape[1], G.shape[1], dtype=torch.float32, device=X.device)
+    L = load()
+    L.gnna_xtg_f32.restype = ctypes.c_int
+    L.gnna_xtg_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_void_p]
+    with torch.cuda.device(X.device):
+        _check(L.gnna_xtg_f32(X.data_ptr(), G.data_ptr(), out.data_ptr(), X.shape[0], X.shape[1], G.shape[1],
+                              _stream(X.device)))
     return out
 
 

@@ -144,7 +144,7 @@ int gnna_profile_end(double *avg_main_ms, double *avg_prologue_ms, int *num_call
         main_ms += b;
     }
     const int n = g_prof.calls;
-    for (auto &e : g_prof.ev) hipEventDestroy(e);
+    for (auto &e : g_prof.ev) (void)hipEventDestroy(e);
     g_prof.ev.clear();
     g_prof.calls = 0;
     if (num_calls) *num_calls = n;

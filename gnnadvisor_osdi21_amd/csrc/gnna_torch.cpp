@@ -89,6 +89,25 @@ torch::Tensor aggregate(AggKind kind, const torch::Tensor &input, const torch::T
 
 // ---- host launchers: reference names (GNNAdvisor_kernel.cu:110,267,422,559,696) -------------
 
+// Weight gradient X^T G on the MFMA units (libgnna's tall-skinny kernel) in place of
+// torch::mm(X.transpose(0,1), G) (.cu:473, :710): the BLAS library runs this shape -- reduction
+// over the node dimension -- 5-14x off the memory bound.
+torch::Tensor xtg(const torch::Tensor &X, const torch::Tensor &G)
+{
+    TORCH_CHECK(X.dim() == 2 && G.dim() == 2 && X.size(0) == G.size(0), "xtg: X [M, K] and G [M, N] expected");
+    CHECK_F32(X);
+    CHECK_F32(G);
+    auto Xc = X.contiguous();
+    auto Gc = G.contiguous();
+    at::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(X.device());
+    auto dW = torch::empty({X.size(1), G.size(1)}, X.options());
+    void *stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    int rc = gnna_xtg_f32(Xc.data_ptr<float>(), Gc.data_ptr<float>(), dW.data_ptr<float>(), X.size(0),
+                          (int)X.size(1), (int)G.size(1), stream);
+    TORCH_CHECK(rc == GNNA_OK, "libgnna: ", gnna_last_error());
+    return dW;
+}
+
 torch::Tensor SAG_cuda(torch::Tensor input, torch::Tensor row_pointers, torch::Tensor column_index,
                        torch::Tensor degrees, torch::Tensor part_pointers, torch::Tensor part2Node,
                        int partSize, int dimWorker, int warpPerBlock)
@@ -120,7 +139,7 @@ std::vector<torch::Tensor> spmm_backward_cuda(torch::Tensor d_output, torch::Ten
     auto d_input_prime = aggregate(AGG_GCN, d_output, row_pointers, column_index, &degrees, 1.f,
                                    part_pointers, part2Node, partSize, dimWorker, warpPerBlock);
     auto d_input = torch::mm(d_input_prime, W.transpose(0, 1));
-    auto d_weight = torch::mm(X.transpose(0, 1), d_input_prime);
+    auto d_weight = xtg(X, d_input_prime);
     return {d_input, d_weight};
 }
 
@@ -144,7 +163,7 @@ std::vector<torch::Tensor> spmm_backward_cuda_gin(torch::Tensor d_output, torch:
                                                   torch::Tensor part2Node, int partSize, int dimWorker,
                                                   int warpPerBlock)
 {
-    auto d_weight = torch::mm(X.transpose(0, 1), d_output);
+    auto d_weight = xtg(X, d_output);
     auto d_input_prime = torch::mm(d_output, W.transpose(0, 1));
     auto d_input = aggregate(AGG_GIN, d_input_prime, row_pointers, column_index, nullptr, epsilon,
                              part_pointers, part2Node, partSize, dimWorker, warpPerBlock);
@@ -233,7 +252,7 @@ std::vector<torch::Tensor> spmm_backward_weight(torch::Tensor d_output, torch::T
     CHECK_INPUT(part2Node);
     auto d_input_prime = aggregate(AGG_GCN, d_output, row_pointers, column_index, &degrees, 1.f,
                                    part_pointers, part2Node, partSize, dimWorker, warpPerBlock);
-    return {torch::mm(X.transpose(0, 1), d_input_prime)};
+    return {xtg(X, d_input_prime)};
 }
 
 std::vector<torch::Tensor> spmm_forward_gin(torch::Tensor input, torch::Tensor weight,
@@ -293,6 +312,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("SAG", &SAG, "GNNAdvisor base Scatter-and-Gather Kernel (HIP, gfx950)");
     m.def("forward", &spmm_forward, "GNNAdvisor forward (HIP, gfx950)");
     m.def("backward", &spmm_backward, "GNNAdvisor backward (HIP, gfx950)");
+    m.def("xtg", [](torch::Tensor X, torch::Tensor G) { CHECK_CUDA(X); CHECK_CUDA(G); return xtg(X, G); },
+          "X^T G, the weight gradient of the dense update, on the MFMA units (extension)");
     m.def("aggregate_gin", &aggregate_gin, "eps * A * input (extension)");
     m.def("backward_weight", &spmm_backward_weight, "GNNAdvisor backward, d_weight only (extension)");
     m.def("forward_gin", &spmm_forward_gin, "GNNAdvisor forward GIN (HIP, gfx950)");

@@ -331,6 +331,14 @@ class ShardedAggregator:
 # gradient aggregation uses the same shard; dW = X_local^T G_local is a partial sum over the
 # rank's rows and is all-reduced (a [Fin, Fout] fp32 payload: latency-, not bandwidth-bound).
 
+def _xtg(X: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+    """X^T G (weight gradient): libgnna's MFMA kernel on the GPU, torch.mm for the CPU/gloo tests."""
+    if X.is_cuda:
+        from . import _lib
+        return _lib.xtg(X, G)
+    return torch.mm(X.t(), G)
+
+
 def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -351,7 +359,7 @@ class ShardedGCNFunction(torch.autograd.Function):
         X_local, weight = ctx.saved_tensors
         G = ctx.agg.gcn(d_output.contiguous(), ctx.deg)          # Â dY, rows of this rank
         d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
-        d_weight = _all_reduce_sum(torch.mm(X_local.t(), G), ctx.agg.group)
+        d_weight = _all_reduce_sum(_xtg(X_local, G), ctx.agg.group)
         return d_input, d_weight, None, None
 
 
@@ -369,7 +377,7 @@ class ShardedGINFunction(torch.autograd.Function):
     def backward(ctx, d_output):
         T, weight = ctx.saved_tensors
         d_output = d_output.contiguous()
-        d_weight = _all_reduce_sum(torch.mm(T.t(), d_output), ctx.agg.group)
+        d_weight = _all_reduce_sum(_xtg(T, d_output), ctx.agg.group)
         d_input = None
         if ctx.needs_input_grad[0]:
             d_input = ctx.agg.gin(torch.mm(d_output, weight.t()), ctx.epsilon)

@@ -79,7 +79,7 @@ class GNNAFunction_GIN(Function):
         if not ctx.needs_input_grad[0]:
             # first layer: d_weight = T^T dY needs no aggregation at all; the reference aggregates
             # dY W^T at the input width (F = 602 on Reddit) and drops the result
-            return None, torch.mm(X_agg.t(), d_output.contiguous()), None, None
+            return None, GNNA.xtg(X_agg, d_output.contiguous()), None, None
         d_input, d_weight = GNNA.backward_gin(d_output.contiguous(), X_agg, weight, rp, ci,
                                               ctx.eplison, pp, p2n, *ctx.knobs)
         return d_input, d_weight, None, None
@@ -109,7 +109,7 @@ class GNNAFunction_GIN_UpdateFirst(Function):
         rp, ci, pp, p2n = ctx.graph
         G = GNNA.aggregate_gin(d_output.contiguous(), rp, ci, ctx.eplison, pp, p2n, *ctx.knobs)   # A symmetric
         d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
-        return d_input, torch.mm(X.t(), G), None, None
+        return d_input, GNNA.xtg(X, G), None, None
 
 
 class _NeighborConv(Module):

@@ -165,6 +165,15 @@ GNNA_API int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const 
                    int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
                    void *stream);
 
+/* Weight gradient of the dense update: dW[K, N] = X^T[K, M] * G[M, N], X = [num_rows, K] and
+ * G = [num_rows, N] row-major fp32 (reference: torch::mm(X.transpose(0,1), d_input_prime),
+ * GNNAdvisor_kernel.cu:473 and :710).  A reduction over the node dimension on the MFMA units
+ * (v_mfma_f32_16x16x4_f32, fp32 in / fp32 accumulate); deterministic (no global atomics).
+ * dW is overwritten.  Uses library scratch of the stream (first use allocates).
+ */
+GNNA_API int gnna_xtg_f32(const float *X, const float *G, float *dW, int64_t num_rows, int K, int N,
+                 void *stream);
+
 /* ---- scheduling knobs (not part of the reference API; used by the tuner and bench) ----
  * Any field <= 0 (or < 0 where 0 is meaningful) keeps the built-in choice.
  */

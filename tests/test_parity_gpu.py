@@ -581,3 +581,18 @@ def test_per_graph_hints_are_keyed_by_the_column_index_array():
         _lib.reset_tuning()
     scale = _lib.sag(X1.abs(), g1.row_pointers, g1.column_index, g1.degrees, *parts[0], 64, 32, 4).double()
     assert bool(((y1.double() - y1h.double()).abs() <= 1e-5 * scale.clamp(min=1.0)).all())
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 64, 64), (4097, 100, 47), (333, 602, 41), (50000, 16, 22), (17, 3, 5),
+                                   (1, 7, 9), (0, 8, 8), (70001, 130, 65), (256, 1, 1)])
+def test_weight_gradient_kernel_matches_fp64(M, K, N):
+    """gnna_xtg_f32: dW = X^T G (MFMA, fp32) against the fp64 product; tails in all three dimensions."""
+    gen = torch.Generator().manual_seed(M + K + N)
+    X = torch.randn(M, K, generator=gen); G = torch.randn(M, N, generator=gen)
+    got = _lib.xtg(X.cuda(), G.cuda())
+    ref = X.double().t() @ G.double()
+    scale = X.double().abs().t() @ G.double().abs()
+    assert got.shape == (K, N)
+    assert_close_f64(got.cpu().numpy(), ref.numpy(), rtol=1e-5, what=f"xtg {M}x{K}x{N}", scale=scale.numpy())
+    # deterministic: the same call returns the same bits
+    assert torch.equal(got, _lib.xtg(X.cuda(), G.cuda()))
