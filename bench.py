@@ -177,6 +177,9 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
     ap.add_argument("--locality", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip the untimed extra legs (other_modes); used for rocprofv3 runs so that the kernel "
+                         "statistics contain the timed workload only")
     ap.add_argument("--pipeline-chunks", type=int, default=0,
                     help="multi-GPU: pieces of the pipelined feature exchange (0 = automatic)")
     ap.add_argument("--backend", default="nccl", help="debug: 'gloo' runs the N-rank path without RCCL")
@@ -342,7 +345,7 @@ def main():
                          if kern_ms > 0 else 0.0,
                          "kernel_edges_per_s": nnz_local / (kern_ms * 1e-3) if kern_ms > 0 else 0.0},
         }
-        if not sharded:
+        if not sharded and not args.headline_only:
             # the weighted forms of the same kernel (a-2 GCN coefficients, a-4 GIN epsilon), outside the timed region
             rec["other_modes"] = other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz_local)
         if not sharded and not args.no_cpu_baseline:

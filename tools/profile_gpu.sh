@@ -9,8 +9,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline $*"
-PBENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --headline-only $*"
+PBENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --headline-only $*"
 rocprofv3 --kernel-trace --stats -T -d $OUT/trace -o bench -f csv -- $BENCH > $OUT/trace_stdout.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM" \
