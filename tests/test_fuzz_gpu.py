@@ -19,7 +19,8 @@ DIMS = [1, 3, 4, 6, 16, 31, 64, 100, 129, 256, 257, 300]
 
 def _rand_tuning(rng):
     _lib.set_tuning(int(rng.integers(1, 64)), int(rng.choice([4, 8, 16])), int(rng.choice([0, 0, 2])),
-                    int(rng.integers(0, 2)), 0, int(rng.choice([1, 1, 2, 3, 7])), gcn_prescale=int(rng.choice([0, 1, 2])))
+                    int(rng.integers(0, 2)), 0, int(rng.choice([1, 1, 2, 3, 7])), gcn_prescale=int(rng.choice([0, 1, 2])),
+                    pad_rows=int(rng.choice([0, 1, 2])))
 
 
 def test_rect_accumulate_random():
@@ -45,10 +46,13 @@ def test_rect_accumulate_random():
             _lib.agg_rect(mode, Xd[lo:hi].contiguous(), ci_l.cuda(), pp_l.cuda(), p2n_l.cuda(), hi - lo, ps,
                           degrees_out=degd[lo:hi].contiguous(), degrees_in=degd[lo:hi].contiguous(), epsilon=eps, out=out)
             _rand_tuning(rng)
-            _lib.agg_rect(mode, Xd, ci_r.cuda(), pp_r.cuda(), p2n_r.cuda(), hi - lo, ps,
-                          degrees_out=degd[lo:hi].contiguous(), degrees_in=degd, epsilon=eps, out=out, accumulate=True)
+            K = int(rng.choice([0, 0, 1, 2, 3, 5, 16]))       # 0: one call; else one call per source window
+            for w in range(max(1, K)):
+                _lib.agg_rect(mode, Xd, ci_r.cuda(), pp_r.cuda(), p2n_r.cuda(), hi - lo, ps,
+                              degrees_out=degd[lo:hi].contiguous(), degrees_in=degd, epsilon=eps, out=out,
+                              accumulate=True, windows=(K, w, w + 1) if K else None)
             assert_close_f64(out.cpu().numpy(), ref, scale=scale,
-                             what=f"case {k}: n={n} e={e} D={D} ps={ps} mode={mode} [{lo},{hi}) {_lib.get_tuning()}")
+                             what=f"case {k}: n={n} e={e} D={D} ps={ps} mode={mode} K={K} [{lo},{hi}) {_lib.get_tuning()}")
     finally:
         _lib.reset_tuning()
 
@@ -108,3 +112,15 @@ def test_module_forward_backward_random():
             np.testing.assert_allclose(dWg.cpu().numpy(), rdWg, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdWg).max()))
     finally:
         _lib.reset_tuning()
+
+
+def test_weight_gradient_random():
+    rng = np.random.default_rng(SEED + 3)
+    for k in range(CASES):
+        M = int(rng.choice([1, 5, 63, 64, 65, 1000, 4099, 70000])); K = int(rng.integers(1, 200)); N = int(rng.integers(1, 150))
+        gen = torch.Generator().manual_seed(k)
+        X = torch.randn(M, K, generator=gen); G = torch.randn(M, N, generator=gen)
+        got = _lib.xtg(X.cuda(), G.cuda()).cpu().numpy()
+        ref = (X.double().t() @ G.double()).numpy()
+        scale = (X.double().abs().t() @ G.double().abs()).numpy()
+        assert_close_f64(got, ref, rtol=1e-5, scale=scale, what=f"xtg case {k}: M={M} K={K} N={N}")
