@@ -445,6 +445,8 @@ int choose_row_stride(int dim)
     return best;
 }
 
+}  // namespace
+
 int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size)
 {
     int b = 1;
@@ -463,6 +465,8 @@ int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, in
     while (b > 1 && num_parts / b < 64) b--;
     return std::max(b, 1);
 }
+
+namespace {
 typedef void (*AggKernel)(const AggParams);
 
 template <int VEC, int LPR, int MODE, int U>

@@ -21,6 +21,10 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // call; overrides tune->avg_degree / nonlocal_ids when there is an entry.  (gnna_host.cpp)
 void apply_graph_hints(const void *column_index, gnna_tuning *tune);
 
+// Number of column phases for a gather from `x_bytes` of source rows (gnna_agg.hip): tune.column_phases
+// when forced, else from the size of X and the two graph hints; 1 = single pass.
+int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size);
+
 // ---- per-device runtime state (gnna_runtime.hip) -------------------------------------------------
 struct Workspace {
     void *ptr = nullptr;

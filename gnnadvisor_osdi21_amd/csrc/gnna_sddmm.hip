@@ -48,9 +48,15 @@ struct SddmmParams {
     int64_t num_chunks;
     int32_t D;
     int32_t G;
+    // column-phased schedule (as in the aggregation kernel): launch `phase` handles, for every run,
+    // the edges from the run's cursor up to the first source id >= phase_hi
+    int32_t *cursor;
+    int32_t phase;
+    int32_t num_phases;
+    int32_t phase_hi;
 };
 
-template <int LPR, int U, bool WIDE>
+template <int LPR, int U, bool WIDE, bool PHASED>
 __global__ void __launch_bounds__(kBlock)
 sddmm_kernel(const SddmmParams p)
 {
@@ -76,11 +82,42 @@ sddmm_kernel(const SddmmParams p)
         const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
         const int my_row = lane < ng ? p.p2n[g0 + lane] : -1;
         const int my_pp = lane <= ng ? p.pp[g0 + lane] : 0;
-        // every group is walked on its own: each edge is written exactly once, no flush to share
-        for (int j = 0; j < ng; j++) {
-            const int row = __builtin_amdgcn_readlane(my_row, j);
-            const int sb = __builtin_amdgcn_readlane(my_pp, j);
-            const int se = __builtin_amdgcn_readlane(my_pp, j + 1);
+        // consecutive groups of one destination row form a run: one load of the row's piece, one
+        // contiguous edge segment.  Every edge is written exactly once, so there is no flush to share
+        // and any partition (canonical or not) is handled alike.
+        const int up_row = __shfl_up(my_row, 1);
+        const bool is_start = lane < ng && (lane == 0 || my_row != up_row);
+        unsigned long long starts = __ballot(is_start);
+        int my_cur = 0, new_cur = 0;
+        if constexpr (PHASED) {
+            if (p.phase > 0 && lane < ng) my_cur = p.cursor[g0 + lane];
+        }
+        while (starts) {
+            const int js = __builtin_ctzll(starts);
+            starts &= starts - 1;
+            const int je = starts ? __builtin_ctzll(starts) : ng;
+            const int row = __builtin_amdgcn_readlane(my_row, js);
+            int sb = __builtin_amdgcn_readlane(my_pp, js);
+            int se = __builtin_amdgcn_readlane(my_pp, je);
+            if constexpr (PHASED) {
+                if (p.phase > 0) sb = __builtin_amdgcn_readlane(my_cur, js);
+                if (p.phase + 1 < p.num_phases) {
+                    // end of this phase's piece: the contiguous prefix of ids below the bound
+                    int pe = sb;
+                    while (pe < se) {
+                        const int nv = se - pe < kWave ? se - pe : kWave;
+                        int id = 0x7fffffff;
+                        if (lane < nv) id = __builtin_nontemporal_load(p.col + pe + lane);
+                        const unsigned long long below = __ballot(lane < nv && id < p.phase_hi);
+                        const int take = below == ~0ull ? kWave : __builtin_ctzll(~below);
+                        pe += take;
+                        if (take < nv) break;
+                    }
+                    se = pe;
+                }
+                if (lane == js) new_cur = se;
+                if (sb >= se) continue;
+            }
             for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
                 const int piece = d0 + c * VEC;
                 const bool cvalid = piece < D;
@@ -125,21 +162,26 @@ sddmm_kernel(const SddmmParams p)
                 }
             }
         }
+        if constexpr (PHASED) {
+            if (is_start && p.phase + 1 < p.num_phases) p.cursor[g0 + lane] = new_cur;
+        }
     }
 }
 
 typedef void (*SddmmKernel)(const SddmmParams);
 
 template <int LPR>
-SddmmKernel pick_sddmm(bool wide)
+SddmmKernel pick_sddmm(bool wide, bool phased)
 {
     constexpr int U = LPR < 4 ? LPR : 4;
-    return wide ? sddmm_kernel<LPR, U, true> : sddmm_kernel<LPR, U, false>;
+    if (phased) return wide ? sddmm_kernel<LPR, U, true, true> : sddmm_kernel<LPR, U, false, true>;
+    return wide ? sddmm_kernel<LPR, U, true, false> : sddmm_kernel<LPR, U, false, false>;
 }
 
 int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *column_index,
                  const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
-                 int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, void *stream_v)
+                 int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
+                 void *stream_v)
 {
     if (num_out_rows < 0 || num_in_rows < 0 || dim < 0 || num_parts < 0)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size");
@@ -152,6 +194,8 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     if (rc != GNNA_OK) return rc;
     gnna_tuning tune;
     gnna_get_tuning(&tune);
+    apply_graph_hints(column_index, &tune);
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const int pieces = (dim + 3) / 4;
     int lpr = 4;
     while (lpr < 64 && lpr < pieces) lpr <<= 1;
@@ -160,20 +204,39 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     p.out = edge_out; p.P = num_parts; p.D = dim;
     p.G = std::max(1, std::min(tune.groups_per_chunk, 63));
     p.num_chunks = (num_parts + p.G - 1) / p.G;
-    const bool wide = (size_t)num_in_rows * (size_t)dim * sizeof(float) > 0xffffffffull;
+    const size_t b_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
+    const bool wide = b_bytes > 0xffffffffull;
+    // the source-side rows are gathered like the aggregation's, so the same column-phase rule applies,
+    // but a phase costs more here (per-edge dot-product fold, cursor scan) and the gain is smaller:
+    // measured on the Reddit-like graph (D = 64) 1 / 2 / 4 / 6 phases = 2.91 / 2.66 / 3.03 / 3.36 ms,
+    // D = 16 and the low-degree products-like graph lose -- automatic mode uses at most two
+    int phases = choose_phases(tune, b_bytes, num_parts, partSize);
+    if (tune.column_phases == 0) phases = (phases >= 4) ? 2 : 1;
+    p.cursor = nullptr; p.phase = 0; p.num_phases = phases; p.phase_hi = 0x7fffffff;
+    if (phases > 1) {
+        void *ws = nullptr;
+        rc = get_workspace(ds, stream, 0, (size_t)num_parts * sizeof(int32_t), &ws);
+        if (rc != GNNA_OK) return rc;
+        p.cursor = static_cast<int32_t *>(ws);
+    }
     SddmmKernel k;
     switch (lpr) {
-    case 4: k = pick_sddmm<4>(wide); break;
-    case 8: k = pick_sddmm<8>(wide); break;
-    case 16: k = pick_sddmm<16>(wide); break;
-    case 32: k = pick_sddmm<32>(wide); break;
-    default: k = pick_sddmm<64>(wide); break;
+    case 4: k = pick_sddmm<4>(wide, phases > 1); break;
+    case 8: k = pick_sddmm<8>(wide, phases > 1); break;
+    case 16: k = pick_sddmm<16>(wide, phases > 1); break;
+    case 32: k = pick_sddmm<32>(wide, phases > 1); break;
+    default: k = pick_sddmm<64>(wide, phases > 1); break;
     }
     int64_t grid = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
     grid = std::max<int64_t>(1, std::min<int64_t>(grid, 0x7fffffff));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, static_cast<hipStream_t>(stream_v), p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "sddmm launch: %s", hipGetErrorString(e));
+    const int64_t width = (num_in_rows + phases - 1) / phases;
+    for (int ph = 0; ph < phases; ph++) {
+        p.phase = ph;
+        p.phase_hi = (int32_t)std::min<int64_t>((int64_t)(ph + 1) * width, 0x7fffffff);
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "sddmm launch: %s", hipGetErrorString(e));
+    }
     return GNNA_OK;
 }
 
@@ -192,7 +255,7 @@ int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const int32_t *
 {
     if (partSize <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "partSize must be positive (got %d)", partSize);
     return launch_sddmm(dst_feat, src_feat, column_index, part_pointers, part2Node, edge_out, num_out_rows,
-                        num_in_rows, dim, num_parts, stream);
+                        num_in_rows, dim, num_parts, partSize, stream);
 }
 
 #pragma GCC visibility pop

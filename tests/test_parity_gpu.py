@@ -596,3 +596,30 @@ def test_weight_gradient_kernel_matches_fp64(M, K, N):
     assert_close_f64(got.cpu().numpy(), ref.numpy(), rtol=1e-5, what=f"xtg {M}x{K}x{N}", scale=scale.numpy())
     # deterministic: the same call returns the same bits
     assert torch.equal(got, _lib.xtg(X.cuda(), G.cuda()))
+
+
+@pytest.mark.parametrize("dim,partSize,phases,sorted_ids", [(64, 32, 3, True), (16, 8, 5, True), (41, 64, 2, True),
+                                                            (300, 16, 4, True), (64, 32, 4, False), (64, 1, 16, True)])
+def test_sddmm_column_phases_match_single_pass(dim, partSize, phases, sorted_ids):
+    """SDDMM with the column-phased schedule (per-run cursors): every edge written exactly once, for
+    sorted and shuffled column ids, partitions whose rows span several groups, and empty rows."""
+    g = graph.powerlaw_graph(1200, 90000, 600, seed=dim + phases)
+    ci_t = g.column_index.clone()
+    if not sorted_ids:
+        rows = torch.repeat_interleave(torch.arange(g.num_nodes), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+        order = torch.argsort(rows.double() + torch.rand(ci_t.numel(), generator=torch.Generator().manual_seed(1),
+                                                         dtype=torch.float64) * 0.5)
+        ci_t = ci_t[order].contiguous()
+    pp, p2n = _lib.build_part(partSize, g.row_pointers)
+    gen = torch.Generator().manual_seed(dim)
+    A = torch.randn(g.num_nodes, dim, generator=gen); B = torch.randn(g.num_nodes, dim, generator=gen)
+    ref = oracle.np_sddmm(A.numpy(), B.numpy(), g.row_pointers.numpy(), ci_t.numpy())
+    rows = np.repeat(np.arange(g.num_nodes), np.diff(g.row_pointers.numpy()))
+    scale = np.einsum("ed,ed->e", np.abs(A.numpy().astype(np.float64))[rows], np.abs(B.numpy().astype(np.float64))[ci_t.numpy()])
+    try:
+        _lib.set_tuning(column_phases=phases)
+        out = torch.full((ci_t.numel(),), float("nan"), device="cuda")
+        _lib.sddmm(A.cuda(), B.cuda(), ci_t.cuda(), pp.cuda(), p2n.cuda(), partSize, out=out)
+    finally:
+        _lib.reset_tuning()
+    assert_close_f64(out.cpu().numpy(), ref, what=f"sddmm phases={phases}", scale=scale, rtol=1e-5)
