@@ -29,8 +29,10 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); before HIP starts
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -213,10 +215,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        limit = datetime.timedelta(seconds=300)                # a rank that dies must not hang the others for long
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(args.backend)
+            dist.init_process_group(args.backend, timeout=limit)
 
     from gnnadvisor_osdi21_amd import _lib, graph
     from gnnadvisor_osdi21_amd.dist import ShardedAggregator
