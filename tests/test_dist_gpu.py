@@ -93,3 +93,25 @@ def test_two_ranks_sharing_the_gpu(chunks):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
+
+
+@pytest.mark.parametrize("model", ["gcn", "gin"])
+def test_sharded_training_driver_two_ranks(model):
+    """python -m torch.distributed.run ... -m gnnadvisor_osdi21_amd.dist_main: epochs run, the loss
+    is finite, replicated weights stay bit-identical, the reference's metric line is printed."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           "-m", "gnnadvisor_osdi21_amd.dist_main", "--synthetic", "reddit-like", "--scale", "0.03",
+           "--dim", "40", "--hidden", "16", "--classes", "5", "--model", model, "--num_epoches", "3",
+           "--backend", "gloo", "--share_gpu", "--pipeline_chunks", "2", "--verbose_mode", "True"]
+    res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = res.stdout
+    assert re.search(r"Time \(ms\): \d+\.\d{3}", out), out
+    assert "# weights identical on all ranks: True" in out, out
+    loss = float(re.search(r"# final loss: (-?\d+\.\d+|nan|inf)", out).group(1))
+    assert loss == loss and abs(loss) < 1e6
