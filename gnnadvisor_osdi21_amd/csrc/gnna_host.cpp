@@ -123,7 +123,7 @@ void gnna_set_tuning(const gnna_tuning *t)
 {
     std::call_once(g_env_once, apply_env);
     std::lock_guard<std::mutex> lock(g_tuning_mutex);
-    if (!t) { g_tuning = kDefaultTuning; return; }
+    if (!t) { g_tuning = kDefaultTuning; apply_env(); return; }  // defaults = built-in values + GNNA_TUNE
     if (t->groups_per_chunk > 0) g_tuning.groups_per_chunk = t->groups_per_chunk;
     if (t->loads_in_flight > 0) g_tuning.loads_in_flight = t->loads_in_flight;
     if (t->blocks_per_cu >= 0) g_tuning.blocks_per_cu = t->blocks_per_cu;
