@@ -32,12 +32,11 @@ typedef VecOf<4>::T f32x4;
 typedef VecOf<4>::M f32x4_mem;
 constexpr int kTile = 64;
 
-// 4 consecutive floats of row `row` starting at column `col`; zeros outside [0, ncols) x [.., row_end)
-__device__ __forceinline__ f32x4 load4(const float *__restrict__ P, int64_t row, int col, int ncols, int64_t row_end)
+// 4 consecutive floats at p (= row start + col); zeros for columns >= ncols and when !row_ok
+__device__ __forceinline__ f32x4 load4(const float *__restrict__ p, int col, int ncols, bool row_ok)
 {
     f32x4 v = (f32x4)(0.f);
-    if (row < row_end && col < ncols) {
-        const float *p = P + row * (int64_t)ncols + col;
+    if (row_ok && col < ncols) {
         if (col + 4 <= ncols) {
             v = *reinterpret_cast<const f32x4_mem *>(p);
         } else {
@@ -49,16 +48,27 @@ __device__ __forceinline__ f32x4 load4(const float *__restrict__ P, int64_t row,
     return v;
 }
 
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 xtg_kernel(const float *__restrict__ X, const float *__restrict__ G, float *__restrict__ part,
            int64_t M, int K, int N, int64_t rows_per_block, int kblocks, int nblocks)
 {
     __shared__ float tile[kTile * kTile];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t bid = blockIdx.x;
+    // Hardware deals consecutive blocks to the 8 XCDs in turn; the tiles of one slab read the same rows
+    // of X and G, so they are placed on one XCD (one L2): block x + 8 y is the y-th (slab, tile) pair of
+    // XCD x.  Slabs beyond the last full round of 8 keep the plain order.
+    const int64_t tiles = (int64_t)nblocks * kblocks;
+    int64_t bid = blockIdx.x;
+    {
+        const int64_t full = (int64_t)gridDim.x / (kXcds * tiles) * (kXcds * tiles);
+        if (bid < full) {
+            const int64_t x = bid % kXcds, y = bid / kXcds;
+            bid = ((y / tiles) * kXcds + x) * tiles + y % tiles;
+        }
+    }
     const int nb = (int)(bid % nblocks);
     const int kb = (int)((bid / nblocks) % kblocks);
-    const int64_t slab = bid / ((int64_t)nblocks * kblocks);
+    const int64_t slab = bid / tiles;
     const int64_t m_begin = slab * rows_per_block;
     const int64_t m_end = m_begin + rows_per_block < M ? m_begin + rows_per_block : M;
     const int s = lane >> 4, q = lane & 15;
@@ -70,23 +80,24 @@ xtg_kernel(const float *__restrict__ X, const float *__restrict__ G, float *__re
 #pragma unroll
         for (int d = 0; d < 4; d++) acc[c][d] = (f32x4)(0.f);
 
-    // 4 waves x 4 rows per step (wave-uniform base row `mb`, lane row mb + s).  Software pipeline:
-    // the loads of the next two steps are issued before the 32 MFMAs of the current two.
-    int64_t mb = m_begin + wave * 4;
-    f32x4 a0 = load4(X, mb + s, kc, K, m_end), b0 = load4(G, mb + s, nc, N, m_end);
-    f32x4 a1 = load4(X, mb + 16 + s, kc, K, m_end), b1 = load4(G, mb + 16 + s, nc, N, m_end);
-    for (; mb < m_end; mb += 32) {
-        const f32x4 na0 = load4(X, mb + 32 + s, kc, K, m_end), nb0 = load4(G, mb + 32 + s, nc, N, m_end);
-        const f32x4 na1 = load4(X, mb + 48 + s, kc, K, m_end), nb1 = load4(G, mb + 48 + s, nc, N, m_end);
+    // 4 waves x 4 rows per step: this lane's rows are lr, lr + 16, ... of the slab.  Software pipeline:
+    // the two loads of the next step are issued before the 16 MFMAs of the current one.  Pointers walk
+    // by 16 rows; everything is relative to the slab so that the row index stays a small int.
+    const int nrows = (int)(m_end - m_begin);
+    int lr = wave * 4 + s;
+    const float *xp = X + (m_begin + lr) * (int64_t)K + kc;
+    const float *gp = G + (m_begin + lr) * (int64_t)N + nc;
+    const int64_t xstep = (int64_t)16 * K, gstep = (int64_t)16 * N;
+    const int steps = (nrows - wave * 4 + 15) / 16;   // wave-uniform: steps in which this wave has at least one row
+    f32x4 a = load4(xp, kc, K, lr < nrows), b = load4(gp, nc, N, lr < nrows);
+    for (int it = 0; it < steps; it++) {
+        xp += xstep; gp += gstep; lr += 16;
+        const f32x4 na = load4(xp, kc, K, lr < nrows), nb4 = load4(gp, nc, N, lr < nrows);
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int d = 0; d < 4; d++) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b0[d], acc[c][d], 0, 0, 0);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
-#pragma unroll
-            for (int d = 0; d < 4; d++) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[c], b1[d], acc[c][d], 0, 0, 0);
-        a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+            for (int d = 0; d < 4; d++) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[d], acc[c][d], 0, 0, 0);
+        a = na; b = nb4;
     }
 
     // D layout of v_mfma_f32_16x16x4_f32: lane (s, q), register r holds D[i = 4 s + r][j = q].
