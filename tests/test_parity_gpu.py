@@ -352,7 +352,10 @@ def test_automatic_phase_selection_follows_the_hints():
         _lib.set_tuning(nonlocal_ids=0)
         _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
         assert _lib.last_num_phases() == 1                     # locality-ordered ids: never
-        _lib.set_tuning(avg_degree=40, nonlocal_ids=1)
+        _lib.set_tuning(avg_degree=50, nonlocal_ids=1)
+        _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        assert _lib.last_num_phases() == 2                     # ~50 edges per row: two phases at most
+        _lib.set_tuning(avg_degree=30, nonlocal_ids=1)
         _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
         assert _lib.last_num_phases() == 1                     # low-degree rows: not worth it
     finally:
@@ -568,7 +571,7 @@ def test_per_graph_hints_are_keyed_by_the_column_index_array():
         _lib.set_graph_hints(g1.column_index, g1.nnz / g1.num_nodes, True)
         y1h = run1(); assert _lib.last_num_phases() == 4       # 59.6 MB of X, scattered ids, degree ~490
         run2(); assert _lib.last_num_phases() == 1             # the other graph is unaffected
-        _lib.set_graph_hints(g2.column_index, 40, True)
+        _lib.set_graph_hints(g2.column_index, 30, True)
         _lib.set_tuning(avg_degree=500, nonlocal_ids=1)        # process-wide hints lose against per-graph ones
         run2(); assert _lib.last_num_phases() == 1
         _lib.set_graph_hints(g2.column_index, 0, False)        # forget g2 -> process-wide hints apply
