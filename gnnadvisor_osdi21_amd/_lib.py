@@ -79,6 +79,11 @@ def load() -> ctypes.CDLL:
     L.gnna_agg_rect_windows_f32.restype = ctypes.c_int
     L.gnna_agg_rect_windows_f32.argtypes = (L.gnna_agg_rect_f32.argtypes[:-1]
                                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
+    L.gnna_set_graph_hints.restype = ctypes.c_int
+    L.gnna_set_graph_hints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.gnna_xtg_f32.restype = ctypes.c_int
+    L.gnna_xtg_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                               ctypes.c_int, ctypes.c_void_p]
     L.gnna_csr_from_edges_i32.restype = ctypes.c_int64
     L.gnna_csr_from_edges_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]
@@ -131,11 +136,8 @@ def set_graph_hints(column_index, avg_degree: float, nonlocal_ids: bool) -> None
     """Per-graph hints (keyed by the device address of `column_index`): average edges per destination
     row and whether the source ids of a row are scattered over the whole id range.  avg_degree <= 0
     forgets the graph; column_index None forgets all."""
-    L = load()
-    L.gnna_set_graph_hints.restype = ctypes.c_int
-    L.gnna_set_graph_hints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     ptr = None if column_index is None else column_index.data_ptr()
-    _check(L.gnna_set_graph_hints(ptr, int(avg_degree), 1 if nonlocal_ids else 0))
+    _check(load().gnna_set_graph_hints(ptr, int(avg_degree), 1 if nonlocal_ids else 0))
 
 
 def get_tuning() -> dict:
@@ -296,12 +298,8 @@ def xtg(X, G, out=None):
     X, G = X.contiguous(), G.contiguous()
     if out is None:
         out = torch.empty(X.shape[1], G.shape[1], dtype=torch.float32, device=X.device)
-    L = load()
-    L.gnna_xtg_f32.restype = ctypes.c_int
-    L.gnna_xtg_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
-                               ctypes.c_int, ctypes.c_void_p]
     with torch.cuda.device(X.device):
-        _check(L.gnna_xtg_f32(X.data_ptr(), G.data_ptr(), out.data_ptr(), X.shape[0], X.shape[1], G.shape[1],
+        _check(load().gnna_xtg_f32(X.data_ptr(), G.data_ptr(), out.data_ptr(), X.shape[0], X.shape[1], G.shape[1],
                               _stream(X.device)))
     return out
 

@@ -126,7 +126,7 @@ xtg_kernel(const float *__restrict__ X, const float *__restrict__ G, float *__re
 // row; thread (e, g) = (tid % 16, tid / 16) sums slabs g, g + 16, ... (independent loads, 64-byte
 // coalesced), the 16 partial sums of an element are folded in LDS.
 __global__ void __launch_bounds__(kBlock)
-xtg_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int K, int N, int64_t slabs,
+xtg_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW, int N, int64_t slabs,
                   int kblocks, int nblocks)
 {
     __shared__ float fold[16][17];
@@ -192,7 +192,7 @@ int gnna_xtg_f32(const float *X, const float *G, float *dW, int64_t num_rows, in
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "xtg launch: %s", hipGetErrorString(e));
     const int64_t rblocks = (int64_t)K * ((N + 15) / 16);
     hipLaunchKernelGGL(xtg_reduce_kernel, dim3((unsigned)rblocks), dim3(kBlock), 0, stream,
-                       static_cast<const float *>(ws), dW, K, N, slabs, kblocks, nblocks);
+                       static_cast<const float *>(ws), dW, N, slabs, kblocks, nblocks);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "xtg reduce launch: %s", hipGetErrorString(e));
     return GNNA_OK;
