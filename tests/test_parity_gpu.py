@@ -17,7 +17,7 @@ from util import assert_close_f64, dev, make_case
 
 pytestmark = pytest.mark.gpu
 
-DIMS = [1, 2, 3, 4, 6, 7, 8, 16, 32, 41, 64, 100, 128, 256, 300, 602]
+DIMS = [1, 2, 3, 4, 6, 7, 8, 16, 32, 41, 64, 100, 128, 256, 300, 602, 1433, 3703]
 
 
 def run_all_modes(g, X, pp, p2n, partSize, eps=0.5):
