@@ -89,15 +89,30 @@ xtg_kernel(const float *__restrict__ X, const float *__restrict__ G, float *__re
     const float *gp = G + (m_begin + lr) * (int64_t)N + nc;
     const int64_t xstep = (int64_t)16 * K, gstep = (int64_t)16 * N;
     const int steps = (nrows - wave * 4 + 15) / 16;   // wave-uniform: steps in which this wave has at least one row
-    f32x4 a = load4(xp, kc, K, lr < nrows), b = load4(gp, nc, N, lr < nrows);
-    for (int it = 0; it < steps; it++) {
+    // kPrefetch steps are in flight: the loads of step it + kPrefetch are issued right after the MFMAs
+    // of step it have consumed their registers
+    constexpr int kPrefetch = 3;
+    f32x4 a[kPrefetch], b[kPrefetch];
+#pragma unroll
+    for (int j = 0; j < kPrefetch; j++) {
+        a[j] = load4(xp, kc, K, lr < nrows);
+        b[j] = load4(gp, nc, N, lr < nrows);
         xp += xstep; gp += gstep; lr += 16;
-        const f32x4 na = load4(xp, kc, K, lr < nrows), nb4 = load4(gp, nc, N, lr < nrows);
+    }
+    for (int it = 0; it < steps; it += kPrefetch) {
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int j = 0; j < kPrefetch; j++) {
+            if (it + j < steps) {
 #pragma unroll
-            for (int d = 0; d < 4; d++) acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[d], acc[c][d], 0, 0, 0);
-        a = na; b = nb4;
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                        acc[c][d] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][c], b[j][d], acc[c][d], 0, 0, 0);
+                a[j] = load4(xp, kc, K, lr < nrows);
+                b[j] = load4(gp, nc, N, lr < nrows);
+                xp += xstep; gp += gstep; lr += 16;
+            }
+        }
     }
 
     // D layout of v_mfma_f32_16x16x4_f32: lane (s, q), register r holds D[i = 4 s + r][j = q].
