@@ -403,9 +403,9 @@ agg_kernel(const AggParams p)
 // D=64, ids folded into one slice: 59.6 MB slice 2.81 ms, 7.45 MB 1.58 ms, 3.7 MB 1.34 ms per full
 // pass).  Each extra phase costs a launch, a pass over the chunk descriptors and a
 // read-modify-write of the touched output rows, so the measured optimum is about one phase per
-// 15 MB of X (tools/sweep.py --phases, Reddit-like: D=16/32/64/128/256 -> 2/2/4/8/16 phases,
+// 14 MB of X (tools/sweep.py --phases, Reddit-like: D=16/32/64/128/256 -> 2/2/4/8/16 phases,
 // +12/+17/+49/+64/+60 %), capped by the work per row and phase (products-like, average degree 50:
-// 2 phases +5 %, 4 phases -21 %) and useless -- harmful -- when the ids of a row are already
+// 2 phases +6 %, 4 phases -12 %) and useless -- harmful -- when the ids of a row are already
 // local (community-ordered variant: 1.38 ms single pass, 2.5 ms in 2 phases).  Locality and degree
 // cannot be seen from here without a device round trip, so the automatic mode acts only on the
 // hints the Decider supplies (gnna_tuning.avg_degree / nonlocal_ids); without hints: one pass.
