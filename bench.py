@@ -260,6 +260,14 @@ def main():
         X = torch.randn(n_local, D, device=dev, generator=gen)
         out = torch.empty_like(X)
 
+        calibrated = None
+        if not args.manual:
+            # Decider auto mode, measuring part: register this graph's hints and let the tuner time the
+            # rule's phase count against its neighbours on the actual graph (set-up, outside the timed region)
+            from gnnadvisor_osdi21_amd.decider import calibrate_phases
+            _lib.set_graph_hints(g.column_index, g.nnz / g.num_nodes, g.avg_edgeSpan > 0.28 * g.num_nodes)
+            calibrated = calibrate_phases(g.column_index, ppd, p2nd, g.num_nodes, ps, [D])
+
         def step():
             _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
         P = int(p2n.numel())
@@ -333,6 +341,7 @@ def main():
                        f"dst-range shards x{world} + RCCL all-gather in {agg.chunks} piece(s), overlapped",
                        "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
                        "column_phases_used": _lib.last_num_phases(),
+                       "calibrated_phases": (calibrated if not sharded else None),
                        "tuning": _lib.get_tuning()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

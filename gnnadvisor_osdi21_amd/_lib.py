@@ -41,7 +41,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32")
+           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases")
 
 
 def load() -> ctypes.CDLL:
@@ -81,6 +81,8 @@ def load() -> ctypes.CDLL:
                                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
     L.gnna_set_graph_hints.restype = ctypes.c_int
     L.gnna_set_graph_hints.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.gnna_set_graph_phases.restype = ctypes.c_int
+    L.gnna_set_graph_phases.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     L.gnna_xtg_f32.restype = ctypes.c_int
     L.gnna_xtg_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                ctypes.c_int, ctypes.c_void_p]
@@ -287,6 +289,11 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
                                         int(num_out_rows), X.shape[1], part2Node.numel(), int(partSize),
                                         1 if accumulate else 0, _stream(X.device)))
     return out
+
+
+def set_graph_phases(column_index, dim: int, column_phases: int) -> None:
+    """Measured schedule for `dim`-wide aggregations on this graph (0 removes it); see include/gnna.h."""
+    _check(load().gnna_set_graph_phases(column_index.data_ptr(), int(dim), int(column_phases)))
 
 
 def xtg(X, G, out=None):

@@ -559,7 +559,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
 
     gnna_tuning tune;
     gnna_get_tuning(&tune);
-    apply_graph_hints(column_index, &tune);
+    apply_graph_hints(column_index, dim, &tune);
 
     int32_t *flag = nullptr;
     const int32_t seq = next_call_seq(ds, &flag);

@@ -37,6 +37,9 @@ struct GraphHint {
     int avg_degree = 0;
     int nonlocal_ids = 0;
     uint64_t stamp = 0;
+    // measured schedules (gnna_set_graph_phases): column phases for up to 8 feature widths
+    int sched_dim[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int sched_phases[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 constexpr int kMaxGraphHints = 64;
 GraphHint g_hints[kMaxGraphHints];
@@ -70,14 +73,20 @@ void apply_env()
 }  // namespace
 
 namespace gnna {
-void apply_graph_hints(const void *column_index, gnna_tuning *tune)
+void apply_graph_hints(const void *column_index, int dim, gnna_tuning *tune)
 {
     if (!column_index) return;
     std::lock_guard<std::mutex> lock(g_tuning_mutex);
     for (auto &h : g_hints) {
         if (h.key == column_index) {
-            tune->avg_degree = h.avg_degree;
-            tune->nonlocal_ids = h.nonlocal_ids;
+            if (h.avg_degree > 0) {
+                tune->avg_degree = h.avg_degree;
+                tune->nonlocal_ids = h.nonlocal_ids;
+            }
+            if (tune->column_phases == 0) {  // an explicit process-wide setting wins over a measured schedule
+                for (int i = 0; i < 8; i++)
+                    if (h.sched_dim[i] == dim && dim > 0) tune->column_phases = h.sched_phases[i];
+            }
             h.stamp = ++g_hint_clock;
             return;
         }
@@ -157,10 +166,41 @@ int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonloc
             if (h.stamp < slot->stamp) slot = &h;
         }
     }
+    if (slot->key != column_index) *slot = GraphHint();
     slot->key = column_index;
     slot->avg_degree = avg_degree;
     slot->nonlocal_ids = nonlocal_ids ? 1 : 0;
     slot->stamp = ++g_hint_clock;
+    return GNNA_OK;
+}
+
+int gnna_set_graph_phases(const int32_t *column_index, int dim, int column_phases)
+{
+    if (!column_index || dim <= 0 || column_phases < 0 || column_phases > 16)
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_set_graph_phases: bad argument (dim=%d phases=%d)", dim,
+                          column_phases);
+    std::lock_guard<std::mutex> lock(g_tuning_mutex);
+    GraphHint *slot = nullptr;
+    for (auto &h : g_hints)
+        if (h.key == column_index) slot = &h;
+    if (!slot) {
+        slot = &g_hints[0];
+        for (auto &h : g_hints) {
+            if (!h.key) { slot = &h; break; }
+            if (h.stamp < slot->stamp) slot = &h;
+        }
+        *slot = GraphHint();
+        slot->key = column_index;
+    }
+    slot->stamp = ++g_hint_clock;
+    int at = -1;
+    for (int i = 0; i < 8; i++)
+        if (slot->sched_dim[i] == dim) at = i;
+    for (int i = 0; i < 8 && at < 0; i++)
+        if (slot->sched_dim[i] == 0) at = i;
+    if (at < 0) at = dim % 8;  // table full: overwrite some entry
+    slot->sched_dim[at] = column_phases > 0 ? dim : 0;
+    slot->sched_phases[at] = column_phases;
     return GNNA_OK;
 }
 

@@ -18,8 +18,9 @@ namespace gnna {
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
 // Per-graph hints registered with gnna_set_graph_hints(), keyed by the column_index pointer of the
-// call; overrides tune->avg_degree / nonlocal_ids when there is an entry.  (gnna_host.cpp)
-void apply_graph_hints(const void *column_index, gnna_tuning *tune);
+// call; overrides tune->avg_degree / nonlocal_ids when there is an entry, and tune->column_phases when a
+// measured schedule for this feature width was registered with gnna_set_graph_phases().  (gnna_host.cpp)
+void apply_graph_hints(const void *column_index, int dim, gnna_tuning *tune);
 
 // Number of column phases for a gather from `x_bytes` of source rows (gnna_agg.hip): tune.column_phases
 // when forced, else from the size of X and the two graph hints; 1 = single pass.

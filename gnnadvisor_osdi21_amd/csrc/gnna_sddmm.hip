@@ -194,7 +194,7 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     if (rc != GNNA_OK) return rc;
     gnna_tuning tune;
     gnna_get_tuning(&tune);
-    apply_graph_hints(column_index, &tune);
+    apply_graph_hints(column_index, 0, &tune);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     const int pieces = (dim + 3) / 4;
     int lpr = 4;

@@ -78,6 +78,56 @@ def reference_formulas(avg_degree, input_dim, hidden_dim, smem_budget_kb, max_wp
                 dw_input=min(input_dim, 32), dw_hidden=min(hidden_dim, 32))
 
 
+def calibrate_phases(column_index, part_pointers, part2Node, num_out_rows, partSize, dims,
+                     num_in_rows=None, reps=3, verbose=False):
+    """Measure instead of guess: time the aggregation of THIS graph (device tensors) at each feature
+    width in ``dims`` with the rule-based column-phase count and its neighbours, and register the
+    fastest per width with libgnna (``gnna_set_graph_phases``, keyed by ``column_index``).
+
+    The rule (size of X, average degree, "ids are scattered") is tuned on randomly labelled
+    synthetic graphs; a real graph with partial locality is where it can be wrong, and a few
+    milliseconds of measurement at set-up time settle it.  Returns {dim: phases}.  The hints for
+    the graph (``set_graph_hints``) should already be registered so that the rule's own choice is
+    among the candidates."""
+    import torch
+    from . import _lib
+    assert column_index.is_cuda, "calibration runs on the GPU"
+    n_in = int(num_in_rows if num_in_rows is not None else num_out_rows)
+    chosen = {}
+    for D in sorted({int(d) for d in dims if int(d) > 0}):
+        X = torch.randn(n_in, D, device=column_index.device)
+        out = torch.empty(int(num_out_rows), D, device=column_index.device)
+
+        def run():
+            _lib.agg_rect(_lib.MODE_SAG, X, column_index, part_pointers, part2Node, num_out_rows, partSize, out=out)
+
+        _lib.set_graph_phases(column_index, D, 0)
+        run()
+        rule = _lib.last_num_phases()
+        cands = sorted({1, rule, max(1, rule // 2), max(1, rule - 1), min(16, rule + 1), min(16, rule * 2)})
+        timing = {}
+        for b in cands:
+            _lib.set_graph_phases(column_index, D, b)
+            run(); run()
+            torch.cuda.synchronize()
+            _lib.profile_begin(reps)
+            for _ in range(reps):
+                run()
+            torch.cuda.synchronize()
+            timing[b] = _lib.profile_end()["main_ms"]
+        # keep the rule's choice unless something else is clearly (> 2 %) faster
+        best = min(timing, key=timing.get)
+        if timing[best] > 0.98 * timing[rule]:
+            best = rule
+        _lib.set_graph_phases(column_index, D, best)
+        chosen[D] = best
+        if verbose:
+            print("# calibrated dim {}: rule {} phase(s), measured {} -> {} phase(s)".format(
+                D, rule, {b: round(t, 3) for b, t in timing.items()}, best))
+        del X, out
+    return chosen
+
+
 class inputProperty(object):
     def __init__(self, row_pointers=None, column_index=None, degrees=None,
                  partSize=None, dimWorker=None, warpPerBlock=None,
@@ -243,6 +293,16 @@ class inputProperty(object):
             _lib.set_graph_hints(ci, self.avg_degree_hint, bool(nonlocal_ids))
         else:
             _lib.set_tuning(avg_degree=self.avg_degree_hint, nonlocal_ids=-1 if nonlocal_ids is None else nonlocal_ids)
+
+    def calibrate(self, dims, verbose=None):
+        """Measured column-phase schedule for this graph at the given feature widths (auto mode,
+        mi355x policy; needs the CSR and the partition on the GPU).  See ``calibrate_phases``."""
+        if self.manual_mode or getattr(self, "policy", "mi355x") != "mi355x":
+            return {}
+        n = int(self.row_pointers.numel()) - 1
+        self.measured_phases = calibrate_phases(self.column_index, self.partPtr, self.part2Node, n, self.partSize,
+                                                dims, verbose=self.verbose_flag if verbose is None else verbose)
+        return self.measured_phases
 
     def print_param(self):
         if self.verbose_flag:

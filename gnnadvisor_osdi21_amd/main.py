@@ -104,6 +104,13 @@ def main(argv=None):
     inputInfo.partPtr = partPtr.int().to(device)
     inputInfo.part2Node = part2Node.int().to(device)
     inputInfo.apply_tuning()      # scheduler knobs + this graph's hints (keyed by the device column_index)
+    if not manual_mode and not (verify_spmm or single_spmm):
+        # measured schedule for the widths the layers aggregate at (hidden, classes; GIN layer 1 aggregates
+        # at the input width unless it is evaluated update-first)
+        widths = {args.hidden, dataset.num_classes}
+        if args.model == 'gin' and dataset.num_features <= 2 * args.hidden:
+            widths.add(dataset.num_features)
+        inputInfo.calibrate(widths)
     degrees = inputInfo.degrees
 
     # ---- single-SpMM verification / profiling (GNNA_main.py:116-137) -------------------------------

@@ -210,6 +210,13 @@ GNNA_API void gnna_get_tuning(gnna_tuning *t);
  * is replaced).  A stale entry can only cost performance, never correctness. */
 GNNA_API int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids);
 
+/* Measured schedule: aggregations of `dim`-wide features on the graph whose column_index array
+ * starts at this device address use `column_phases` (1..16) column phases instead of the rule
+ * based on the hints; 0 removes the entry.  Up to 8 widths per graph.  An explicit process-wide
+ * gnna_tuning.column_phases >= 1 still wins.  (decider.inputProperty.calibrate() measures and
+ * registers these.) */
+GNNA_API int gnna_set_graph_phases(const int32_t *column_index, int dim, int column_phases);
+
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
 GNNA_API int gnna_last_num_phases(void);
 

@@ -302,3 +302,37 @@ def test_gin_update_first_is_the_same_layer(fin, fout, needs_dx, expect):
     for a, b, what in zip(res[0], res[1], ("out", "dX", "dW")):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(a.abs().max())), what
     assert auto._use_update_first(X.clone().requires_grad_(needs_dx)) == expect
+
+
+def test_calibration_measures_the_phase_schedule_per_graph():
+    """decider.calibrate_phases: the tuner times the rule's phase count against its neighbours on the actual
+    graph.  A randomly labelled graph keeps a multi-phase schedule; a community-ordered graph that was given
+    the WRONG hint ("ids are scattered") is corrected to a single pass; results stay within tolerance."""
+    from gnnadvisor_osdi21_amd.decider import calibrate_phases
+    D = 256
+    for locality, expect_single in ((0.0, False), (1.0, True)):
+        g = graph.make_config_graph("reddit-like", device="cuda", scale=0.25, locality=locality)
+        pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+        ppd, p2nd = pp.cuda(), p2n.cuda()
+        X = torch.randn(g.num_nodes, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+        try:
+            y1 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)      # no hints: 1 pass
+            assert _lib.last_num_phases() == 1
+            _lib.set_graph_hints(g.column_index, g.nnz / g.num_nodes, True)                        # claims scattered ids
+            _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+            assert _lib.last_num_phases() == 4                                                      # the rule's choice
+            chosen = calibrate_phases(g.column_index, ppd, p2nd, g.num_nodes, 64, [D])
+            y2 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+            assert _lib.last_num_phases() == chosen[D]
+            if expect_single:
+                assert chosen[D] == 1, chosen
+            else:
+                assert chosen[D] >= 2, chosen
+            _lib.set_tuning(column_phases=3)                     # an explicit process-wide setting still wins
+            _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+            assert _lib.last_num_phases() == 3
+        finally:
+            _lib.set_graph_hints(None, 0, False)
+            _lib.reset_tuning()
+        scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double()
+        assert bool(((y1.double() - y2.double()).abs() <= 1e-5 * scale.clamp(min=1.0)).all())
