@@ -281,6 +281,7 @@ def main():
         ps = decide(n_local, float(ci.numel()) / n_local, n_global / 3.0)
         agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
                                 pipeline_chunks=args.pipeline_chunks)
+        calibrated = agg.calibrate([D]) if not (args.manual or args.headline_only) else None
         nnz_local, n_src = agg.nnz_local, n_global
         gen = torch.Generator(device=dev).manual_seed(1234 + rank)
         X = torch.randn(n_local, D, device=dev, generator=gen)
@@ -342,7 +343,7 @@ def main():
                        f"dst-range shards x{world} + RCCL all-gather in {agg.chunks} piece(s), overlapped",
                        "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
                        "column_phases_used": _lib.last_num_phases(),
-                       "calibrated_phases": (calibrated if not sharded else None),
+                       "calibrated_phases": calibrated,
                        "tuning": _lib.get_tuning()},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -314,6 +314,61 @@ class ShardedAggregator:
                                     windows=(self.chunks, k, k + 1))
         return out
 
+    def calibrate(self, dims, reps: int = 3) -> dict:
+        """Measured phase counts for the parts of this shard (no collective involved: every rank tunes its
+        own kernels on random features).  Local part and, without pipelining, the remote / whole part go
+        through ``decider.calibrate_phases``; the windowed remote part is timed as K window calls for total
+        phase counts K, 2K, 3K, 4K.  Only with the real kernel (no injected aggregate_fn)."""
+        if self.aggregate_fn is not _default_aggregate or self.device.type != "cuda":
+            return {}
+        from . import _lib
+        from .decider import calibrate_phases
+        res = {}
+        n_all = self.world * self.rows_per_rank
+        if not self.overlap:
+            res["whole"] = calibrate_phases(self.column_index, self.part_pointers, self.part2Node, self.n_local,
+                                            self.partSize, dims, num_in_rows=n_all if self.world > 1 else self.n_local)
+            return res
+        ci_l, pp_l, p2n_l = self.local_part
+        if ci_l.numel():
+            res["local"] = calibrate_phases(ci_l, pp_l, p2n_l, self.n_local, self.partSize, dims, num_in_rows=self.n_local)
+        ci_r, pp_r, p2n_r = self.remote_part
+        if not ci_r.numel():
+            return res
+        if self.chunks == 1:
+            res["remote"] = calibrate_phases(ci_r, pp_r, p2n_r, self.n_local, self.partSize, dims, num_in_rows=n_all)
+            return res
+        res["remote"] = {}
+        K = self.chunks
+        for D in sorted({int(d) for d in dims}):
+            X = torch.randn(n_all, D, device=self.device)
+            out = torch.zeros(self.n_local, D, device=self.device)
+
+            def run():
+                for k in range(K):
+                    _lib.agg_rect(_lib.MODE_SAG, X, ci_r, pp_r, p2n_r, self.n_local, self.partSize, out=out,
+                                  accumulate=True, windows=(K, k, k + 1))
+            _lib.set_graph_phases(ci_r, D, 0)
+            run()
+            rule = _lib.last_num_phases()
+            timing = {}
+            for total in sorted({rule, *[m * K for m in (1, 2, 3, 4) if m * K <= 16]}):
+                _lib.set_graph_phases(ci_r, D, total)
+                run(); run()
+                torch.cuda.synchronize()
+                _lib.profile_begin(reps * K)
+                for _ in range(reps):
+                    run()
+                torch.cuda.synchronize()
+                timing[total] = _lib.profile_end()["main_ms"] * K
+            best = min(timing, key=timing.get)
+            if timing[best] > 0.98 * timing[rule]:
+                best = rule
+            _lib.set_graph_phases(ci_r, D, best)
+            res["remote"][D] = best
+            del X, out
+        return res
+
     def sag(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         return self.aggregate(X_local, 0, out=out)
 
