@@ -44,6 +44,9 @@ def build_parser():
     p.add_argument('--hip_graph', default='False', **tf,
                    help="True: capture one training epoch (forward, backward, Adam) into a HIP graph and replay it "
                         "(MI355X addition; pays on small, launch-bound graphs)")
+    p.add_argument('--tune_gemm', default='False', **tf,
+                   help="True: let PyTorch's TunableOp time the rocBLAS / hipBLASLt solutions for the layer GEMMs at "
+                        "first use (X W and G W^T run 1.3-2x faster; costs 1-2 minutes of set-up, MI355X addition)")
     p.add_argument('--policy', type=str, default='mi355x', choices=['mi355x', 'compat'], help="Decider policy")
     return p
 
@@ -59,6 +62,14 @@ def main(argv=None):
 
     assert torch.cuda.is_available(), "requires an MI355X GPU: there is no CPU path"
     device = torch.device('cuda')
+    if flag(args.tune_gemm):
+        import tempfile
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(50)
+        tunable.set_max_tuning_iterations(10)
+        tunable.set_filename(osp.join(tempfile.gettempdir(), "gnna_tunableop.csv"))   # keep the results out of the cwd
 
     from . import load_extension
     from .decider import inputProperty
