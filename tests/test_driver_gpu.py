@@ -81,3 +81,19 @@ def test_hip_graph_epochs_train_like_eager_epochs(capsys, model, hidden):
         assert re.search(r"Time \(ms\): (\d+\.\d{3})", out)
         finals.append(float(re.search(r"# final loss: (-?\d+\.\d+|nan|inf)", out).group(1)))
     assert finals[0] == finals[0] and abs(finals[0] - finals[1]) <= 1e-3 * max(1.0, abs(finals[0])), finals
+
+
+def test_c_abi_consumer_without_python(tmp_path):
+    """examples/sag_c_abi.cpp: a host that owns its device memory through the HIP runtime and calls only
+    include/gnna.h -- built with hipcc against libgnna.so, run as a separate process."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "sag_c_abi")
+    libdir = os.path.join(root, "gnnadvisor_osdi21_amd", "csrc")
+    subprocess.run([hipcc, "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "sag_c_abi.cpp"),
+                    "-L", libdir, "-lgnna", "-Wl,-rpath," + libdir, "-o", exe], check=True, timeout=300)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip().endswith("OK"), res.stdout + res.stderr
