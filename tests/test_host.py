@@ -184,3 +184,18 @@ def test_graph_builders_follow_the_reference_loader():
     fwd = set(zip(rows.tolist(), a.column_index.tolist()))
     assert all((c, r) in fwd for r, c in fwd)
     assert int((a.row_pointers[1:] - a.row_pointers[:-1]).max()) <= 2 * 120 + 20
+
+
+def test_c_abi_example_compiles_and_links(tmp_path):
+    """examples/sag_c_abi.cpp builds against include/gnna.h + libgnna.so with hipcc (no GPU needed to link)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    libdir = os.path.join(root, "gnnadvisor_osdi21_amd", "csrc")
+    exe = str(tmp_path / "sag_c_abi")
+    subprocess.run([hipcc, "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "sag_c_abi.cpp"),
+                    "-L", libdir, "-lgnna", "-Wl,-rpath," + libdir, "-o", exe], check=True, timeout=300)
+    assert os.path.getsize(exe) > 0
