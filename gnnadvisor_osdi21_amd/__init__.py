@@ -40,7 +40,8 @@ def load_extension():
 def install_reference_aliases() -> None:
     """Register the reference's top-level module names so that its scripts' imports
     (``import GNNAdvisor as GNNA``, ``from param import *``, ``from gnn_conv import *``,
-    ``from unitest import *`` -- GNNA_main.py:10-12,117,131) resolve to this package."""
+    ``from dataset import *``, ``from unitest import *`` -- GNNA_main.py:10-13,117,131) resolve to this
+    package (``dataset`` -> loader.custom_dataset, which needs neither dgl nor rabbit)."""
     sys.modules.setdefault("GNNAdvisor", load_extension())
-    for ref_name, ours in (("param", "decider"), ("gnn_conv", "ops"), ("unitest", "verify")):
+    for ref_name, ours in (("param", "decider"), ("gnn_conv", "ops"), ("dataset", "loader"), ("unitest", "verify")):
         sys.modules.setdefault(ref_name, importlib.import_module(f"{__name__}.{ours}"))

@@ -336,3 +336,29 @@ def test_calibration_measures_the_phase_schedule_per_graph():
             _lib.reset_tuning()
         scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double()
         assert bool(((y1.double() - y2.double()).abs() <= 1e-5 * scale.clamp(min=1.0)).all())
+
+
+def test_reference_module_names_resolve_to_this_package():
+    """install_reference_aliases(): the import lines of the reference's GNNA_main.py (:10-13,117,131) resolve
+    to this package's module, Decider, op layer, loader and verification harness."""
+    import importlib
+    import sys
+    import gnnadvisor_osdi21_amd as pkg
+    saved = {k: sys.modules.get(k) for k in ("GNNAdvisor", "param", "gnn_conv", "dataset", "unitest")}
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        pkg.install_reference_aliases()
+        ns = {}
+        exec("import GNNAdvisor as GNNA\nfrom param import *\nfrom gnn_conv import *\nfrom dataset import *\nfrom unitest import *", ns)
+        for name in ("inputProperty", "GCNConv", "GINConv", "custom_dataset", "Verification"):
+            assert name in ns, name
+        for fn in ("SAG", "forward", "backward", "forward_gin", "backward_gin", "build_part"):
+            assert hasattr(ns["GNNA"], fn)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        importlib.invalidate_caches()
