@@ -20,14 +20,22 @@
 //   * column ids are fetched 64 at a time with one coalesced non-temporal load and
 //     handed to the slots with ds_bpermute; partial rows live in VGPRs (the reference's
 //     shared-memory read-modify-write chain, .cu:245-249, is what it is bound by).
-//   * slots are folded once per destination row with v_permlane16_swap /
-//     v_permlane32_swap (strides 16/32) and ds_bpermute (strides < 16).
+//   * slots are folded once per destination row as a reduce-scatter with v_permlane32_swap /
+//     v_permlane16_swap (3 swaps + 3 adds leave every lane with one float of the row) and DPP
+//     row rotations for narrow rows.
 //   * flush: plain (non-temporal) vector store when the row is wholly owned by the wave,
 //     hardware global_atomic_add_f32 only for rows shared with a neighbouring chunk.
 //   * a prologue kernel zero-fills `out` and checks that the partition is canonical
 //     (part2Node and partPtr non-decreasing); if it is not, every group is flushed with
 //     atomics, which is correct for any partition.
-//   * column phases (PHASED): the kernel is launched once per source-id range so that the#include <hip/hip_runtime.h>
+//   * column phases (PHASED): the kernel is launched once per source-id range so that the slice of
+//     X being gathered is cache resident; every run keeps a cursor (next unconsumed edge) between
+//     the launches.  The windowed entry point runs a sub-range of those launches per call
+//     (pipelined multi-GPU exchange).
+//   * row staging: for widths whose rows straddle 128-byte lines (41, 47, 56 ...) and for the
+//     pre-scaled GCN form the source rows are first copied into scratch with a line-friendly
+//     row stride (and multiplied by their degree norm); the kernel takes the stride as `ldx`.
+#include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdint>
