@@ -6,8 +6,10 @@
 // names, positional arguments, return shapes and the same CHECK_INPUT error texts.
 // The five host launchers keep the reference's names (SAG_cuda, spmm_forward_cuda, ...,
 // GNNAdvisor_kernel.cu:110,267,422,559,696) but are thin shims over the C ABI of
-// libgnna.so (include/gnna.h); the dense update stays torch::mm (rocBLAS/hipBLASLt MFMA)
-// exactly where the reference calls it.
+// libgnna.so (include/gnna.h); the dense updates X W and G W^T stay torch::mm (rocBLAS /
+// hipBLASLt) exactly where the reference calls it, the weight gradient X^T G goes to libgnna's
+// MFMA kernel (gnna_xtg_f32).  Extension functions beyond the reference's six: backward_weight,
+// aggregate_gin, xtg (used by ops.py).
 //
 // Differences from the reference, all deliberate (DESIGN.md "Boundary"):
 //   * work is enqueued on PyTorch's *current* HIP stream of the input's device (the
