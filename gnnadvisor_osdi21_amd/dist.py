@@ -19,6 +19,12 @@ backend "nccl" == RCCL over xGMI):
   remote blocks arrive over xGMI, then the remote-source part is accumulated into the same
   output (``gnna_agg_rect_f32(..., accumulate=1)``).
 
+* pipelined exchange (``pipeline_chunks = K``): the blocks are cut into K sub-blocks, the gather buffer is
+  sub-block-major, K asynchronous all-gathers are in flight at once and source window k of the
+  remote part is aggregated as soon as piece k has arrived (``gnna_agg_rect_windows_f32``).
+* ``ShardedGCNConv`` / ``ShardedGINConv``: the layers on top (local dense update, sharded aggregation in
+  forward and backward, all-reduce of the weight gradient); ``dist_main.py`` is the training driver.
+
 ``aggregate_fn`` is the local kernel (defaults to the HIP path through the C ABI); the
 CPU/gloo tests inject a checker there, the product never does.
 """
