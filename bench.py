@@ -3,42 +3,97 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A "step" is one pass of the hot path -- `gnna_sag_f32` through the C ABI (prologue +
-aggregation kernel) -- over the whole synthetic graph, inputs already resident in HBM.
-Workload (BASELINE.json config 3, the one the metric is quoted on): a seeded Reddit-like
-power-law graph (N = 232,965, ~1.1e8 CSR entries, max degree ~21.6k, random node order),
-D = 64 fp32 features; neighbor-group size and scheduling (incl. the column-phased schedule)
-are chosen by the Decider in auto mode (`--manual` = the reference's manual mode, partSize 32,
-single pass).  N > 1 (launched by torch.distributed.run, one rank
-per GPU): weak scaling -- every rank owns a Reddit-sized block of destination rows whose
-sources are drawn from all ranks' nodes; each step all-gathers the feature blocks over
-RCCL/xGMI and aggregates locally (gnnadvisor_osdi21_amd/dist.py).
+A "step" is one pass of the hot path -- `gnna_sag_f32` through the C ABI (prologue + the
+aggregation kernel's column-phase launches) -- over the whole synthetic graph, inputs already
+resident in HBM.  Headline workload (BASELINE.json config 3, the one the metric is quoted on): a
+seeded Reddit-like power-law graph (N = 232,965, ~1.1e8 CSR entries, max degree ~21.6k, random
+node order), D = 64 fp32 features; neighbor-group size and schedule are chosen by the Decider in
+auto mode (`--manual` = the reference's manual mode, partSize 32, single pass).
+
+`--gpus N` with N > 1 launches N ranks by itself (re-exec under torch.distributed.run on
+127.0.0.1) unless the launcher's environment (WORLD_SIZE) is already there: weak scaling -- every
+rank owns a Reddit-sized block of destination rows whose sources are drawn from all ranks' nodes;
+each step exchanges source features over RCCL/xGMI (only the referenced remote rows when that is clearly
+less than the whole blocks, `--exchange`) and aggregates locally (gnnadvisor_osdi21_amd/dist.py).
 
 Rank 0 prints ONE JSON line; `value` = total aggregated edges per second over all ranks.
-`roofline` prices the aggregation kernel with the gather model of SURVEY.md 8(d) /
-BASELINE.md 2: bytes = nnz*(4D+4) + N*(4D+4) + P*8 per step, divided by the aggregation
-kernel's time per step (all column-phase launches of agg_kernel together) measured with HIP
-events on the launch stream (gnna_profile_begin/end).
-`cpu_baseline` times the oracle (CPU port of the same computation) on the host cores.
+
+`verified`: after the timed loop the timed configuration itself is checked -- X = ones must give the
+exact row nnz in every column (the reference's own known-answer test, unitest.py:54-63), and 256
+sampled rows of the timed randn output are compared with an fp64 gather-sum.
+
+`roofline` (single-GPU line): the kernel is bound by the L2-miss path (L2 <-> Infinity Cache / HBM
+fabric), so `achieved` is the MEASURED fabric traffic of the aggregation kernel (rocprofv3 PMC passes
+FETCH_SIZE and WRITE_SIZE of this very invocation: bench.py re-runs itself as a short child under
+rocprofv3, FETCH_SIZE calibrated on a 1 GiB device copy in the same child) divided by the kernel
+time measured with HIP events on the launch stream during the timed loop; `frac` = that / 8 TB/s.
+The gather-model rate of SURVEY.md 8(d) (bytes = nnz*(4D+4) + N*(4D+4) + P*8 per step, which
+counts every gathered row whether it came from L2, Infinity Cache or HBM and therefore may exceed
+the HBM peak) and the compulsory-model rate are reported beside it, never as `frac`.
+`hbm_resident` repeats the measurement on a workload whose features (627 MB) exceed the 256 MiB
+Infinity Cache (products-like, D = 64).  `cpu_baseline` times the oracle (CPU port) on the host.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); before HIP starts
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: pinned OpenMP threads (before libgomp starts)
+os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling is ~6290
+CALIB_BYTES = 1 << 30
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--partSize", type=int, default=0,
+                    help="neighbor-group size; 0 = the Decider's choice (auto mode, mi355x policy)")
+    ap.add_argument("--manual", action="store_true",
+                    help="reference manual mode: partSize 32 and library-default scheduling, no Decider")
+    ap.add_argument("--config", default="reddit-like")
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
+    ap.add_argument("--locality", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (traffic = null)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the HBM-resident second workload")
+    ap.add_argument("--secondary-config", default="products-like")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline workload: no calibration, other modes, PMC children, second "
+                         "workload or CPU baseline (used for rocprofv3 kernel-trace runs)")
+    ap.add_argument("--pipeline-chunks", type=int, default=0,
+                    help="multi-GPU all-gather exchange: pieces of the pipelined feature exchange (0 = automatic)")
+    ap.add_argument("--exchange", default="auto", choices=("auto", "halo", "allgather"),
+                    help="multi-GPU source-feature exchange: only the referenced remote rows (all_to_all), whole "
+                         "blocks (all-gather), or whichever moves clearly fewer bytes (decided collectively)")
+    ap.add_argument("--backend", default="nccl", help="debug: 'gloo' runs the N-rank path without RCCL")
+    ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="debug: take the sharded (torch.distributed) path even with one rank")
+    # internal: PMC child mode (run under rocprofv3 by the parent)
+    ap.add_argument("--pmc-child", default="", help=argparse.SUPPRESS)     # manifest path
+    ap.add_argument("--pmc-workloads", default="", help=argparse.SUPPRESS)  # cfg:dim:partSize:phases,...
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------- models
 
 def gather_model_bytes(nnz: int, n_rows: int, parts: int, dim: int) -> int:
     """per edge one fp32 source row + one int32 column id; per destination
@@ -50,43 +105,295 @@ def compulsory_bytes(nnz: int, n_rows: int, n_src: int, dim: int) -> int:
     return nnz * 4 + (n_rows + 1) * 4 + (n_rows + n_src) * dim * 4
 
 
-def measured_traffic(workload: str, dim: int, part_size: int, nnz: int):
-    """HBM-side bytes per launch of the aggregation kernel from the committed rocprofv3 PMC
-    passes (profiles/*traffic.json; FETCH_SIZE doubled per the gfx950 calibration).  PMC
-    counters cannot be read from inside this process, so the newest profile whose workload
-    matches is reported, scaled by nnz if the graph differs slightly; None if there is none."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json"))):
-        try:
-            t = json.load(open(f))
-        except Exception:
-            continue
-        if t.get("workload") == workload and t.get("dim") == dim and t.get("partSize") == part_size:
-            best = (t, os.path.basename(f))
-    if best is None:
-        return None, None
-    t, name = best
-    return t["corrected_bytes"] * (nnz / t["nnz"]), name
+# ---------------------------------------------------------------------------------------------- self launch
 
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int):
+    """`python bench.py --gpus N` from a bare shell: become N ranks (one per GPU) under
+    torch.distributed.run.  The ranks inherit stdout, so rank 0's JSON line is this command's."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+# ---------------------------------------------------------------------------------------------- workload
+
+class Workload:
+    """One single-GPU aggregation workload: graph + partition + features, and its step()."""
+
+    def __init__(self, config, dim, dev, *, scale=1.0, locality=0.0, manual=False, part_size=0,
+                 calibrate=True, force_phases=0):
+        import torch
+        from gnnadvisor_osdi21_amd import _lib, graph
+        from gnnadvisor_osdi21_amd.decider import inputProperty, calibrate_phases
+        self.config, self.dim, self.dev = config, dim, dev
+        cfg = graph.CONFIGS[config]
+        g = graph.make_config_graph(config, device=dev, locality=locality, scale=scale)
+        self.g = g
+
+        class _Profile:
+            pass
+        prof = _Profile()
+        prof.num_nodes, prof.avg_degree, prof.avg_edgeSpan = g.num_nodes, g.avg_degree, g.avg_edgeSpan
+        prof.num_features, prof.reorder_flag = cfg["feat"], False
+        prof.rabbit_reorder = lambda: None
+        info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=dim, dataset_obj=prof,
+                             enable_rabbit=False, manual_mode=manual)
+        info.decider()
+        if not manual:
+            info.apply_tuning()
+        self.ps = part_size if part_size > 0 else info.partSize
+        self.pp, self.p2n = _lib.build_part(self.ps, g.row_pointers.cpu())
+        self.ppd, self.p2nd = self.pp.to(dev), self.p2n.to(dev)
+        self.P = int(self.p2n.numel())
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        self.X = torch.randn(g.num_nodes, dim, device=dev, generator=gen)
+        self.out = torch.empty_like(self.X)
+        self.calibrated = None
+        if not manual:
+            # Decider auto mode, measuring part: register this graph's hints and let the tuner time the
+            # rule's phase count against its neighbours on the actual graph (set-up, outside the timed region)
+            _lib.set_graph_hints(g.column_index, g.nnz / g.num_nodes, g.avg_edgeSpan > 0.28 * g.num_nodes)
+            if force_phases > 0:
+                _lib.set_graph_phases(g.column_index, dim, force_phases)
+            elif calibrate:
+                self.calibrated = calibrate_phases(g.column_index, self.ppd, self.p2nd, g.num_nodes, self.ps, [dim])
+        self._lib = _lib
+
+    def step(self, X=None, out=None):
+        g = self.g
+        return self._lib.sag(self.X if X is None else X, g.row_pointers, g.column_index, g.degrees,
+                             self.ppd, self.p2nd, self.ps, 32, 4, out=self.out if out is None else out)
+
+    def time(self, steps, warmup):
+        import torch
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        self._lib.profile_begin(steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = self._lib.profile_end()
+        self.phases = self._lib.last_num_phases()
+        self.launches = self._lib.last_num_launches()
+        return elapsed, prof
+
+    def verify(self, samples=256):
+        """Checks the configuration that was just timed (same partition, hints, phase schedule):
+        (1) X = ones -> every output element equals the row's nnz exactly (unitest.py:54-63);
+        (2) `samples` rows of the timed randn output against an fp64 gather-sum, bound
+            1e-4 * max(1, sum |x_j|) per element (north_star: 1e-4 fp32)."""
+        import torch
+        g = self.g
+        ones = torch.ones_like(self.X)
+        y1 = torch.empty_like(self.X)
+        self.step(ones, y1)
+        deg = (g.row_pointers[1:] - g.row_pointers[:-1]).to(torch.float32)
+        exact = bool((y1 == deg[:, None]).all())
+        phases_ones = self._lib.last_num_phases()
+        del ones, y1
+        self.step()                                            # the timed call once more -> self.out
+        gen = torch.Generator(device="cpu").manual_seed(99)
+        rows = torch.randint(0, g.num_nodes, (samples,), generator=gen).tolist()
+        rows[0] = int(torch.argmax(deg))                       # the hub row is always among them
+        worst = 0.0
+        ok = True
+        for i in rows:
+            b, e = int(g.row_pointers[i]), int(g.row_pointers[i + 1])
+            xs = self.X[g.column_index[b:e].long()].double()
+            ref = xs.sum(0)
+            scale = torch.clamp(xs.abs().sum(0), min=1.0)
+            err = (self.out[i].double() - ref).abs()
+            worst = max(worst, float((err / scale).max()))
+            ok = ok and bool((err <= 1e-4 * scale).all())
+        return {"ones_exact": exact, "sampled_rows": samples, "sampled_rows_ok": ok,
+                "max_err_over_sum_abs": worst, "bound": 1e-4, "column_phases_checked": phases_ones,
+                "verified": bool(exact and ok)}
+
+
+# ---------------------------------------------------------------------------------------------- PMC child
+
+def pmc_child(args):
+    """Runs under rocprofv3 --pmc: a few steps of each workload with the parent's schedule forced, then
+    a known-size device copy for the FETCH_SIZE / WRITE_SIZE calibration.  Writes a manifest that tells
+    the parent which dispatches belong to which workload."""
+    import torch
+    from gnnadvisor_osdi21_amd import _lib
+    _lib.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    manifest = {"workloads": [], "calib_bytes": CALIB_BYTES, "calib_copies": 3}
+    for spec in args.pmc_workloads.split(","):
+        cfg, dim, ps, phases = spec.split(":")
+        w = Workload(cfg, int(dim), dev, scale=args.scale, locality=args.locality, manual=args.manual,
+                     part_size=int(ps), calibrate=False, force_phases=0 if args.manual else int(phases))
+        warm, steps = 1, 3
+        for _ in range(warm + steps):
+            w.step()
+        torch.cuda.synchronize()
+        manifest["workloads"].append({"config": cfg, "dim": int(dim), "warmup": warm, "steps": steps,
+                                      "launches_per_step": _lib.last_num_launches(),
+                                      "phases": _lib.last_num_phases()})
+        del w
+        torch.cuda.empty_cache()
+    x = torch.randn(CALIB_BYTES // 4, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        y.copy_(x)
+    torch.cuda.synchronize()
+    with open(args.pmc_child, "w") as f:
+        json.dump(manifest, f)
+
+
+def run_pmc_pass(counters, specs, args, workdir):
+    """One rocprofv3 --pmc pass of the child.  -> (manifest, rows of the counter CSV) or raises."""
+    tag = "_".join(counters)[:40]
+    outdir = os.path.join(workdir, tag)
+    manifest_path = os.path.join(workdir, tag + "_manifest.json")
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", manifest_path,
+             "--pmc-workloads", ",".join(specs), "--scale", str(args.scale), "--locality", str(args.locality)]
+    if args.manual:
+        child.append("--manual")
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "agg_kernel|stream_kernel|copyBuffer", "-T",
+           "-d", outdir, "-o", "pmc", "-f", "csv", "--", *child]
+    env = dict(os.environ, TMPDIR="/tmp")
+    r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    if r.returncode != 0 or not os.path.exists(manifest_path):
+        raise RuntimeError(f"rocprofv3 pass {tag} failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-400:]}")
+    rows = []
+    for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    rows.sort(key=lambda r_: int(r_["Dispatch_Id"]))
+    return json.load(open(manifest_path)), rows
+
+
+def split_counters(manifest, rows, counter):
+    """-> ([per-step sum of `counter` over the aggregation launches, per workload], copy-kernel values)"""
+    agg = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter
+           and ("agg_kernel" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"])]
+    cp = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and "copyBuffer" in r["Kernel_Name"]]
+    cp = cp[-manifest["calib_copies"]:]      # the calibration copies are the child's last dispatches (earlier
+    #                                          copyBuffer dispatches are small host-to-device transfers)
+    per_step, at = [], 0
+    for w in manifest["workloads"]:
+        n = (w["warmup"] + w["steps"]) * w["launches_per_step"]
+        seg = agg[at:at + n]
+        at += n
+        timed = seg[w["warmup"] * w["launches_per_step"]:]
+        per_step.append(sum(timed) / w["steps"] if len(timed) == w["steps"] * w["launches_per_step"] else None)
+    return per_step, cp
+
+
+def measure_traffic(workloads, args):
+    """Fabric-side bytes per step of the aggregation launches of each workload, from rocprofv3 PMC
+    passes of this invocation's configuration (separate passes: FETCH_SIZE and WRITE_SIZE do not fit
+    one; counters in KiB; FETCH_SIZE under-reports wide streaming reads on gfx950 and is calibrated on
+    a 1 GiB device copy in the same child, as MI355X_MICROARCH.md prescribes).  -> list of dicts."""
+    if shutil.which("rocprofv3") is None:
+        return [{"error": "rocprofv3 not found"} for _ in workloads]
+    specs = [f"{w.config}:{w.dim}:{w.ps}:{w.phases}" for w in workloads]
+    workdir = tempfile.mkdtemp(prefix="gnna_pmc_", dir="/tmp")
+    res = [dict() for _ in workloads]
+    try:
+        mf, rows = run_pmc_pass(["FETCH_SIZE"], specs, args, workdir)
+        fetch, cp_f = split_counters(mf, rows, "FETCH_SIZE")
+        mw, rows = run_pmc_pass(["WRITE_SIZE"], specs, args, workdir)
+        write, cp_w = split_counters(mw, rows, "WRITE_SIZE")
+        try:
+            mh, rows = run_pmc_pass(["TCC_HIT_sum", "TCC_MISS_sum"], specs, args, workdir)
+            hit, _ = split_counters(mh, rows, "TCC_HIT_sum")
+            miss, _ = split_counters(mh, rows, "TCC_MISS_sum")
+        except Exception:
+            hit = miss = [None] * len(workloads)
+        # calibration: a 1 GiB copy reads 1 GiB and writes 1 GiB
+        kf = (CALIB_BYTES / (1024.0 * (sum(cp_f) / len(cp_f)))) if cp_f else 2.0
+        kw = (CALIB_BYTES / (1024.0 * (sum(cp_w) / len(cp_w)))) if cp_w else 1.0
+        for i, w in enumerate(workloads):
+            if fetch[i] is None or write[i] is None or mf["workloads"][i]["launches_per_step"] != w.launches \
+                    or mf["workloads"][i]["phases"] != w.phases:
+                res[i] = {"error": "dispatch count of the PMC child does not match the timed schedule"}
+                continue
+            res[i] = {"bytes_per_step": (fetch[i] * kf + write[i] * kw) * 1024.0,
+                      "fetch_KiB_per_step_raw": fetch[i], "write_KiB_per_step_raw": write[i],
+                      "fetch_calibration": kf, "write_calibration": kw,
+                      "calibrated_in_this_run": bool(cp_f and cp_w),
+                      "l2_hit_rate": (hit[i] / (hit[i] + miss[i])) if hit[i] and miss[i] is not None else None,
+                      "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench.py invocation "
+                                "(3 steps each, same partition and phase schedule as the timed loop)"}
+    except Exception as exc:  # profiler missing / refused: report, never fake
+        res = [{"error": str(exc)[:300]} for _ in workloads]
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    return res
+
+
+def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
+    g = w.g
+    alg = gather_model_bytes(g.nnz, g.num_nodes, w.P, w.dim)
+    comp = compulsory_bytes(g.nnz, g.num_nodes, g.num_nodes, w.dim)
+    t = kern_ms * 1e-3
+    fabric = traffic.get("bytes_per_step") if traffic else None
+    rec = {"bound": bound, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "kernel": "stream_kernel (sliced schedule, one launch)" if w.launches == 1 and w.phases > 1 else
+                     ("stream_kernel" if w.launches == 1 else "agg_kernel (one launch per column phase)"),
+           "kernel_ms": kern_ms, "kernel_launches_per_step": w.launches, "column_phases": w.phases,
+           "kernel_ms_per_launch": kern_ms / max(1, w.launches), "prologue_ms": prologue_ms,
+           "kernel_edges_per_s": g.nnz / t if t > 0 else 0.0,
+           "gather_model": {"bytes_per_step": alg, "GBs": alg / t / 1e9 if t > 0 else 0.0,
+                            "formula": "nnz*(4D+4) + N*(4D+4) + P*8 (SURVEY 8d; counts L2 / Infinity-Cache hits, "
+                                       "so it is an effective gather rate, not an HBM fraction)"},
+           "compulsory_model": {"bytes_per_step": comp, "GBs": comp / t / 1e9 if t > 0 else 0.0}}
+    if fabric:
+        rec.update({"achieved": fabric / t / 1e9, "frac": fabric / t / 1e9 / HBM_PEAK_GBS,
+                    "achieved_source": "measured fabric traffic (2*FETCH_SIZE + WRITE_SIZE, calibrated) / HIP-event kernel time",
+                    "traffic": fabric / max(1, w.launches), "traffic_per_step": fabric,
+                    "traffic_over_compulsory": fabric / comp,
+                    "l2_hit_rate": traffic.get("l2_hit_rate"), "traffic_detail": traffic})
+    else:
+        rec.update({"achieved": comp / t / 1e9 if t > 0 else 0.0,
+                    "frac": comp / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                    "achieved_source": "compulsory model (no PMC traffic available: "
+                                       + (traffic or {}).get("error", "not measured") + ")",
+                    "traffic": None})
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------- CPU baseline
 
 def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
-    """Oracle timed on the host: row-parallel fp32 CSR SpMM on all cores (value) and the
-    single-thread neighbor-group port on a bounded slice of groups."""
+    """Oracle timed on the host: row-parallel fp32 CSR SpMM on all cores (value = median of >= 10
+    passes; threads pinned with OMP_PROC_BIND=close / OMP_PLACES=cores, X and the output first-touched
+    by the same threads so that their pages are spread over the NUMA nodes) and the single-thread
+    neighbor-group port on a bounded slice of groups."""
     import numpy as np
     import oracle
-    rp = g_cpu.row_pointers.numpy(); ci = g_cpu.column_index.numpy(); X = X_cpu.numpy()
+    rp = g_cpu.row_pointers.numpy(); ci = g_cpu.column_index.numpy()
+    X = oracle.first_touch_copy(X_cpu.numpy())
     nnz = int(ci.size)
-    cores = len(os.sched_getaffinity(0))
-    out = np.zeros_like(X)
-    oracle.csr_sag_omp(X, rp, ci, 0, 1024, out)  # page in / thread pool warm-up
-    reps, best = 0, float("inf")
+    threads = oracle.num_threads()
+    out = oracle.first_touch_copy(None, X.shape)
+    for _ in range(2):
+        oracle.csr_sag_omp(X, rp, ci, out=out)              # thread pool / page warm-up
+    times = []
     t_all = time.perf_counter()
-    while reps < 3 or (time.perf_counter() - t_all < 8.0 and reps < 20):
+    while len(times) < 10 or (time.perf_counter() - t_all < 6.0 and len(times) < 30):
         t0 = time.perf_counter()
         oracle.csr_sag_omp(X, rp, ci, out=out)
-        best = min(best, time.perf_counter() - t0)
-        reps += 1
+        times.append(time.perf_counter() - t0)
+    order = list(times)
+    times.sort()
+    med = times[len(times) // 2]
     # scalar port of the reference algorithm on ~1/16 of the groups
     ppn, p2nn = pp.numpy(), p2n.numpy()
     P = int(p2nn.size)
@@ -96,16 +403,16 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
     oracle.sag_groups_slice(X, ci, ppn, p2nn, 0, g_end, out1)
     t1 = time.perf_counter() - t0
     e1 = int(ppn[g_end] - ppn[0])
-    libs = library_baselines(rp, ci, X, nnz, cores)
     return {
-        "value": nnz / best, "unit": "edges/s", "cores": cores, "kind": "port",
-        "sample": f"full graph ({nnz} edges, D={dim}), best of {reps} passes of the OpenMP row-parallel "
-                  f"fp32 CSR SpMM in oracle/gnna_oracle.c",
-        "ms": best * 1e3,
-        "gather_model_GBs": gather_model_bytes(nnz, len(rp) - 1, P, dim) / best / 1e9,
+        "value": nnz / med, "unit": "edges/s", "cores": threads, "kind": "port",
+        "sample": f"full graph ({nnz} edges, D={dim}), median of {len(times)} passes of the OpenMP row-parallel "
+                  f"fp32 CSR SpMM in oracle/gnna_oracle.c (threads pinned, NUMA first-touch)",
+        "ms": med * 1e3, "ms_min": times[0] * 1e3, "ms_max": times[-1] * 1e3,
+        "pass_ms_in_order": [round(t * 1e3, 1) for t in order],
+        "gather_model_GBs": gather_model_bytes(nnz, len(rp) - 1, P, dim) / med / 1e9,
         "single_thread": {"value": e1 / t1, "unit": "edges/s", "cores": 1,
                           "sample": f"first {g_end} neighbor-groups ({e1} edges), scalar neighbor-group port"},
-        "libraries": libs,
+        "libraries": library_baselines(rp, ci, X, nnz, threads),
     }
 
 
@@ -146,14 +453,15 @@ def library_baselines(rp, ci, X, nnz, cores):
     return res
 
 
-def other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz, steps: int = 10):
+def other_modes(w, steps: int = 10):
     """edges/s of the GCN-weighted and GIN entries on the bench graph (same partition, same knobs)."""
     import torch
+    _lib, g = w._lib, w.g
     res = {}
-    for name, fn in (("gcn_weighted", lambda: _lib.agg_gcn(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd,
-                                                           ps, 32, 4, out=out)),
-                     ("gin_eps", lambda: _lib.agg_gin(X, g.row_pointers, g.column_index, 0.5, ppd, p2nd,
-                                                      ps, 32, 4, out=out))):
+    for name, fn in (("gcn_weighted", lambda: _lib.agg_gcn(w.X, g.row_pointers, g.column_index, g.degrees, w.ppd,
+                                                           w.p2nd, w.ps, 32, 4, out=w.out)),
+                     ("gin_eps", lambda: _lib.agg_gin(w.X, g.row_pointers, g.column_index, 0.5, w.ppd, w.p2nd,
+                                                      w.ps, 32, 4, out=w.out))):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -161,34 +469,220 @@ def other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz, steps: int = 10):
         for _ in range(steps):
             fn()
         torch.cuda.synchronize()
-        res[name + "_edges_per_s"] = nnz * steps / (time.perf_counter() - t0)
+        res[name + "_edges_per_s"] = g.nnz * steps / (time.perf_counter() - t0)
     return res
 
 
+# ---------------------------------------------------------------------------------------------- single GPU
+
+def run_single(args, result_fd):
+    import torch
+    from gnnadvisor_osdi21_amd import _lib
+    _lib.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    w = Workload(args.config, args.dim, dev, scale=args.scale, locality=args.locality, manual=args.manual,
+                 part_size=args.partSize, calibrate=not args.headline_only)
+    elapsed, prof = w.time(args.steps, args.warmup)
+    g = w.g
+    kern_ms, pro_ms = prof["main_ms"], prof["prologue_ms"]
+    check = w.verify() if not args.headline_only else {"verified": None}
+    extras = not args.headline_only
+    tuning = _lib.get_tuning()
+    modes = other_modes(w) if extras else None
+
+    second = None
+    if extras and not args.no_secondary and args.scale == 1.0:
+        w2 = Workload(args.secondary_config, 64, dev, manual=args.manual)
+        e2, p2 = w2.time(max(5, args.steps // 2), 3)
+        second = (w2, e2, p2, max(5, args.steps // 2), w2.verify(64))
+    traffic = [None, None]
+    if extras and not args.no_pmc:
+        ws = [w] + ([second[0]] if second else [])
+        # the children build their own copies of the graphs: release this process's big buffers first
+        t = measure_traffic(ws, args)
+        traffic = t + [None] * (2 - len(t))
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    wl_name = (f"{args.config} power-law graph, random node order"
+               + (f", locality={args.locality}" if args.locality else "")
+               + (f", scale={args.scale}" if args.scale != 1.0 else ""))
+    x_mb = g.num_nodes * args.dim * 4 / 1e6
+    rec = {
+        "metric": "aggregated edges/sec, GCN sum-aggregation SpMM (SAG) hidden=64",
+        "value": g.nnz * args.steps / elapsed, "unit": "edges/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "verified": check["verified"], "verification": check,
+        "config": {"workload": wl_name, "num_nodes_per_gpu": g.num_nodes, "nnz_per_gpu": g.nnz, "dim": args.dim,
+                   "partSize": w.ps, "num_parts_per_gpu": w.P, "source_nodes": g.num_nodes,
+                   "feature_MB": x_mb, "parallelism": "single GPU", "world_size": 1, "device": str(dev),
+                   "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
+                   "column_phases_used": w.phases, "calibrated_phases": w.calibrated, "tuning": tuning},
+        "roofline": roofline_record(w, kern_ms, pro_ms, traffic[0],
+                                    "l2-fabric" if x_mb * 1e6 < (256 << 20) else "hbm"),
+    }
+    if modes:
+        rec["other_modes"] = modes
+    if second:
+        w2, e2, p2, k2, chk2 = second
+        g2 = w2.g
+        rec["hbm_resident"] = {
+            "workload": f"{args.secondary_config} power-law graph, random node order (features "
+                        f"{g2.num_nodes * 64 * 4 / 1e6:.0f} MB > 256 MiB Infinity Cache)",
+            "value": g2.nnz * k2 / e2, "unit": "edges/s", "steps": k2, "ms_per_step": e2 * 1e3 / k2,
+            "num_nodes": g2.num_nodes, "nnz": g2.nnz, "dim": 64, "partSize": w2.ps, "num_parts": w2.P,
+            "column_phases_used": w2.phases, "calibrated_phases": w2.calibrated,
+            "verified": chk2["verified"], "verification": chk2,
+            "roofline": roofline_record(w2, p2["main_ms"], p2["prologue_ms"], traffic[1], "hbm"),
+        }
+        del w2
+    if extras and not args.no_cpu_baseline:
+        rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.X.cpu(), w.pp, w.p2n, args.dim)
+    os.write(result_fd, (json.dumps(rec) + "\n").encode())
+
+
+# ---------------------------------------------------------------------------------------------- N ranks
+
+def run_sharded(args, result_fd, world, rank, local_rank):
+    import datetime
+    import torch
+    import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    limit = datetime.timedelta(seconds=300)                # a rank that dies must not hang the others for long
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev, timeout=limit)
+    else:
+        dist.init_process_group(args.backend, timeout=limit)
+
+    from gnnadvisor_osdi21_amd import _lib, graph
+    from gnnadvisor_osdi21_amd.decider import inputProperty
+    from gnnadvisor_osdi21_amd.dist import ShardedAggregator
+    _lib.load()
+    cfg = graph.CONFIGS[args.config]
+    D = args.dim
+    n_local = max(2, int(cfg["num_nodes"] * args.scale))
+    e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
+    n_global = n_local * world
+    rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
+                                  seed=cfg["seed"] * 1000 + rank, device=dev)
+    bounds = [i * n_local for i in range(world + 1)]
+
+    class _Profile:
+        pass
+    prof_obj = _Profile()
+    # sources are drawn from all ranks' nodes with no locality: span ~ n_global / 3
+    prof_obj.num_nodes, prof_obj.avg_degree, prof_obj.avg_edgeSpan = n_local, float(ci.numel()) / n_local, n_global / 3.0
+    prof_obj.num_features, prof_obj.reorder_flag = cfg["feat"], False
+    prof_obj.rabbit_reorder = lambda: None
+    info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=prof_obj,
+                         enable_rabbit=False, manual_mode=args.manual)
+    info.decider()
+    if not args.manual:
+        info.apply_tuning()
+    ps = args.partSize if args.partSize > 0 else info.partSize
+    agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
+                            pipeline_chunks=args.pipeline_chunks, exchange=args.exchange)
+    calibrated = agg.calibrate([D]) if not (args.manual or args.headline_only) else None
+    nnz_local = agg.nnz_local
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    X = torch.randn(n_local, D, device=dev, generator=gen)
+    out = torch.empty_like(X)
+    P = int(agg.part2Node.numel())
+
+    def step():
+        agg.sag(X, out=out)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    _lib.profile_begin(args.steps * 64)                    # a sharded step is several library calls
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_end()
+    calls_per_step = prof["calls"] / max(1, args.steps)
+    kern_ms = prof["main_ms"] * calls_per_step
+
+    # verification of the timed configuration: X = ones everywhere -> exact row nnz on every rank
+    ones = torch.ones_like(X)
+    y1 = agg.sag(ones)
+    deg = (rp[1:] - rp[:-1]).to(torch.float32)
+    exact = torch.tensor([1.0 if bool((y1 == deg[:, None]).all()) else 0.0], dtype=torch.float64, device=dev)
+    del ones, y1
+
+    stats = torch.tensor([elapsed, kern_ms, float(agg.bytes_received_per_step(D)),
+                          float(agg.allgather_bytes_per_step(D))], dtype=torch.float64, device=dev)
+    sums = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
+    cpu = args.backend != "nccl"
+    if cpu:
+        stats, sums, exact = stats.cpu(), sums.cpu(), exact.cpu()
+    dist.all_reduce(stats, op=dist.ReduceOp.MAX)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    dist.all_reduce(exact, op=dist.ReduceOp.MIN)
+    elapsed, kern_ms = float(stats[0]), float(stats[1])
+    total_edges = float(sums[0])
+
+    if rank == 0:
+        t = kern_ms * 1e-3
+        comp = compulsory_bytes(nnz_local, n_local, n_global, D)
+        alg = gather_model_bytes(nnz_local, n_local, P, D)
+        rec = {
+            "metric": "aggregated edges/sec, GCN sum-aggregation SpMM (SAG) hidden=64",
+            "value": total_edges * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "verified": bool(float(exact[0]) == 1.0),
+            "verification": {"ones_exact_on_every_rank": bool(float(exact[0]) == 1.0)},
+            "config": {"workload": f"{args.config} power-law graph, random node order"
+                                   + (f", scale={args.scale}" if args.scale != 1.0 else ""),
+                       "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
+                       "num_parts_per_gpu": P, "source_nodes": n_global,
+                       "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                       "device": str(dev) + (" (shared by all ranks)" if args.share_gpu else ""),
+                       "parallelism": f"dst-range shards x{world} + " + agg.describe_exchange(),
+                       "exchange": agg.exchange, "exchange_requested": args.exchange,
+                       "bytes_received_per_rank_per_step": float(stats[2]),
+                       "allgather_bytes_per_rank_per_step": float(stats[3]),
+                       "exchange_volume_vs_allgather": float(stats[2]) / float(stats[3]) if float(stats[3]) else None,
+                       "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
+                       "calibrated_phases": calibrated, "tuning": _lib.get_tuning()},
+            "roofline": {"bound": "l2-fabric", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "achieved": comp / t / 1e9 if t > 0 else 0.0,
+                         "frac": comp / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                         "achieved_source": "compulsory model per rank (no PMC passes in multi-rank runs)",
+                         "traffic": None, "kernel": "agg_kernel", "kernel_ms": kern_ms,
+                         "library_calls_per_step": calls_per_step,
+                         "gather_model": {"bytes_per_step": alg, "GBs": alg / t / 1e9 if t > 0 else 0.0},
+                         "kernel_edges_per_s": nnz_local / t if t > 0 else 0.0},
+        }
+        os.write(result_fd, (json.dumps(rec) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--dim", type=int, default=64)
-    ap.add_argument("--partSize", type=int, default=0,
-                    help="neighbor-group size; 0 = the Decider's choice (auto mode, mi355x policy)")
-    ap.add_argument("--manual", action="store_true",
-                    help="reference manual mode: partSize 32 and library-default scheduling, no Decider")
-    ap.add_argument("--config", default="reddit-like")
-    ap.add_argument("--scale", type=float, default=1.0, help="shrink the graph (debug only)")
-    ap.add_argument("--locality", type=float, default=0.0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--headline-only", action="store_true",
-                    help="skip the untimed extra legs (other_modes); used for rocprofv3 runs so that the kernel "
-                         "statistics contain the timed workload only")
-    ap.add_argument("--pipeline-chunks", type=int, default=0,
-                    help="multi-GPU: pieces of the pipelined feature exchange (0 = automatic)")
-    ap.add_argument("--backend", default="nccl", help="debug: 'gloo' runs the N-rank path without RCCL")
-    ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="debug: take the sharded (torch.distributed) path even with one rank")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.pmc_child:
+        import torch  # noqa: F401
+        return pmc_child(args)
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        self_launch(args.gpus)                                 # does not return
 
     # stdout carries exactly one JSON line: libraries that chat on fd 1 (RCCL prints a version banner
     # there at init) are pointed at stderr, the result is written to the saved descriptor
@@ -196,181 +690,16 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-        args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU path")
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    sharded = world > 1 or args.force_dist
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        import datetime
-        limit = datetime.timedelta(seconds=300)                # a rank that dies must not hang the others for long
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, timeout=limit)
-        else:
-            dist.init_process_group(args.backend, timeout=limit)
-
-    from gnnadvisor_osdi21_amd import _lib, graph
-    from gnnadvisor_osdi21_amd.dist import ShardedAggregator
-    _lib.load()
-
-    cfg = graph.CONFIGS[args.config]
-    D = args.dim
-    n_local = max(2, int(cfg["num_nodes"] * args.scale))
-    e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
-
-    # ---- build the workload on the GPU -------------------------------------------------
-    def decide(num_nodes, avg_degree, avg_span):
-        """Decider in auto mode (the reference's --manual_mode False): partSize + scheduler knobs + hints."""
-        from gnnadvisor_osdi21_amd.decider import inputProperty
-
-        class _Profile:
-            pass
-        prof_obj = _Profile()
-        prof_obj.num_nodes, prof_obj.avg_degree, prof_obj.avg_edgeSpan = num_nodes, avg_degree, avg_span
-        prof_obj.num_features, prof_obj.reorder_flag = cfg["feat"], False
-        prof_obj.rabbit_reorder = lambda: None
-        info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=prof_obj,
-                             enable_rabbit=False, manual_mode=args.manual)
-        info.decider()
-        if not args.manual:
-            info.apply_tuning()
-        return args.partSize if args.partSize > 0 else info.partSize
-
-    if not sharded:
-        g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
-        ps = decide(g.num_nodes, g.avg_degree, g.avg_edgeSpan)
-        rp_cpu = g.row_pointers.cpu()
-        pp, p2n = _lib.build_part(ps, rp_cpu)
-        ppd, p2nd = pp.to(dev), p2n.to(dev)
-        nnz_local, n_src = g.nnz, g.num_nodes
-        gen = torch.Generator(device=dev).manual_seed(1234)
-        X = torch.randn(n_local, D, device=dev, generator=gen)
-        out = torch.empty_like(X)
-
-        calibrated = None
-        if not args.manual:
-            # Decider auto mode, measuring part: register this graph's hints and let the tuner time the
-            # rule's phase count against its neighbours on the actual graph (set-up, outside the timed region)
-            from gnnadvisor_osdi21_amd.decider import calibrate_phases
-            _lib.set_graph_hints(g.column_index, g.nnz / g.num_nodes, g.avg_edgeSpan > 0.28 * g.num_nodes)
-            if not args.headline_only:      # (profiling runs keep the kernel statistics to the timed workload)
-                calibrated = calibrate_phases(g.column_index, ppd, p2nd, g.num_nodes, ps, [D])
-
-        def step():
-            _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4, out=out)
-        P = int(p2n.numel())
+    if world > 1 or args.force_dist:
+        run_sharded(args, result_fd, world, rank, local_rank)
     else:
-        n_global = n_local * world
-        rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
-                                      seed=cfg["seed"] * 1000 + rank, device=dev)
-        bounds = [i * n_local for i in range(world + 1)]
-        # sources are drawn from all ranks' nodes with no locality: span ~ n_global / 3
-        ps = decide(n_local, float(ci.numel()) / n_local, n_global / 3.0)
-        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
-                                pipeline_chunks=args.pipeline_chunks)
-        calibrated = agg.calibrate([D]) if not (args.manual or args.headline_only) else None
-        nnz_local, n_src = agg.nnz_local, n_global
-        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-        X = torch.randn(n_local, D, device=dev, generator=gen)
-        out = torch.empty_like(X)
-
-        def step():
-            agg.sag(X, out=out)
-        P = int(agg.part2Node.numel())
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if sharded:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    _lib.profile_begin(args.steps * 32)                    # a sharded step is several library calls
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    prof = _lib.profile_end()
-
-    # max over ranks, total edges over ranks
-    calls_per_step = prof["calls"] / max(1, args.steps)
-    prof["main_ms"] *= calls_per_step                      # per-call averages -> per step
-    prof["prologue_ms"] *= calls_per_step
-    stats = torch.tensor([elapsed, float(nnz_local), prof["main_ms"], float(P)], dtype=torch.float64, device=dev)
-    if sharded:
-        mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, total_edges, kern_ms = float(mx[0]), float(sm[1]), float(mx[2])
-    else:
-        total_edges, kern_ms = float(nnz_local), prof["main_ms"]
-
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = total_edges * args.steps / elapsed
-        alg_bytes = gather_model_bytes(nnz_local, n_local, P, D)
-        wl_name = f"{args.config} power-law graph, random node order"
-        traffic, traffic_src = (None, None)
-        if not sharded and args.scale == 1.0 and not args.locality:
-            traffic, traffic_src = measured_traffic(wl_name, D, ps, nnz_local)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        rec = {
-            "metric": "aggregated edges/sec, GCN sum-aggregation SpMM (SAG) hidden=64",
-            "value": value, "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config} power-law graph, random node order"
-                                   + (f", locality={args.locality}" if args.locality else "")
-                                   + (f", scale={args.scale}" if args.scale != 1.0 else ""),
-                       "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
-                       "num_parts_per_gpu": P, "source_nodes": n_src,
-                       "parallelism": "single GPU" if world == 1 else
-                       f"dst-range shards x{world} + RCCL all-gather in {agg.chunks} piece(s), overlapped",
-                       "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
-                       "column_phases_used": _lib.last_num_phases(),
-                       "calibrated_phases": calibrated,
-                       "tuning": _lib.get_tuning()},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         # fabric-side rate of the measured traffic (L2 <-> Infinity Cache / HBM) over the same kernel time
-                         "traffic_GBs": traffic / (kern_ms * 1e-3) / 1e9 if traffic and kern_ms > 0 else None,
-                         "traffic_frac": traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and kern_ms > 0 else None,
-                         "kernel": "agg_kernel<4,16,SAG>", "kernel_ms": kern_ms,
-                         "library_calls_per_step": calls_per_step,
-                         "kernel_launches_per_step": _lib.last_num_phases() if calls_per_step == 1 else None,
-                         "kernel_ms_per_launch": kern_ms / max(1, _lib.last_num_phases()) if calls_per_step == 1 else None,
-                         "prologue_ms": prof["prologue_ms"], "algorithmic_bytes": alg_bytes,
-                         "model": "gather: nnz*(4D+4) + N*(4D+4) + P*8",
-                         "compulsory_GBs": compulsory_bytes(nnz_local, n_local, n_src, D) / (kern_ms * 1e-3) / 1e9
-                         if kern_ms > 0 else 0.0,
-                         "kernel_edges_per_s": nnz_local / (kern_ms * 1e-3) if kern_ms > 0 else 0.0},
-        }
-        if not sharded and not args.headline_only:
-            # the weighted forms of the same kernel (a-2 GCN coefficients, a-4 GIN epsilon), outside the timed region
-            rec["other_modes"] = other_modes(_lib, g, X, ppd, p2nd, ps, out, nnz_local)
-        if not sharded and not args.no_cpu_baseline:
-            rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), X.cpu(), pp, p2n, D)
-        sys.stdout.flush()
-        os.write(result_fd, (json.dumps(rec) + "\n").encode())
-
-    if sharded:
-        dist.barrier()
-        dist.destroy_process_group()
+        run_single(args, result_fd)
 
 
 if __name__ == "__main__":

@@ -27,7 +27,7 @@ class Tuning(ctypes.Structure):
                 ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
                 ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int),
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
-                ("pad_rows", ctypes.c_int)]
+                ("pad_rows", ctypes.c_int), ("stream_kernel", ctypes.c_int)]
 
 
 _lib = None
@@ -41,7 +41,8 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases")
+           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
+           "gnna_last_num_launches", "gnna_reorder_community_i32")
 
 
 def load() -> ctypes.CDLL:
@@ -96,7 +97,10 @@ def load() -> ctypes.CDLL:
     L.gnna_reorder_rcm_i32.restype = ctypes.c_int
     L.gnna_reorder_rcm_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_void_p]
+    L.gnna_reorder_community_i32.restype = ctypes.c_int
+    L.gnna_reorder_community_i32.argtypes = L.gnna_reorder_rcm_i32.argtypes
     L.gnna_last_num_phases.restype = ctypes.c_int
+    L.gnna_last_num_launches.restype = ctypes.c_int
     L.gnna_sddmm_f32.restype = ctypes.c_int
     L.gnna_sddmm_f32.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                                         ctypes.c_int, ctypes.c_void_p]
@@ -124,9 +128,9 @@ def _stream(device: torch.device) -> int:
 
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
-               pad_rows=-1) -> None:
+               pad_rows=-1, stream_kernel=-1) -> None:
     t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
-               avg_degree, nonlocal_ids, gcn_prescale, pad_rows)
+               avg_degree, nonlocal_ids, gcn_prescale, pad_rows, stream_kernel)
     load().gnna_set_tuning(ctypes.byref(t))
 
 
@@ -134,12 +138,36 @@ def reset_tuning() -> None:
     load().gnna_set_tuning(None)
 
 
+_registered: dict = {}      # device address -> token of the tensor that registered hints / schedules for it
+
+
+def _forget_when_freed(column_index) -> None:
+    """libgnna keys its per-graph table by the device address of `column_index`; PyTorch's caching allocator
+    hands that address to an unrelated tensor once this one is freed.  Drop the entry together with the
+    tensor (unless a newer tensor has registered the same address in the meantime)."""
+    import weakref
+    ptr = column_index.data_ptr()
+    token = object()
+    _registered[ptr] = token
+
+    def drop(ptr=ptr, token=token):
+        if _registered.get(ptr) is token:
+            del _registered[ptr]
+            if _lib is not None:
+                _lib.gnna_set_graph_hints(ptr, 0, 0)
+    weakref.finalize(column_index, drop)
+
+
 def set_graph_hints(column_index, avg_degree: float, nonlocal_ids: bool) -> None:
     """Per-graph hints (keyed by the device address of `column_index`): average edges per destination
     row and whether the source ids of a row are scattered over the whole id range.  avg_degree <= 0
-    forgets the graph; column_index None forgets all."""
+    forgets the graph; column_index None forgets all.  The entry is dropped when the tensor is freed."""
     ptr = None if column_index is None else column_index.data_ptr()
     _check(load().gnna_set_graph_hints(ptr, int(avg_degree), 1 if nonlocal_ids else 0))
+    if column_index is None:
+        _registered.clear()
+    elif avg_degree > 0:
+        _forget_when_freed(column_index)
 
 
 def get_tuning() -> dict:
@@ -188,8 +216,20 @@ def reorder_rcm(src, dst, num_nodes: int) -> torch.Tensor:
     return out
 
 
+def reorder_community(src, dst, num_nodes: int) -> torch.Tensor:
+    """new_id[old_id] from the native community renumbering (label propagation + chain + barycentre sweeps)."""
+    s, d = _host_i32(src), _host_i32(dst)
+    out = torch.empty(int(num_nodes), dtype=torch.int32)
+    _check(load().gnna_reorder_community_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes), out.data_ptr()))
+    return out
+
+
 def last_num_phases() -> int:
     return int(load().gnna_last_num_phases())
+
+
+def last_num_launches() -> int:
+    return int(load().gnna_last_num_launches())
 
 
 def profile_begin(max_calls: int) -> None:
@@ -294,6 +334,8 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
 def set_graph_phases(column_index, dim: int, column_phases: int) -> None:
     """Measured schedule for `dim`-wide aggregations on this graph (0 removes it); see include/gnna.h."""
     _check(load().gnna_set_graph_phases(column_index.data_ptr(), int(dim), int(column_phases)))
+    if column_phases > 0 and column_index.data_ptr() not in _registered:
+        _forget_when_freed(column_index)
 
 
 def xtg(X, G, out=None):

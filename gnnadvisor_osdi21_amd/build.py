@@ -26,7 +26,7 @@ EXT = os.path.join(PKG, "GNNAdvisor.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-LIB_SOURCES = [os.path.join(CSRC, f) for f in ("gnna_agg.hip", "gnna_sddmm.hip", "gnna_gemm.hip", "gnna_runtime.hip", "gnna_host.cpp")]
+LIB_SOURCES = [os.path.join(CSRC, f) for f in ("gnna_agg.hip", "gnna_stream.hip", "gnna_sddmm.hip", "gnna_gemm.hip", "gnna_runtime.hip", "gnna_host.cpp", "gnna_reorder.cpp")]
 LIB_DEPS = LIB_SOURCES + [os.path.join(CSRC, "gnna_internal.h"), os.path.join(CSRC, "gnna_device.h"),
                            os.path.join(INCLUDE, "gnna.h")]
 EXT_SOURCES = [os.path.join(CSRC, "gnna_torch.cpp")]

@@ -418,6 +418,7 @@ agg_kernel(const AggParams p)
 // cannot be seen from here without a device round trip, so the automatic mode acts only on the
 // hints the Decider supplies (gnna_tuning.avg_degree / nonlocal_ids); without hints: one pass.
 thread_local int t_last_phases = 1;
+thread_local int t_last_launches = 1;   // aggregation kernel launches of the calling thread's last call
 
 // Average number of 128-byte lines one gathered row touches when rows of `row_bytes` bytes
 // lie `stride_bytes` apart (row k starts at k * stride_bytes; the base is at least 128-aligned).
@@ -451,6 +452,35 @@ int choose_row_stride(int dim)
         if (cc < best_cost) { best = c; best_cost = cc; }
     }
     return best;
+}
+
+// Number of phases of the sliced schedule from the slice statistics of the partition (st.cells[l] =
+// non-empty (group, slice) cells when the 16 fine slices are merged into 16 >> l).
+//  * not at all when the column ids of a row stay near the row (average |id - row| below two slices: a
+//    locality-ordered graph gathers from a small moving window already) -- measurable when rows and columns
+//    share one numbering; a caller's "scattered ids" hint settles it otherwise;
+//  * slices of at most 8 MiB of source rows (Reddit-like graph, D = 16 / 32 / 64 / 128: best 4 / 4 / 8 / 16
+//    phases; two slices are live while the chip moves from one to the next, and an XCD's L2 is 4 MiB);
+//  * at least ~12 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses
+//    (products-like, average degree 50: best 4 phases; amazon0505-like, degree 12: none).
+int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
+                  bool square, bool hinted_scattered)
+{
+    if (st.groups <= 0 || st.edges <= 0) return 1;
+    if (!hinted_scattered) {
+        if (square && st.span / st.edges < 2.0 * (double)slice_rows) return 1;
+        if (st.cells[0] <= 1.15 * st.groups) return 1;       // every group inside one slice
+    }
+    int b = 1;
+    while (b < S && x_bytes / b > ((size_t)8 << 20)) b <<= 1;
+    int lvl = 0;
+    for (int t = S; t > b; t >>= 1) lvl++;
+    const double rows = std::min((double)num_out_rows, st.groups);
+    auto piece = [&](int l) {   // edges per (row, slice) piece: cells of one row that are adjacent merge
+        return st.edges / std::max(rows, st.cells[l] - (st.groups - rows));
+    };
+    while (b > 1 && lvl < 4 && piece(lvl) < 12.0) { b >>= 1; lvl++; }
+    return (lvl >= 4 && b > 1 && piece(3) < 12.0) ? 1 : std::max(b, 1);
 }
 
 }  // namespace
@@ -650,12 +680,50 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             mode = MODE_GIN;  // unweighted gather + per-row factor at the flush
         }
     }
+    // Streaming kernel (gnna_stream.hip): unweighted gathers of rows of >= 4 floats that are not part of a
+    // windowed sequence.  Its sliced schedule is stateless and a single launch; the number of phases is
+    // tune.column_phases when set (process-wide or measured per graph), otherwise chosen from the slice
+    // statistics of the partition (first sight of a graph: one counting pass + one stream synchronisation).
+    if (vec == 4 && mode != MODE_GCN && num_windows == 1 && tune.stream_kernel != 2) {
+        int B = 1;
+        const uint8_t *cnt = nullptr;
+        const int S = 16;
+        const uint32_t slice_rows = (uint32_t)std::max<int64_t>(1, (num_in_rows + S - 1) / S);
+        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && x_bytes >= ((size_t)2 << 20);
+        if (tune.column_phases >= 2 && num_in_rows >= S) {
+            B = std::min(tune.column_phases, S);
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, false, &cnt, nullptr);
+            if (rc != GNNA_OK) return rc;
+        } else if (tune.column_phases == 0 && can_slice && x_bytes >= ((size_t)6 << 20)) {
+            SlicePlanStats st;
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, true, &cnt, &st);
+            if (rc != GNNA_OK) return rc;
+            if (cnt && st.valid)
+                B = choose_slices(st, x_bytes, S, slice_rows, num_nodes, num_in_rows == num_nodes, tune.nonlocal_ids == 1);
+        }
+        if (!cnt || B < 2) { B = 1; cnt = nullptr; }
+        t_last_phases = B;
+        StreamLaunch a;
+        a.mode = mode; a.X = p.X; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node; a.Y = out;
+        a.cnt = cnt; a.row_scale = p.row_scale; a.flag = flag; a.seq = seq; a.trust = p.trust; a.P = num_parts;
+        // a work item is (chunk, slice): keep its edge count about what `groups_per_chunk` groups are in one pass
+        a.D = dim; a.ldx = ldx; a.G = std::min(64, tune.groups_per_chunk * B); a.U = tune.loads_in_flight; a.S = S; a.B = B;
+        t_last_launches = 1;
+        a.wide = wide; a.plain_ok = (B == 1 && !accumulate_into_out); a.xcd_remap = tune.xcd_remap != 0;
+        a.eps = p.eps;
+        rc = launch_stream(a, stream);
+        if (rc != GNNA_OK) return rc;
+        profile_record(prof_call, 2, stream);
+        return GNNA_OK;
+    }
+
     // phases: `sub` launches per source window (one window == the whole source range unless the caller
     // pipelines a chunked feature exchange); this call runs the launches of windows [win_begin, win_end)
     const int total = choose_phases(tune, x_bytes, num_parts, partSize);
     const int sub = std::max(1, (total + num_windows / 2) / num_windows);
     const int phases = sub * num_windows;
     t_last_phases = phases;
+    t_last_launches = sub * (win_end - win_begin);
     AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
     p.cursor = nullptr; p.phase = 0; p.num_phases = 1; p.phase_hi = 0x7fffffff;
     p.acc_in = accumulate_into_out ? 1 : 0;
@@ -746,6 +814,7 @@ int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows,
 }
 
 int gnna_last_num_phases(void) { return t_last_phases; }
+int gnna_last_num_launches(void) { return t_last_launches; }
 
 #pragma GCC visibility pop
 }  // extern "C"

@@ -46,6 +46,34 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
 // Fresh non-zero sequence number of an aggregation call and its slot in the flag ring.
 int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
 
+// ---- streaming kernel + sliced schedule (gnna_stream.hip) ----------------------------------------------
+struct SlicePlanStats {
+    bool valid = false;
+    double cells[4] = {0, 0, 0, 0};  // non-empty (group, slice) cells at S, S/2, S/4, S/8 slices
+    double edges = 0, groups = 0;
+    double span = 0;                 // sum over the edges of |column id - destination row|
+};
+// Slice counts cnt[P][16] of the partition for S slices of slice_rows source rows (library cache; a miss
+// enqueues the counting kernel on `stream`, and with want_stats synchronises it once to read the
+// statistics).  *out stays null when the plan cannot be built right now (stream capture).
+int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_index, const int32_t *part_pointers,
+                   const int32_t *part2Node, int64_t num_parts, int S, uint32_t slice_rows, bool want_stats, const uint8_t **out,
+                   SlicePlanStats *stats_out);
+void drop_slice_plans();
+
+struct StreamLaunch {
+    int mode;                 // MODE_SAG or MODE_GIN (the pre-scaled GCN form arrives as GIN + row_scale)
+    const float *X; const int32_t *col; const int32_t *pp; const int32_t *p2n; float *Y;
+    const uint8_t *cnt;       // slice counts or nullptr (single phase)
+    const float *row_scale;
+    const int32_t *flag; int32_t seq; int32_t trust;
+    int64_t P;
+    int D, ldx, G, U, S, B;
+    bool wide, plain_ok, xcd_remap;
+    float eps;
+};
+int launch_stream(const StreamLaunch &a, hipStream_t stream);
+
 // ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------------
 // Returns the index of this call in the active profile (-1 when not profiling).
 int profile_acquire_call(bool has_work);

@@ -54,6 +54,13 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     Workspace &w = ds->ws[std::make_pair(stream, slot)];
     if (w.bytes < bytes) {
+        // growing means hipFree + hipMalloc: illegal inside a stream capture, and it would leave dangling
+        // pointers in a graph captured earlier on this stream -- refuse instead (warm the path up before capturing)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone)
+            return fail(GNNA_ERR_UNSUPPORTED, "library scratch (%zu B) would have to grow during stream capture: "
+                        "run the same call once before capturing", bytes);
         if (w.ptr) (void)hipFree(w.ptr);
         w.ptr = nullptr;
         w.bytes = 0;

@@ -1,0 +1,635 @@
+// gnna_stream.hip -- the streaming form of the neighbor-group aggregation kernel and the sliced
+// (source-range) schedule built on it.  CDNA4 / gfx950 only.
+//
+// Same computation as agg_kernel (gnna_agg.hip; reference GNNAdvisor_kernel.cu:186-259, 620-689):
+//   out[part2Node[g], :] += sum_{e in [partPtr[g], partPtr[g+1])} X[colidx[e], :]      (x eps / row factor)
+// What is different is how a wavefront walks its chunk of G neighbor-groups.
+//
+// Why: the column-phased schedule of round 1 (one launch per source-id range, per-run cursors) is
+// bound by a fixed cost per phase -- measured 70-90 us on the Reddit-like graph even for a phase that
+// finds nothing to gather -- because every run costs a chain of dependent round trips (chunk
+// descriptors -> cursor -> id tile at the cursor -> rows -> read-modify-write) with nothing else of
+// that wavefront in flight, and eight waves per SIMD cannot hide ~12 such trips per chunk.  Four
+// phases (14.9 MB slices, 60 % L2 hits) were therefore the optimum, although 3.7 MB slices would be
+// L2 resident.  Here the work item is (chunk, slice) and costs a fixed number of round trips
+// whatever the number of groups or rows in the chunk:
+//
+//   1. descriptors: part2Node / partPtr of the G groups and the group's 16 slice counts -- one
+//      coalesced load each, all in flight together;
+//   2. the pieces of all G groups that fall into this slice are laid out as one list of wave-wide
+//      row loads (a piece is padded to a multiple of RPI = rows per load, so that a load never mixes
+//      destination rows), the column ids of up to 256 list slots are fetched together and parked
+//      in LDS (1 KiB per wavefront);
+//   3. the list is streamed: U row loads are always in flight, across piece and row boundaries;
+//      partial rows accumulate in VGPRs and are folded and flushed when the list says "last load of
+//      this destination row" (scalar bit mask).  Loads are never predicated (a padded slot re-reads
+//      slot 0's row and is masked at the add), so the compiler's in-order vmcnt bookkeeping stays
+//      exact and the ring really stays full.
+//
+// Sliced schedule: the source rows are cut into S <= 16 equal slices; `cnt[g][f]` (uint8) is the
+// number of column ids of group g that lie in slice f, computed once per graph by slice_count_kernel
+// and kept in a small library cache.  A slice phase takes, from every group, the id positions
+// [sum_{f'<lo} cnt, sum_{f'<hi} cnt) clamped to the group's length (the last phase takes the rest):
+// whatever bytes `cnt` holds, the phases partition every group's positions exactly, so a stale cache
+// entry (same addresses, different contents) can only cost locality, never correctness -- the same
+// rule as for the graph hints.  With sorted ids (the loader's CSR) positions and slices coincide.
+// All flushes of the sliced schedule are float atomics on a zero-filled output, so the phases need
+// no order: they are ONE launch whose blocks are numbered slice-major, i.e. the chip sweeps the
+// slices in time (each XCD's L2 holds about one slice) without launch gaps or per-phase tails, and
+// there is no state between library calls (the cursors are gone).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+
+#include "gnna.h"
+#include "gnna_device.h"
+#include "gnna_internal.h"
+
+namespace gnna {
+namespace {
+
+constexpr int kMaxSlices = 16;   // bytes of slice counts per group
+constexpr int kIdSlots = 512;    // at most this many column ids parked in LDS per wavefront and round
+
+struct StreamParams {
+    const float *X;
+    const int32_t *col;
+    const int32_t *pp;
+    const int32_t *p2n;
+    float *Y;
+    const uint8_t *cnt;        // [S-1][P] cumulative slice counts, or nullptr: one phase takes everything
+    const float *row_scale;    // MODE_GIN: optional per-destination-row factor on top of eps
+    const int32_t *flag;       // *flag == seq  <=>  partition is NOT canonical
+    int64_t P;
+    int64_t num_chunks;
+    int64_t blocks_per_phase;  // multiple of kXcds when xcd_remap
+    int32_t seq;
+    int32_t trust;
+    int32_t D;
+    int32_t ldx;
+    int32_t G;
+    int32_t S;                 // fine slices (1..16)
+    int32_t B;                 // phases: phase p covers fine slices [p*S/B, (p+1)*S/B)
+    int32_t phase_lo;          // first phase of this launch
+    int32_t plain_ok;          // 1: rows owned by one work item may be written with plain stores
+    int32_t xcd_remap;
+    int32_t dbg_noflush;
+    float eps;
+};
+
+// ---- slice counts ---------------------------------------------------------------------------------
+// cnt[g][f] = number of column ids of neighbor-group g in source slice f (saturating at 255; the
+// consumer clamps, see above).  One wavefront per group tile; also counts the non-empty (group,
+// slice) cells for S, S/2, S/4, S/8 slices and the edges, which the launcher uses to pick the
+// number of phases.
+struct SliceStats {
+    unsigned long long cells[4];   // non-empty cells when the S slices are merged in pairs 0, 1, 2, 3 times
+    unsigned long long edges;
+    unsigned long long groups;     // non-empty groups
+    unsigned long long span;       // sum over the edges of |column id - destination row|
+};
+
+__global__ void __launch_bounds__(kBlock)
+slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp, const int32_t *__restrict__ p2n,
+                   int64_t P, uint32_t slice_rows, int S, uint8_t *__restrict__ cnt, SliceStats *stats)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long cells[4] = {0, 0, 0, 0}, edges = 0, groups = 0, span = 0;
+    for (int64_t g = wave; g < P; g += nwaves) {
+        const int beg = pp[g], end = pp[g + 1];
+        const int row = p2n[g];
+        int mine = 0;  // lane f < 16 accumulates the count of slice f
+        for (int t = beg; t < end; t += kWave) {
+            const bool valid = t + lane < end;
+            int f = -1;
+            if (valid) {
+                const uint32_t id = (uint32_t)__builtin_nontemporal_load(col + t + lane);
+                f = (int)min(id / slice_rows, (uint32_t)(S - 1));
+                const int dist = (int)id - row;
+                span += (unsigned long long)(dist < 0 ? -dist : dist);
+            }
+#pragma unroll
+            for (int b = 0; b < kMaxSlices; b++) {
+                const int c = __popcll(__ballot(f == b));
+                if (lane == b) mine += c;
+            }
+        }
+        {
+            // cum[f][g] = ids of the group below slice f + 1 = inclusive prefix over lanes 0 .. f (a 16-lane DPP row)
+            int pre = lane < kMaxSlices ? mine : 0;
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false);
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xF, 0xF, false);
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xF, 0xF, false);
+            pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xF, 0xF, false);
+            if (lane < S - 1) cnt[(size_t)lane * (size_t)P + (size_t)g] = (uint8_t)min(pre, 255);
+        }
+        if (end > beg) {
+            // non-empty cells at 16, 8, 4, 2 slices (lanes 0..15 hold the fine counts)
+            int v = lane < kMaxSlices ? mine : 0;
+#pragma unroll
+            for (int lvl = 0; lvl < 4; lvl++) {
+                const unsigned long long m = __ballot(v > 0 && lane < (kMaxSlices >> lvl));
+                cells[lvl] += (unsigned long long)__popcll(m);
+                // merge pairs: lane i takes lanes 2i, 2i+1
+                const int a = __shfl(v, 2 * lane), b2 = __shfl(v, 2 * lane + 1);
+                v = lane < (kMaxSlices >> (lvl + 1)) ? a + b2 : 0;
+            }
+            edges += (unsigned long long)(end - beg);
+            groups += 1;
+        }
+    }
+    // span was accumulated per lane: reduce over the wavefront
+    for (int d = 32; d > 0; d >>= 1) span += __shfl_down(span, d);
+    if (stats && lane == 0) {
+        if (span) atomicAdd(&stats->span, span);
+        for (int i = 0; i < 4; i++)
+            if (cells[i]) atomicAdd(&stats->cells[i], cells[i]);
+        if (edges) atomicAdd(&stats->edges, edges);
+        if (groups) atomicAdd(&stats->groups, groups);
+    }
+}
+
+// ---- flush ----------------------------------------------------------------------------------------
+// fold_row: folds the RPI slots of `acc`.  LPR <= 16: reduce-scatter with v_permlane32_swap /
+// v_permlane16_swap (+ DPP rotations); every lane ends with ONE float, component lane>>4 of piece lane%LPR
+// (returned in [0]).  Wider rows: butterfly per component, every slot ends with the row's 4-float piece.
+template <int LPR, int MODE>
+__device__ __forceinline__ typename VecOf<4>::T fold_row(const typename VecOf<4>::T acc, float scale)
+{
+    typedef typename VecOf<4>::T VT;
+    VT r = acc;
+    if constexpr (LPR <= 16) {
+        float px, qy;
+        {
+            auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[2]), false, false);
+            px = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+            t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[1]), __float_as_uint(acc[3]), false, false);
+            qy = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        }
+        float val;
+        {
+            auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(px), __float_as_uint(qy), false, false);
+            val = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        }
+        if constexpr (LPR <= 8) val += row_ror<8>(val);
+        if constexpr (LPR <= 4) val += row_ror<4>(val);
+        if constexpr (MODE == MODE_GIN) val *= scale;
+        r[0] = val;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float s = slot_reduce<LPR>(acc[k]);
+            if constexpr (MODE == MODE_GIN) s *= scale;
+            r[k] = s;
+        }
+    }
+    return r;
+}
+
+// park_row: stores a folded row piece (the layout fold_row leaves) into the wavefront's LDS buffer in natural
+// float order: float i of the buffer is out[row, d0 + i].  A ragged last piece (shifted back to end at D)
+// overlaps its predecessor with identical values.
+template <int LPR>
+__device__ __forceinline__ void park_row(const typename VecOf<4>::T r, float *__restrict__ buf, int rel_col, bool cvalid,
+                                         int lane, int slot)
+{
+    // (rel_col + k < 0: floats of a shifted piece that belong to the previous dimension sweep, flushed there)
+    if constexpr (LPR <= 16) {
+        const int at = rel_col + (lane >> 4);
+        if ((lane & 15) < LPR && cvalid && at >= 0) buf[at] = r[0];
+    } else {
+        if (slot == 0 && cvalid) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (rel_col + k >= 0) buf[rel_col + k] = r[k];
+        }
+    }
+}
+
+// emit_row: writes / adds a parked row piece of `width` floats to out[row, d0 : d0 + width], 64 consecutive
+// floats per instruction (one fully covered 256-byte run per wave-wide store / atomic).
+template <int LPR>
+__device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *__restrict__ Y, int64_t row, int D, int d0,
+                                         int width, bool use_atomic, int lane)
+{
+    float *dst = Y + (size_t)row * D + d0;
+#pragma unroll
+    for (int i = 0; i < (4 * LPR + kWave - 1) / kWave; i++) {
+        const int idx = i * kWave + lane;
+        if (idx < width) {
+            if (!use_atomic) __builtin_nontemporal_store(buf[idx], dst + idx);
+            else unsafeAtomicAdd(dst + idx, buf[idx]);
+        }
+    }
+}
+
+// ---- the streaming kernel ---------------------------------------------------------------------------
+
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (no LDS round trips).
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+template <int LPR, int MODE, int U, bool WIDE>
+__global__ void __launch_bounds__(kBlock)
+stream_kernel(const StreamParams p)
+{
+    typedef typename VecOf<4>::T VT;
+    typedef typename VecOf<4>::M MT;
+    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
+    constexpr int RPI = kWave / LPR;                                   // neighbor rows per wave-wide load
+    constexpr int RL = (kIdSlots / RPI < kWave) ? kIdSlots / RPI : kWave;  // loads per round
+    static_assert(RL % U == 0, "a round is a whole number of batches");
+    // per wavefront: the round's list slots as row offsets into X (bytes; row index when X > 4 GiB)
+    __shared__ uint32_t s_off[kWavesPerBlock][RL * RPI];
+    // folded rows waiting to be written: the float atomics of the sliced schedule are memory-side round
+    // trips that sit in the same in-order vmcnt queue as the row loads, so a flush in the middle of the
+    // stream would stall the ring until it retires.  Rows are parked here (2 KiB per wavefront) and
+    // emitted in a batch between rounds.
+    constexpr int PEND = LPR <= 16 ? 8 : (LPR == 32 ? 4 : 2);          // rows parked per wavefront
+    constexpr int PEND_FLOATS = LPR * 4;                               // floats per parked row (one dimension sweep)
+    __shared__ float s_pend[kWavesPerBlock][PEND * PEND_FLOATS];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int slot = lane / LPR;
+    const int c = lane % LPR;
+    const int D = p.D;
+    const bool canonical = p.trust || (*p.flag != p.seq);
+    const char *xbase = reinterpret_cast<const char *>(p.X);
+    const uint32_t row_bytes32 = (uint32_t)p.ldx * 4u;
+    uint32_t *offs = s_off[wib];
+    float *pend = s_pend[wib];
+    int pend_meta = 0;      // lane q: (row << 2 | atomic) of parked row q
+    int npend = 0;
+
+    // block -> (phase, chunk): blocks are numbered phase-major, inside a phase every XCD gets one
+    // contiguous range of chunks (blocks land on XCD blockIdx % 8)
+    const int64_t bpp = p.blocks_per_phase;
+    const int phase = p.phase_lo + (int)((int64_t)blockIdx.x / bpp);
+    int64_t item = (int64_t)blockIdx.x % bpp;
+    if (p.xcd_remap) item = (item % kXcds) * (bpp / kXcds) + item / kXcds;
+    const int64_t chunk = item * kWavesPerBlock + wib;
+    if (chunk >= p.num_chunks) return;
+    const int G = p.G;
+    const int64_t g0 = chunk * G;
+    const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
+
+    // ---- 1. descriptors (all loads in flight together) ---------------------------------------------
+    const bool gl = lane < ng;
+    const int my_row = gl ? p.p2n[g0 + lane] : -1;
+    const int pa = gl ? p.pp[g0 + lane] : 0;
+    const int pb = gl ? p.pp[g0 + lane + 1] : 0;
+    // cumulative slice counts of the group at the phase's two slice boundaries (phase-major byte arrays)
+    const int f_lo = p.cnt ? phase * p.S / p.B : 0, f_hi = p.cnt ? (phase + 1) * p.S / p.B : 1;
+    int cum_lo = 0, cum_hi = 0x7fffffff;
+    if (p.cnt && gl) {
+        if (f_lo > 0) cum_lo = p.cnt[(size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane)];
+        if (f_hi < p.S) cum_hi = p.cnt[(size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane)];
+    }
+    int prev_row = -1, next_row = -1;
+    if (g0 > 0) prev_row = p.p2n[g0 - 1];
+    if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
+
+    const int len = pb > pa ? pb - pa : 0;
+    // positions [beg, end) of the group belong to this phase.  The stored bytes are non-decreasing in the
+    // slice index (the counting kernel writes prefixes), so consecutive phases meet exactly whatever the
+    // bytes are: stale counts cost locality, not correctness.
+    const int beg = cum_lo < len ? cum_lo : len;
+    int end = cum_hi < len ? cum_hi : len;
+    end = end > beg ? end : beg;
+    const int n_own = gl ? end - beg : 0;  // edges of this group in this phase
+    if (__ballot(n_own > 0) == 0) return;  // nothing of this chunk in this phase
+
+    // destination-row segments and who flushes
+    const int up_row = __shfl_up(my_row, 1);
+    const bool seg_start = gl && (lane == 0 || my_row != up_row || !canonical);
+    const unsigned long long SS = __ballot(seg_start);
+    const unsigned long long upto = (2ull << lane) - 1ull;             // lanes <= lane
+    const unsigned long long above = ~upto;                             // lanes > lane
+    // pieces of consecutive groups of one row that are adjacent in the edge array (sorted ids: the row's
+    // part of the slice) are merged into one piece, headed by the first: no padding, no bookkeeping between them
+    const int up_end = __shfl_up(pa + end, 1), up_n = __shfl_up(n_own, 1);
+    const bool cont = n_own > 0 && !seg_start && up_n > 0 && up_end == pa + beg;
+    const unsigned long long NE = __ballot(n_own > 0 && !cont);        // piece heads
+    const int n_cum = wave_inclusive_scan(n_own);
+    const unsigned long long heads_above = NE & above;
+    const int next_head = heads_above ? __builtin_ctzll(heads_above) : 64;
+    const int chain_cum = __shfl(n_cum, next_head - 1);   // (every lane takes part: the sources are not heads)
+    const int n = (n_own > 0 && !cont) ? chain_cum - n_cum + n_own : 0;
+    const unsigned long long ne_above = NE & above;
+    const int next_ne = ne_above ? __builtin_ctzll(ne_above) : 64;
+    // a segment starts in (lane, next_ne]  <=>  this piece is the last non-empty one of its row segment
+    const unsigned long long between = SS & above & (next_ne < 63 ? ((2ull << next_ne) - 1ull) : ~0ull);
+    const bool last_in_seg = n > 0 && (next_ne == 64 || between != 0);
+    const int seg_first = 63 - __builtin_clzll((SS & upto) | 1ull);
+    const unsigned long long ss_above = SS & above;
+    const int seg_last = ss_above ? __builtin_ctzll(ss_above) - 1 : ng - 1;
+    const bool shared = canonical && ((seg_first == 0 && prev_row == my_row) || (seg_last == ng - 1 && next_row == my_row));
+    const int use_atomic_l = (shared || !canonical || !p.plain_ok) ? 1 : 0;
+
+    // non-empty pieces compacted to lanes 0 .. R-1 (forward permute to the piece's rank); piece r then
+    // holds its first edge, edge count, row + flags, and the inclusive prefix of its wave-wide loads
+    const int rank = __popcll(NE & (upto >> 1));
+    const int R = __popcll(NE);
+    const int dst = (n > 0 ? rank : 63) << 2;       // empty pieces all land on lane 63 (unused unless R == 64, then none is empty)
+    const int c_pbeg = __builtin_amdgcn_ds_permute(dst, pa + beg);
+    const int t_n = __builtin_amdgcn_ds_permute(dst, n);   // (executed by every lane: the senders are not the receivers)
+    const int c_n = lane < R ? t_n : 0;
+    const int c_meta = __builtin_amdgcn_ds_permute(dst, (my_row << 2) | (last_in_seg ? 2 : 0) | use_atomic_l);
+    const int c_nl = (c_n + RPI - 1) / RPI;
+    const int c_offI = wave_inclusive_scan(c_nl);
+    const int c_offX = c_offI - c_nl;
+    const int L = __builtin_amdgcn_readlane(c_offI, kWave - 1);
+
+    for (int d0 = 0; d0 < D; d0 += 4 * LPR) {
+        // lane c owns the 4 floats starting at dcol; a ragged last piece is shifted back to end at D
+        const int piece = d0 + c * 4;
+        const bool cvalid = piece < D;
+        int dcol = piece, shift = 0;
+        if (piece + 4 > D && cvalid) { dcol = D - 4; shift = piece - dcol; }
+        (void)shift;
+        const uint32_t col_off = (uint32_t)(cvalid ? dcol : (d0 + 4 <= D ? d0 : D - 4)) * 4u;
+        VT acc = vzero<4>();
+        const int sweep_width = D - d0 < 4 * LPR ? D - d0 : 4 * LPR;
+        auto drain = [&]() {
+            for (int q = 0; q < npend; q++) {
+                const int meta = __builtin_amdgcn_readlane(pend_meta, q);
+                emit_row<LPR>(pend + q * PEND_FLOATS, p.Y, meta >> 2, D, d0, sweep_width, (meta & 1) != 0, lane);
+            }
+            npend = 0;
+        };
+
+        for (int r0 = 0; r0 < L; r0 += RL) {
+            // ---- 2. this round's loads: lane j describes load r0 + j --------------------------------
+            // piece of load J = number of pieces whose inclusive prefix is <= J.  Prefixes of the compacted
+            // pieces are strictly increasing: those below r0 are counted with a ballot, those inside the
+            // round's window set one bit each in a scalar mask (a short scalar loop), the rest is a popcount.
+            const unsigned long long below = __ballot(lane < R && c_offI <= r0);
+            unsigned long long inwin = __ballot(lane < R && c_offI > r0 && c_offI <= r0 + RL - 1);
+            unsigned long long E = 0;
+            while (inwin) {
+                const int kk = __builtin_ctzll(inwin);
+                inwin &= inwin - 1;
+                E |= 1ull << (__builtin_amdgcn_readlane(c_offI, kk) - r0);
+            }
+            const int k = __popcll(below) + __popcll(E & upto);
+            const int k_offX = __shfl(c_offX, k), k_pbeg = __shfl(c_pbeg, k), k_n = __shfl(c_n, k);
+            const int k_meta = __shfl(c_meta, k);
+            const int J = r0 + lane;
+            const bool active = J < L && lane < RL;
+            const int i = J - k_offX;
+            const int e_j = k_pbeg + i * RPI;
+            int v_j = active ? k_n - i * RPI : 0;
+            const bool fl_j = active && (k_meta & 2) && v_j <= RPI;   // last load of the last piece of its row
+            v_j = v_j > RPI ? RPI : v_j;
+            const unsigned long long FL = __ballot(fl_j);
+            const unsigned long long TM = __ballot(active && v_j < RPI);   // loads with padded slots
+            const int nr = (L - r0) < RL ? (L - r0) : RL;
+
+            // lane j fetches the RPI column ids of its load (one vector load when the load is full) and parks
+            // them in LDS as row offsets; a padded slot repeats slot 0, an unused load reads row 0
+            if (lane < RL) {
+                uint32_t o[RPI];
+                if (v_j == RPI) {
+                    if constexpr (RPI >= 4) {
+                        typedef int i32x4 __attribute__((ext_vector_type(4)));
+                        typedef i32x4 i32x4u __attribute__((aligned(4)));
+#pragma unroll
+                        for (int s4 = 0; s4 < RPI; s4 += 4) {
+                            const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(p.col + e_j + s4));
+                            o[s4] = (uint32_t)t[0]; o[s4 + 1] = (uint32_t)t[1]; o[s4 + 2] = (uint32_t)t[2]; o[s4 + 3] = (uint32_t)t[3];
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < RPI; s++) o[s] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + s);
+                    }
+                } else {
+                    const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(p.col + e_j) : 0u;
+#pragma unroll
+                    for (int s = 0; s < RPI; s++) {
+                        o[s] = first;
+                        if (s > 0 && s < v_j) o[s] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + s);
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < RPI; s++) {
+                    if constexpr (!WIDE) o[s] *= row_bytes32;
+                    offs[lane * RPI + s] = o[s];
+                }
+            }
+
+            // ---- 3. stream: U unpredicated row loads always in flight ---------------------------------
+            auto row_ptr = [&](uint32_t o) -> const MT * {
+                if constexpr (WIDE) return reinterpret_cast<const MT *>(xbase + ((uint64_t)o * (uint64_t)row_bytes32 + col_off));
+                else return reinterpret_cast<const MT *>(xbase + (o + col_off));
+            };
+            const int nb = (nr + U - 1) / U;
+            VT v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = *row_ptr(offs[u * RPI + slot]);
+#pragma unroll 1
+            for (int b = 0; b < nb; b++) {
+                const int jn = (b + 1 < nb ? b + 1 : nb - 1) * U;   // the last batch re-requests its own (hot) rows
+                uint32_t nn[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) nn[u] = offs[(jn + u) * RPI + slot];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int j = b * U + u;
+                    if (j < nr) {
+                        if ((TM >> j) & 1ull) {
+                            const int vj = __builtin_amdgcn_readlane(v_j, j);
+                            if (slot >= vj) v[u] = vzero<4>();
+                        }
+                        acc += v[u];
+                        if (((FL >> j) & 1ull) && !p.dbg_noflush) {
+                            const int meta = __builtin_amdgcn_readlane(k_meta, j);
+                            float scale = p.eps;
+                            if constexpr (MODE == MODE_GIN) {
+                                if (p.row_scale) scale *= p.row_scale[meta >> 2];
+                            }
+                            const VT r = fold_row<LPR, MODE>(acc, scale);
+                            if (npend == PEND) { drain(); }
+                            park_row<LPR>(r, pend + npend * PEND_FLOATS, dcol - d0, cvalid, lane, slot);
+                            pend_meta = lane == npend ? meta : pend_meta;
+                            npend++;
+                            acc = vzero<4>();
+                        }
+                    }
+                    v[u] = *row_ptr(nn[u]);
+                }
+            }
+            if (npend > PEND / 2 || r0 + RL >= L) drain();   // between rounds: nothing of the ring waits behind these
+        }
+    }
+}
+
+// ---- plan cache -------------------------------------------------------------------------------------
+struct Plan {
+    const void *col = nullptr, *pp = nullptr, *p2n = nullptr;
+    int64_t P = 0;
+    int S = 0;
+    uint32_t slice_rows = 0;
+    int device = -1;
+    uint8_t *cnt = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ready = nullptr;
+    hipStream_t made_on = nullptr;
+    SliceStats stats{};
+    bool have_stats = false;
+    uint64_t stamp = 0;
+};
+constexpr int kMaxPlans = 8;
+Plan g_plans[kMaxPlans];
+std::mutex g_plan_mutex;
+uint64_t g_plan_clock = 0;
+SliceStats *g_stats_dev[64] = {nullptr};
+
+typedef void (*StreamKernel)(const StreamParams);
+
+template <int LPR, int MODE>
+StreamKernel pick_stream_wide(bool wide, int u)
+{
+    constexpr int RPI = kWave / LPR;
+    constexpr int RL = (kIdSlots / RPI < kWave) ? kIdSlots / RPI : kWave;
+    if constexpr (RL % 8 == 0) {
+        if (u >= 8) return wide ? stream_kernel<LPR, MODE, 8, true> : stream_kernel<LPR, MODE, 8, false>;
+    }
+    return wide ? stream_kernel<LPR, MODE, 4, true> : stream_kernel<LPR, MODE, 4, false>;
+}
+
+template <int MODE>
+StreamKernel pick_stream_lpr(int lpr, bool wide, int u)
+{
+    switch (lpr) {
+    case 4: return pick_stream_wide<4, MODE>(wide, u);
+    case 8: return pick_stream_wide<8, MODE>(wide, u);
+    case 16: return pick_stream_wide<16, MODE>(wide, u);
+    case 32: return pick_stream_wide<32, MODE>(wide, u);
+    default: return pick_stream_wide<64, MODE>(wide, u);
+    }
+}
+
+}  // namespace
+
+// Looks up / builds the slice counts of (column_index, part_pointers) for S slices of slice_rows source
+// rows.  A miss runs slice_count_kernel on `stream`; with want_stats the first use also synchronises
+// the stream once to read the statistics (never during stream capture: then *out stays null and the
+// caller takes the single-pass schedule).
+int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_index, const int32_t *part_pointers,
+                   const int32_t *part2Node, int64_t num_parts, int S, uint32_t slice_rows, bool want_stats, const uint8_t **out,
+                   SlicePlanStats *stats_out)
+{
+    *out = nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    Plan *hit = nullptr, *victim = &g_plans[0];
+    for (auto &pl : g_plans) {
+        if (pl.cnt && pl.col == column_index && pl.pp == part_pointers && pl.p2n == part2Node && pl.P == num_parts && pl.S == S &&
+            pl.slice_rows == slice_rows && pl.device == dev) { hit = &pl; break; }
+        if (!pl.cnt) { if (victim->cnt) victim = &pl; }
+        else if (victim->cnt && pl.stamp < victim->stamp) victim = &pl;
+    }
+    if (!hit) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return GNNA_OK;   // no allocation / sync while capturing
+        Plan &pl = *victim;
+        const size_t bytes = (size_t)num_parts * (size_t)(kMaxSlices - 1);
+        if (pl.bytes < bytes) {
+            if (pl.cnt) (void)hipFree(pl.cnt);
+            pl.cnt = nullptr; pl.bytes = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.cnt), bytes);
+            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(slice counts %zu B): %s", bytes, hipGetErrorString(e));
+            pl.bytes = bytes;
+        }
+        if (!pl.ready) (void)hipEventCreateWithFlags(&pl.ready, hipEventDisableTiming);
+        if (!g_stats_dev[dev]) {
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&g_stats_dev[dev]), sizeof(SliceStats));
+            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(slice stats): %s", hipGetErrorString(e));
+        }
+        pl.col = column_index; pl.pp = part_pointers; pl.p2n = part2Node; pl.P = num_parts; pl.S = S; pl.slice_rows = slice_rows;
+        pl.device = dev; pl.have_stats = false; pl.made_on = stream;
+        (void)hipMemsetAsync(g_stats_dev[dev], 0, sizeof(SliceStats), stream);
+        int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((num_parts + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                                  (int64_t)ds->num_cus * 16));
+        hipLaunchKernelGGL(slice_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, column_index,
+                           part_pointers, part2Node, num_parts, slice_rows, S, pl.cnt, g_stats_dev[dev]);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "slice count launch: %s", hipGetErrorString(e));
+        if (want_stats) {
+            e = hipMemcpyAsync(&pl.stats, g_stats_dev[dev], sizeof(SliceStats), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "slice statistics: %s", hipGetErrorString(e));
+            pl.have_stats = true;
+        }
+        (void)hipEventRecord(pl.ready, stream);
+        hit = &pl;
+    } else if (hit->made_on != stream) {
+        (void)hipStreamWaitEvent(stream, hit->ready, 0);   // built on another stream: order after it
+    }
+    hit->stamp = ++g_plan_clock;
+    *out = hit->cnt;
+    if (stats_out) {
+        stats_out->valid = hit->have_stats;
+        for (int i = 0; i < 4; i++) stats_out->cells[i] = (double)hit->stats.cells[i];
+        stats_out->edges = (double)hit->stats.edges;
+        stats_out->groups = (double)hit->stats.groups;
+        stats_out->span = (double)hit->stats.span;
+    }
+    return GNNA_OK;
+}
+
+void drop_slice_plans()
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    for (auto &pl : g_plans) {
+        if (pl.cnt) (void)hipFree(pl.cnt);
+        if (pl.ready) (void)hipEventDestroy(pl.ready);
+        pl = Plan();
+    }
+}
+
+int launch_stream(const StreamLaunch &a, hipStream_t stream)
+{
+    StreamParams p;
+    p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
+    p.flag = a.flag; p.P = a.P; p.seq = a.seq; p.trust = a.trust; p.D = a.D; p.ldx = a.ldx;
+    p.G = std::max(1, std::min(a.G, kWave));
+    p.num_chunks = (a.P + p.G - 1) / p.G;
+    int64_t items = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    p.xcd_remap = a.xcd_remap ? 1 : 0;
+    if (p.xcd_remap) items = (items + kXcds - 1) / kXcds * kXcds;
+    p.blocks_per_phase = items;
+    p.S = a.cnt ? a.S : 1; p.B = a.cnt ? a.B : 1; p.phase_lo = 0;
+    p.plain_ok = a.plain_ok ? 1 : 0;
+    p.eps = a.eps;
+    { static const int dbg = std::getenv("GNNA_DEBUG_NOFLUSH") ? 1 : 0; p.dbg_noflush = dbg; }
+    const int64_t grid = items * (int64_t)p.B;
+    if (grid > 0x7fffffffLL) return fail(GNNA_ERR_UNSUPPORTED, "aggregation grid too large (%lld blocks)", (long long)grid);
+    int lpr = 4;
+    const int pieces = (a.D + 3) / 4;
+    while (lpr < 64 && lpr < pieces) lpr <<= 1;
+    StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
+    return GNNA_OK;
+}
+
+}  // namespace gnna

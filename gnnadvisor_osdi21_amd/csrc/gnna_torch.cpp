@@ -291,7 +291,11 @@ std::vector<torch::Tensor> spmm_backward_gin(torch::Tensor d_output, torch::Tens
 }
 
 // CPU neighbor-group partitioner (GNNAdvisor.cpp:210-251): indptr is a CPU int32 tensor.
-std::vector<torch::Tensor> build_part(int partSize, torch::Tensor indptr)
+// float_compat = false (default): exact int32 tensors.  float_compat = true: float32 tensors like the
+// reference returns (GNNAdvisor.cpp:229-230) for callers that depend on the dtype -- with the closing
+// sentinel always written (reference bug A fixed), and refused with an error when an offset would not
+// survive the float32 round trip (> 2^24 edges: reference bug B would silently misplace groups).
+std::vector<torch::Tensor> build_part(int partSize, torch::Tensor indptr, bool float_compat)
 {
     TORCH_CHECK(!indptr.is_cuda(), "indptr must be a CPU tensor");
     TORCH_CHECK(indptr.dim() == 1 && indptr.size(0) >= 1, "indptr must be 1-D with num_nodes + 1 entries");
@@ -306,6 +310,13 @@ std::vector<torch::Tensor> build_part(int partSize, torch::Tensor indptr)
     int rc = gnna_build_part_i32(partSize, ip.data_ptr<int32_t>(), num_nodes, partPtr.data_ptr<int32_t>(),
                                  part2Node.data_ptr<int32_t>(), num_parts);
     TORCH_CHECK(rc == GNNA_OK, "GNNAdvisor (libgnna) error ", rc, ": ", gnna_last_error());
+    if (float_compat) {
+        const int64_t nnz = num_nodes > 0 ? (int64_t)ip.data_ptr<int32_t>()[num_nodes] : 0;
+        TORCH_CHECK(nnz <= (int64_t(1) << 24) && num_nodes <= (int64_t(1) << 24),
+                    "build_part(float_compat=True): ", nnz, " edges / ", num_nodes,
+                    " nodes cannot be stored exactly in float32 tensors (limit 2^24); use the int32 result");
+        return {partPtr.to(torch::kFloat32), part2Node.to(torch::kFloat32)};
+    }
     return {partPtr, part2Node};
 }
 
@@ -320,5 +331,6 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("backward_weight", &spmm_backward_weight, "GNNAdvisor backward, d_weight only (extension)");
     m.def("forward_gin", &spmm_forward_gin, "GNNAdvisor forward GIN (HIP, gfx950)");
     m.def("backward_gin", &spmm_backward_gin, "GNNAdvisor backward GIN (HIP, gfx950)");
-    m.def("build_part", &build_part, "GNNAdvisor neighbor-group partitioner (CPU)");
+    m.def("build_part", &build_part, "GNNAdvisor neighbor-group partitioner (CPU)", pybind11::arg("partSize"),
+          pybind11::arg("indptr"), pybind11::arg("float_compat") = false);
 }

@@ -25,6 +25,8 @@ is (param.py:59-64); ``degrees`` is never refreshed after reordering.
 from __future__ import annotations
 
 import math
+from dataclasses import dataclass
+from typing import Optional
 
 WAVE = 64                # CDNA4 wavefront
 NUM_CUS = 256            # MI355X
@@ -128,7 +130,50 @@ def calibrate_phases(column_index, part_pointers, part2Node, num_out_rows, partS
     return chosen
 
 
+@dataclass
+class LaunchKnobs:
+    """The (dimWorker, warpPerBlock) pair one layer kind is launched with (param.py:25-33)."""
+    dimWorker: Optional[int] = None
+    warpPerBlock: Optional[int] = None
+
+
+class _Manual:
+    """manual_mode=True (param.py:58-70): the caller's knobs stay; the only decision is whether the graph
+    is renumbered, and in this mode the renumbered CSR IS adopted by the profile."""
+
+    @staticmethod
+    def run(ip: "inputProperty") -> None:
+        ds = ip.dataset_obj
+        ds.reorder_flag = bool(ip.enable_rabbit)
+        ip.reorder_status = bool(ip.enable_rabbit)
+        if ip.enable_rabbit:
+            ds.rabbit_reorder()
+            ip.row_pointers, ip.column_index = ds.row_pointers, ds.column_index
+        ip._say("\n=> MANUAL Config Complete !!!\n")
+
+
+class _Auto:
+    """manual_mode=False (param.py:72-120): knobs from the policy, then the reorder rule.  Quirk kept on
+    purpose: the renumbered CSR is NOT copied back into the profile here (param.py:108-117)."""
+
+    @staticmethod
+    def run(ip: "inputProperty") -> None:
+        (ip._decide_compat if ip.policy == "compat" else ip._decide_mi355x)()
+        if ip.enable_rabbit:
+            wants = math.sqrt(ip.avgEdgeSpan) > math.sqrt(ip.num_nodes) / 100     # param.py:108
+            ip.dataset_obj.reorder_flag = ip.reorder_status = bool(wants)
+            ip.dataset_obj.rabbit_reorder()
+        ip._say("\n=> AUTO Decider Complete !!!\n")
+
+
 class inputProperty(object):
+    """Graph profile + launch knobs handed to every layer (reference: param.py:4-164; read by
+    gnn_conv.py:17-25,44,67 and GNNA_main.py:101-110).  Public surface kept: constructor arguments, the
+    attributes ``row_pointers column_index degrees partSize dimWorker warpPerBlock partPtr part2Node`` (+ the
+    ``*_input`` / ``*_hidden`` pairs and the statistics), ``decider() set_input() set_hidden() print_param()``.
+    Inside, the per-layer knobs are two ``LaunchKnobs`` records and ``dimWorker`` / ``warpPerBlock`` are
+    views of the active one."""
+
     def __init__(self, row_pointers=None, column_index=None, degrees=None,
                  partSize=None, dimWorker=None, warpPerBlock=None,
                  sharedMem=None,
@@ -138,87 +183,79 @@ class inputProperty(object):
                  manual_mode=True,
                  verbose=False,
                  policy="mi355x"):
-
         if dataset_obj is None:
             raise ValueError("Dataset object MUST SET !!!")
         if policy not in ("mi355x", "compat"):
             raise ValueError("policy must be 'mi355x' or 'compat'")
-
-        self.dataset_obj = dataset_obj
-        self.policy = policy
-
-        self.row_pointers = row_pointers
-        self.column_index = column_index
-        self.degrees = degrees
-
+        self.dataset_obj, self.policy = dataset_obj, policy
+        # the graph as the kernels see it (the caller moves these to the GPU, GNNA_main.py:107-110)
+        self.row_pointers, self.column_index, self.degrees = row_pointers, column_index, degrees
+        self.partPtr = self.part2Node = None
+        # statistics the rules read
         self.num_nodes = dataset_obj.num_nodes
         self.avgNodeDegree = dataset_obj.avg_degree
         self.avgEdgeSpan = dataset_obj.avg_edgeSpan
-
+        self.inputDim, self.hiddenDim = dataset_obj.num_features, hiddenDim
+        # knobs: one neighbor-group size for the whole model, one LaunchKnobs per layer kind
         self.partSize = partSize
-        self.dimWorker = dimWorker
-        self.warpPerBlock = warpPerBlock
-
-        self.dimWorker_input = dimWorker
-        self.dimWorker_hidden = dimWorker
-        self.warpPerBlock_input = warpPerBlock
-        self.warpPerBlock_hidden = warpPerBlock
-        self.inputDim = dataset_obj.num_features
-        self.hiddenDim = hiddenDim
-
-        self.manual_mode = manual_mode
-        self.enable_rabbit = enable_rabbit
-        self.verbose_flag = verbose
+        self._knobs = {"input": LaunchKnobs(dimWorker, warpPerBlock), "hidden": LaunchKnobs(dimWorker, warpPerBlock)}
+        self._active = LaunchKnobs(dimWorker, warpPerBlock)
         self.state_set_input = False
+        # switches
+        self.manual_mode, self.enable_rabbit, self.verbose_flag = manual_mode, enable_rabbit, verbose
         self.reorder_status = False
-
-        self.MAX_warpPerBlock = 8
-        self.share_memory = (sharedMem if sharedMem is not None else 0) * 0.4
-        self.gap_smem = 100
-
-        self.partPtr = None
-        self.part2Node = None
-
+        # constants of the reference's shared-memory model (compat policy only)
+        self.MAX_warpPerBlock, self.gap_smem = 8, 100
+        self.share_memory = 0.4 * (sharedMem if sharedMem is not None else 0)
         # libgnna scheduler knobs / graph hints chosen by the mi355x policy (None = library default)
-        self.groups_per_chunk = None
-        self.loads_in_flight = None
-        self.avg_degree_hint = None
-        self.nonlocal_ids_hint = None
+        self.groups_per_chunk = self.loads_in_flight = None
+        self.avg_degree_hint = self.nonlocal_ids_hint = None
+
+    # ---- views ----------------------------------------------------------------------------------------
+    def _say(self, text):
+        if self.verbose_flag:
+            print(text)
+
+    def _view(kind, field):                                   # noqa: N805  (class-body helper)
+        def get(self):
+            return getattr(self._knobs[kind], field)
+
+        def put(self, value):
+            setattr(self._knobs[kind], field, value)
+        return property(get, put)
+
+    dimWorker_input = _view("input", "dimWorker")
+    dimWorker_hidden = _view("hidden", "dimWorker")
+    warpPerBlock_input = _view("input", "warpPerBlock")
+    warpPerBlock_hidden = _view("hidden", "warpPerBlock")
+    del _view
+
+    @property
+    def dimWorker(self):
+        return self._active.dimWorker
+
+    @dimWorker.setter
+    def dimWorker(self, value):
+        self._active.dimWorker = value
+
+    @property
+    def warpPerBlock(self):
+        return self._active.warpPerBlock
+
+    @warpPerBlock.setter
+    def warpPerBlock(self, value):
+        self._active.warpPerBlock = value
+
+    def _activate(self, kind):
+        src = self._knobs[kind]
+        self._active = LaunchKnobs(src.dimWorker, src.warpPerBlock)
+        self.state_set_input = kind == "input"
+        return self
 
     # ------------------------------------------------------------------ decider
     def decider(self):
-        """manual_mode: keep the user's knobs; auto: choose them (param.py:51-120)."""
-        if self.manual_mode:
-            if self.enable_rabbit:
-                self.dataset_obj.reorder_flag = True
-                self.dataset_obj.rabbit_reorder()
-                self.reorder_status = True
-                self.row_pointers = self.dataset_obj.row_pointers
-                self.column_index = self.dataset_obj.column_index
-            else:
-                self.dataset_obj.reorder_flag = False
-                self.reorder_status = False
-            if self.verbose_flag:
-                print("\n=> MANUAL Config Complete !!!\n")
-            return
-
-        if self.policy == "compat":
-            self._decide_compat()
-        else:
-            self._decide_mi355x()
-
-        if self.enable_rabbit:
-            # reorder iff the average edge span is large relative to the graph (param.py:108-117)
-            if math.sqrt(self.avgEdgeSpan) > math.sqrt(self.num_nodes) / 100:
-                self.dataset_obj.reorder_flag = True
-                self.reorder_status = True
-            else:
-                self.dataset_obj.reorder_flag = False
-                self.reorder_status = False
-            self.dataset_obj.rabbit_reorder()
-
-        if self.verbose_flag:
-            print("\n=> AUTO Decider Complete !!!\n")
+        """Chooses the knobs (auto mode) or keeps the caller's (manual mode); param.py:51-120."""
+        (_Manual if self.manual_mode else _Auto).run(self)
 
     def _decide_compat(self):
         k = reference_formulas(self.avgNodeDegree, self.inputDim, self.hiddenDim, self.share_memory,
@@ -261,18 +298,12 @@ class inputProperty(object):
 
     # ------------------------------------------------------------------ per-layer switches
     def set_input(self):
-        """Switch to the input-layer knobs (param.py:122-131)."""
-        self.dimWorker = self.dimWorker_input
-        self.warpPerBlock = self.warpPerBlock_input
-        self.state_set_input = True
-        return self
+        """Layers that aggregate at the input width take the input-layer knobs (param.py:122-131)."""
+        return self._activate("input")
 
     def set_hidden(self):
-        """Switch to the hidden-layer knobs (param.py:133-141)."""
-        self.dimWorker = self.dimWorker_hidden
-        self.warpPerBlock = self.warpPerBlock_hidden
-        self.state_set_input = False
-        return self
+        """... and every other layer the hidden-layer knobs (param.py:133-141)."""
+        return self._activate("hidden")
 
     def apply_tuning(self):
         """Push the scheduler knobs and graph hints chosen by the mi355x policy into libgnna.
@@ -282,8 +313,11 @@ class inputProperty(object):
             return
         from . import _lib
         nonlocal_ids = self.nonlocal_ids_hint
-        if nonlocal_ids is not None and self.reorder_status:
-            nonlocal_ids = 0   # the graph has just been renumbered for locality
+        if nonlocal_ids is not None and self.reorder_status and \
+                self.row_pointers is getattr(self.dataset_obj, "row_pointers", None):
+            # the CSR these kernels will run on IS the renumbered one (manual mode adopts it; auto mode keeps the
+            # original, reference quirk param.py:108-117 -- there the ids are as scattered as they were)
+            nonlocal_ids = 0
         _lib.set_tuning(groups_per_chunk=self.groups_per_chunk or -1,
                         loads_in_flight=self.loads_in_flight or -1)
         if self.avg_degree_hint is None:

@@ -22,6 +22,15 @@ backend "nccl" == RCCL over xGMI):
 * pipelined exchange (``pipeline_chunks = K``): the blocks are cut into K sub-blocks, the gather buffer is
   sub-block-major, K asynchronous all-gathers are in flight at once and source window k of the
   remote part is aggregated as soon as piece k has arrived (``gnna_agg_rect_windows_f32``).
+* halo exchange (``exchange="halo"``; ``"auto"`` picks it when it moves clearly fewer bytes): instead of
+  whole blocks, every rank receives only the remote source rows its shard actually references.  The
+  unique remote ids per owner are found once, the owners learn which of their rows each peer needs
+  (one all-to-all of index lists at construction), and per step each rank gathers those rows
+  (``index_select``) and the ranks swap them with ``all_to_all_single``; the remote part's column ids
+  are remapped into the compact halo buffer.  The K-piece pipeline applies unchanged: piece k of every
+  peer's list lands in window k of the buffer.  On an id-local (community-ordered) partition the halo is
+  a small fraction of the all-gather volume; on a randomly labelled graph it is not, and ``"auto"``
+  keeps the all-gather there.
 * ``ShardedGCNConv`` / ``ShardedGINConv``: the layers on top (local dense update, sharded aggregation in
   forward and backward, all-reduce of the weight gradient); ``dist_main.py`` is the training driver.
 
@@ -149,7 +158,7 @@ class ShardedAggregator:
                  aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None,
                  overlap: bool = True, force_overlap: bool = False,
                  hint_fn: Optional[Callable] = None, scattered_sources: bool = True,
-                 pipeline_chunks: int = 0):
+                 pipeline_chunks: int = 0, exchange: str = "allgather"):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -161,15 +170,22 @@ class ShardedAggregator:
         self.overlap = bool(overlap) and (self.world > 1 or force_overlap)
         # pipelined exchange: K all-gathers of 1/K of every block, each aggregated on arrival
         # (0 = automatic: 4 pieces once the remote part is big enough to keep every piece busy)
+        assert exchange in ("allgather", "halo", "auto")
+        self.device = torch.device(device) if device is not None else column_index.device
+        if exchange != "allgather" and self.world > 1:
+            self.overlap = True                                  # the halo buffer holds remote rows only
         K = int(pipeline_chunks)
         if K <= 0:
-            remote_edges = column_index.numel() * (self.world - 1) // max(1, self.world)
+            # every rank must arrive at the same K (it fixes the layout and the number of collectives
+            # per step), so the decision is taken on the largest shard
+            remote_edges = self._agree_max(column_index.numel() * (self.world - 1) // max(1, self.world))
             K = 4 if (self.world > 1 and remote_edges >= (16 << 20)) else 1
         self.chunks = max(1, min(K, 16, self.rows_per_rank)) if self.overlap else 1
+        assert self._agree_max(self.chunks) == self.chunks == -self._agree_max(-self.chunks), \
+            "ranks disagree on the number of exchange pieces"
         self.chunk_rows = (self.rows_per_rank + self.chunks - 1) // self.chunks
         self.rows_per_rank = self.chunk_rows * self.chunks          # padded so the pieces are equal
         self.partSize = int(partSize)
-        self.device = torch.device(device) if device is not None else column_index.device
         # hints are only meaningful for the real kernel; an injected aggregate_fn gets none
         self.hint_fn = hint_fn if hint_fn is not None else (_default_hints if aggregate_fn is None else None)
         self.scattered_sources = bool(scattered_sources)
@@ -185,6 +201,8 @@ class ShardedAggregator:
             self.column_index = sort_columns_within_rows(self.row_pointers, self.column_index)
         self.part_pointers = pp.to(self.device)
         self.part2Node = p2n.to(self.device)
+        self.halo_rows = 0
+        self.remote_rows = self.world * self.rows_per_rank
         # local-source / remote-source split for the overlapped schedule
         if self.overlap:
             lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
@@ -195,10 +213,16 @@ class ShardedAggregator:
             self.avg_degree_local = ci_l.numel() / max(1, self.n_local)
             self.avg_degree_remote = ci_r.numel() / max(1, self.n_local)
             self.local_part = (ci_l.contiguous(), pp_l.to(self.device), p2n_l.to(self.device))
-            ci_r = remap_columns_to_padded(ci_r, self.bounds, self.rows_per_rank, self.chunks)
+            self.exchange = self._plan_exchange(exchange, ci_r)
+            if self.exchange == "halo":
+                ci_r = self._halo_remap(ci_r)
+            else:
+                ci_r = remap_columns_to_padded(ci_r, self.bounds, self.rows_per_rank, self.chunks)
             if self.chunks > 1:
                 ci_r = sort_columns_within_rows(rp_r, ci_r)
             self.remote_part = (ci_r.contiguous(), pp_r.to(self.device), p2n_r.to(self.device))
+        else:
+            self.exchange = "allgather"
         self.avg_degree_all = column_index.numel() / max(1, self.n_local)
         if self.hint_fn:
             self.hint_fn(self.column_index, self.avg_degree_all, self.scattered_sources)
@@ -209,10 +233,134 @@ class ShardedAggregator:
         self._pad_buf: Optional[torch.Tensor] = None
         self._deg_all: Optional[torch.Tensor] = None
         self._deg_src: Optional[torch.Tensor] = None
+        self._halo_buf: Optional[torch.Tensor] = None
 
     @property
     def nnz_local(self) -> int:
         return int(self.column_index.numel())
+
+    # ---- collective set-up decisions ------------------------------------------------------------
+    def _agree_max(self, value: int) -> int:
+        """max of an integer over the ranks of the group (identity without a process group)."""
+        if not (dist.is_initialized() and self.world > 1):
+            return int(value)
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        t = torch.tensor([int(value)], dtype=torch.int64, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    def _comm_device(self):
+        return self.device if (dist.is_initialized() and dist.get_backend(self.group) == "nccl") else torch.device("cpu")
+
+    def _plan_exchange(self, exchange: str, ci_remote_global: torch.Tensor) -> str:
+        """Decides between the block all-gather and the halo exchange (collectively: every rank must take the
+        same path) and, for the halo exchange, builds its index lists.  ``ci_remote_global``: global source
+        ids of the remote-source edges of this shard."""
+        self.halo_rows = 0
+        self.remote_rows = self.world * self.rows_per_rank       # rows of the buffer the remote part reads
+        if exchange == "allgather" or self.world == 1:
+            return "allgather"
+        uniq = torch.unique(ci_remote_global.to(torch.int64))    # sorted => grouped by owner
+        worst = self._agree_max(int(uniq.numel()))
+        if exchange == "auto" and worst > 0.7 * (self.world - 1) * self.rows_per_rank:
+            return "allgather"                                   # nearly everything is referenced anyway
+        K, world = self.chunks, self.world
+        b = torch.as_tensor(self.bounds, dtype=torch.int64, device=uniq.device)
+        owner = torch.searchsorted(b[1:], uniq, right=True)
+        need = torch.bincount(owner, minlength=world)            # rows wanted from each peer
+        cdev = self._comm_device()
+        send_counts = torch.empty(world, dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(send_counts, need.to(cdev), group=self.group)
+        need_l, send_l = need.tolist(), send_counts.tolist()
+        wanted = (uniq - b[owner]).to(cdev)                      # offsets inside the owner's block
+        asked = torch.empty(int(sum(send_l)), dtype=torch.int64, device=cdev)
+        dist.all_to_all_single(asked, wanted, output_split_sizes=send_l, input_split_sizes=need_l, group=self.group)
+        asked = asked.to(self.device)
+        assert not asked.numel() or (int(asked.min()) >= 0 and int(asked.max()) < self.n_local)
+
+        # piece k of a list of n rows = rows [k*c, (k+1)*c) with c = ceil(n / K); both sides derive it from n
+        def pieces(n):
+            c = (n + K - 1) // K if n else 0
+            return [max(0, min(n, (k + 1) * c) - min(n, k * c)) for k in range(K)]
+        need_pc = [pieces(n) for n in need_l]                    # [peer][k]
+        send_pc = [pieces(n) for n in send_l]
+        self._recv_splits = [[need_pc[p][k] for p in range(world)] for k in range(K)]
+        self._send_splits = [[send_pc[p][k] for p in range(world)] for k in range(K)]
+        self.window_rows = max(1, max(sum(r) for r in self._recv_splits))
+        self.remote_rows = K * self.window_rows
+        # send side: per piece, the rows of this rank's block to ship, concatenated by receiver
+        starts = [0]
+        for n in send_l:
+            starts.append(starts[-1] + n)
+        self._send_index = []
+        for k in range(K):
+            parts = []
+            for p in range(world):
+                c = (send_l[p] + K - 1) // K if send_l[p] else 0
+                lo = starts[p] + min(send_l[p], k * c)
+                parts.append(asked[lo: lo + send_pc[p][k]])
+            self._send_index.append(torch.cat(parts) if parts else asked[:0])
+        # receive side: position of every needed id in the window-major halo buffer
+        pos = torch.empty_like(uniq)
+        at = 0
+        for p in range(world):
+            n = need_l[p]
+            if not n:
+                continue
+            c = (n + K - 1) // K
+            j = torch.arange(n, device=uniq.device)
+            k = torch.div(j, c, rounding_mode="floor")
+            off = torch.zeros(K, dtype=torch.int64, device=uniq.device)
+            for kk in range(K):
+                off[kk] = kk * self.window_rows + sum(self._recv_splits[kk][:p])
+            pos[at: at + n] = off[k] + (j - k * c)
+            at += n
+        self._halo_ids, self._halo_pos = uniq, pos
+        self.halo_rows = int(uniq.numel())
+        return "halo"
+
+    def _halo_remap(self, ci_remote_global: torch.Tensor) -> torch.Tensor:
+        idx = torch.searchsorted(self._halo_ids, ci_remote_global.to(torch.int64))
+        return self._halo_pos[idx].to(torch.int32)
+
+    def exchange_halo(self, X_local: torch.Tensor, buf: Optional[torch.Tensor] = None):
+        """Ships the rows of this rank's block that the peers reference and receives this shard's halo rows
+        into the window-major buffer: K asynchronous all_to_all_single calls.  -> (buffer, [work handles])."""
+        D = X_local.shape[1] if X_local.dim() == 2 else 1
+        shape = (self.remote_rows, D) if X_local.dim() == 2 else (self.remote_rows,)
+        if buf is None:
+            if self._halo_buf is None or self._halo_buf.shape != shape or self._halo_buf.device != X_local.device:
+                self._halo_buf = torch.zeros(shape, dtype=X_local.dtype, device=X_local.device)
+            buf = self._halo_buf
+        works, keep = [], []
+        for k in range(self.chunks):
+            send = X_local.index_select(0, self._send_index[k])
+            n_in = sum(self._recv_splits[k])
+            recv = buf[k * self.window_rows: k * self.window_rows + n_in]
+            keep.append(send)
+            works.append(dist.all_to_all_single(recv, send, output_split_sizes=self._recv_splits[k],
+                                                input_split_sizes=self._send_splits[k], group=self.group,
+                                                async_op=True))
+        self._in_flight = keep                                   # the send buffers live until the next exchange
+        return buf, works
+
+    def bytes_received_per_step(self, dim: int) -> int:
+        """Feature bytes this rank receives from its peers per aggregation."""
+        if self.world == 1:
+            return 0
+        if self.exchange == "halo":
+            return self.halo_rows * dim * 4
+        return (self.world - 1) * self.rows_per_rank * dim * 4
+
+    def allgather_bytes_per_step(self, dim: int) -> int:
+        return (self.world - 1) * self.rows_per_rank * dim * 4 if self.world > 1 else 0
+
+    def describe_exchange(self) -> str:
+        if self.world == 1:
+            return "no exchange (one rank)"
+        how = ("halo rows only (all_to_all_single of %d of %d remote rows)" % (self.halo_rows, (self.world - 1) * self.rows_per_rank)
+               if self.exchange == "halo" else "all-gather of the feature blocks")
+        return f"{how} in {self.chunks} piece(s), overlapped with the local-source aggregation"
 
     def gather_features(self, X_local: torch.Tensor, async_op: bool = False):
         """all-gather the per-rank feature blocks into the padded [world * rows_per_rank, D] layout.
@@ -260,7 +408,13 @@ class ShardedAggregator:
     def prepare_degrees(self, degrees_local: torch.Tensor) -> torch.Tensor:
         """all-gather the per-node degree norms once (graph constant) into the padded layout."""
         assert degrees_local.numel() == self.n_local
-        if self.world == 1 and self.chunks == 1:
+        if self.exchange == "halo":
+            buf = torch.ones(self.remote_rows, dtype=degrees_local.dtype, device=degrees_local.device)
+            _, works = self.exchange_halo(degrees_local.contiguous(), buf)
+            for w in works:
+                w.wait()
+            self._deg_all = buf
+        elif self.world == 1 and self.chunks == 1:
             self._deg_all = degrees_local
         elif self.world == 1:
             pad = torch.ones(self.rows_per_rank, dtype=degrees_local.dtype, device=degrees_local.device)
@@ -291,7 +445,7 @@ class ShardedAggregator:
             X_all = self.gather_features(X_local)
             return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node,
                                      self.n_local, self.partSize, degrees_local, deg_in, epsilon, out)
-        if self.chunks > 1:
+        if self.chunks > 1 or self.exchange == "halo":
             return self._aggregate_pipelined(X_local, mode, degrees_local, deg_in, epsilon, out)
         # overlapped: remote blocks travel while the local-source edges are aggregated
         X_all, work = self.gather_features(X_local, async_op=True)
@@ -307,7 +461,10 @@ class ShardedAggregator:
     def _aggregate_pipelined(self, X_local, mode, degrees_local, deg_in, epsilon, out):
         """K-piece exchange: all pieces are put in flight at once; the local-source edges are
         aggregated meanwhile, then source window k of the remote part as soon as piece k is there."""
-        X_all, works = self.gather_feature_chunks(X_local)
+        if self.exchange == "halo":
+            X_all, works = self.exchange_halo(X_local.contiguous())
+        else:
+            X_all, works = self.gather_feature_chunks(X_local)
         ci_l, pp_l, p2n_l = self.local_part
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
                                 degrees_local, degrees_local, epsilon, out)
@@ -317,7 +474,7 @@ class ShardedAggregator:
                 work.wait()
             out = self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
                                     degrees_local, deg_in, epsilon, out, accumulate=True,
-                                    windows=(self.chunks, k, k + 1))
+                                    windows=(self.chunks, k, k + 1) if self.chunks > 1 else None)
         return out
 
     def calibrate(self, dims, reps: int = 3) -> dict:
@@ -330,7 +487,7 @@ class ShardedAggregator:
         from . import _lib
         from .decider import calibrate_phases
         res = {}
-        n_all = self.world * self.rows_per_rank
+        n_all = self.remote_rows if self.overlap else self.world * self.rows_per_rank
         if not self.overlap:
             res["whole"] = calibrate_phases(self.column_index, self.part_pointers, self.part2Node, self.n_local,
                                             self.partSize, dims, num_in_rows=n_all if self.world > 1 else self.n_local)

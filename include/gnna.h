@@ -97,6 +97,13 @@ GNNA_API int gnna_edge_span(const int32_t *src, const int32_t *dst, int64_t num_
 GNNA_API int gnna_reorder_rcm_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
                          int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
 
+/* Locality renumbering by communities: writes new_id[old_id] (a permutation).  Size-capped label propagation
+ * on the symmetrised graph (multi-threaded, deterministic), the communities laid out as a chain by their
+ * ties, positions refined by barycentre sweeps -- the role of rabbit.reorder (community-based Rabbit Order,
+ * rabbit_module/src/reorder.cpp:235-295) with a different, reproducible algorithm (gnna_reorder.cpp). */
+GNNA_API int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
+                               int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
+
 /* ---- aggregation (device) ------------------------------------------------------------
  * out[i, :] = sum over groups p with part2Node[p] == i, over e in [part_pointers[p],
  *             part_pointers[p+1]):  coef(i, column_index[e]) * input[column_index[e], :]
@@ -198,6 +205,10 @@ typedef struct gnna_tuning {
                              padded to a 128-byte-line-friendly size when the width calls for
                              it (e.g. 41 -> 48, 56 -> 64 floats), 2 = never, 0 = automatic (when
                              a source row is gathered >= ~32 times)                           */
+    int stream_kernel;    /* 0/1 = the streaming kernel with the sliced (single-launch, stateless) schedule
+                             where it applies (rows of >= 4 floats, unweighted or pre-scaled gather, no
+                             source windows), 2 = always the chunk-walk kernel with per-launch column
+                             phases (round-1 schedule; kept for the per-edge GCN form and the windows) */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
@@ -219,6 +230,9 @@ GNNA_API int gnna_set_graph_phases(const int32_t *column_index, int dim, int col
 
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
 GNNA_API int gnna_last_num_phases(void);
+/* Number of aggregation-kernel launches that call issued (the sliced schedule of the streaming kernel is one
+ * launch whatever its number of phases; the chunk-walk kernel launches once per phase). */
+GNNA_API int gnna_last_num_launches(void);
 
 /* ---- kernel timing (HIP events on the caller's stream; used by bench.py) ---------------
  * Between gnna_profile_begin() and gnna_profile_end() every aggregation call records HIP

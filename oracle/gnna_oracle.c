@@ -31,6 +31,7 @@
  * Compile with -ffp-contract=off: the reference rounds coefficient*feature and the
  * accumulate separately (__fmaf_rn(a, b, 0) followed by +=, .cu:355,389,405).
  */
+#include <omp.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
@@ -222,6 +223,30 @@ void oracle_csr_sag_omp(const float *restrict input, const int32_t *restrict row
             for (int d = 0; d < w; d++) out[d] = acc[d];
         }
     }
+}
+
+/* First-touch copy for the timed CPU baseline: `dst` is a fresh (never written) allocation; copying
+ * it with the same static thread layout that later reads it spreads its pages over the NUMA nodes of
+ * the threads instead of leaving them all on the node of the one thread that filled the array. */
+void oracle_first_touch_copy(float *restrict dst, const float *restrict src, int64_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (n + 1023) / 1024; b++) {
+        const int64_t lo = b * 1024, hi = lo + 1024 < n ? lo + 1024 : n;
+        if (src) for (int64_t i = lo; i < hi; i++) dst[i] = src[i];
+        else for (int64_t i = lo; i < hi; i++) dst[i] = 0.0f;
+    }
+}
+
+int oracle_num_threads(void)
+{
+    int n = 1;
+#pragma omp parallel
+    {
+#pragma omp master
+        n = omp_get_num_threads();
+    }
+    return n;
 }
 
 /* Single-thread neighbor-group SAG over a slice of groups [g_beg, g_end): the scalar

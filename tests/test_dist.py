@@ -55,19 +55,23 @@ def _oracle_build_part(ps, rp):
     return torch.from_numpy(pp), torch.from_numpy(p2n)
 
 
-def _worker(rank, world, port, n, e, dim, seed, q, overlap=True, chunks=1):
+def _worker(rank, world, port, n, e, dim, seed, q, overlap=True, chunks=1, exchange="allgather", locality=0.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = graph.powerlaw_graph(n, e, 60, seed=seed)             # same graph on every rank
+        g = graph.powerlaw_graph(n, e, 60, seed=seed, locality=locality, window=6)   # same graph on every rank
         bounds = balanced_row_splits(g.row_pointers, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
         X = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1))
         agg = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate,
-                                build_part_fn=_oracle_build_part, overlap=overlap, pipeline_chunks=chunks)
+                                build_part_fn=_oracle_build_part, overlap=overlap, pipeline_chunks=chunks,
+                                exchange=exchange)
         assert agg.overlap == overlap and agg.chunks == (chunks if overlap else 1)
+        if exchange == "halo":
+            assert agg.exchange == "halo" and agg.halo_rows <= (world - 1) * agg.rows_per_rank
+            assert agg.bytes_received_per_step(dim) == agg.halo_rows * dim * 4
         if overlap:
             assert agg.local_part[0].numel() + agg.remote_part[0].numel() == ci.numel()
             assert bool((agg.local_part[0] >= 0).all()) and bool((agg.local_part[0] < hi - lo).all())
@@ -79,7 +83,8 @@ def _worker(rank, world, port, n, e, dim, seed, q, overlap=True, chunks=1):
         ok &= np.allclose(Ys.numpy(), oracle.csr_f64(0, X.numpy(), rpn, cin)[lo:hi], atol=1e-4)
         ok &= np.allclose(Yg.numpy(), oracle.csr_f64(1, X.numpy(), rpn, cin, g.degrees.numpy())[lo:hi], rtol=1e-4, atol=1e-2)
         ok &= np.allclose(Yi.numpy(), oracle.csr_f64(2, X.numpy(), rpn, cin, None, 0.5)[lo:hi], atol=1e-4)
-        q.put((rank, bool(ok), lo, hi, agg.rows_per_rank))
+        q.put((rank, bool(ok), lo, hi, agg.rows_per_rank, agg.exchange,
+               agg.bytes_received_per_step(dim) / max(1, agg.allgather_bytes_per_step(dim))))
     finally:
         dist.destroy_process_group()
 
@@ -103,8 +108,75 @@ def test_two_rank_sharded_aggregation_matches_single_graph(n, e, overlap, chunks
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, *_ in res), res
-    spans = sorted((lo, hi) for _, _, lo, hi, _ in res)
+    spans = sorted((lo, hi) for _, _, lo, hi, *_ in res)
     assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == n   # rows tile exactly
+
+
+def _run_ranks(target, args, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, *args, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+def _halo_worker(rank, world, port, n, e, chunks, exchange, locality, q):
+    _worker(rank, world, port, n, e, 10, 13, q, True, chunks, exchange, locality)
+
+
+@pytest.mark.parametrize("n,e,chunks,locality", [(120, 1800, 1, 0.0), (120, 1800, 3, 0.0), (400, 3000, 1, 0.9),
+                                                  (400, 3000, 4, 0.9), (64, 40, 2, 0.0)])
+def test_two_rank_halo_exchange_matches_single_graph(n, e, chunks, locality):
+    """exchange="halo": only the referenced remote rows travel (all_to_all_single), the remote part reads the
+    compact halo buffer; results equal the whole-graph oracle in all three modes, with and without the
+    K-piece pipeline.  On an id-local graph the halo is well under half of the all-gather volume."""
+    res = _run_ranks(_halo_worker, (n, e, chunks, "halo", locality))
+    assert all(ok for _, ok, *_ in res), res
+    assert all(r[5] == "halo" for r in res)
+    if locality >= 0.9:
+        assert all(r[6] < 0.5 for r in res), [r[6] for r in res]
+
+
+def _auto_worker(rank, world, port, n, e, locality, q):
+    _worker(rank, world, port, n, e, 10, 13, q, True, 1, "auto", locality)
+
+
+def test_auto_exchange_is_a_collective_choice():
+    """exchange="auto": the all-gather stays on a graph whose shards reference nearly every remote row, the
+    halo exchange is taken on an id-local one -- and both ranks always take the same path."""
+    dense = _run_ranks(_auto_worker, (60, 3000, 0.0))
+    assert all(ok for _, ok, *_ in dense) and {r[5] for r in dense} == {"allgather"}
+    local = _run_ranks(_auto_worker, (400, 3000, 0.9))
+    assert all(ok for _, ok, *_ in local) and {r[5] for r in local} == {"halo"}
+
+
+def _uneven_k_worker(rank, world, port, q):
+    """the automatic piece count must be the same on every rank even when their shards differ."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = graph.powerlaw_graph(90, 1200, 40, seed=3)
+        bounds = [0, 20, 90]                                   # very different shard sizes
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        agg = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate, build_part_fn=_oracle_build_part,
+                                pipeline_chunks=0)
+        ks = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ks, torch.tensor([agg.chunks]))
+        q.put((rank, len({int(k) for k in ks}) == 1))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_automatic_piece_count_is_agreed_between_ranks():
+    assert all(ok for _, ok in _run_ranks(_uneven_k_worker, ()))
 
 
 def test_balanced_splits_and_remap():

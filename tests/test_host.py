@@ -83,6 +83,23 @@ def test_extension_module_surface_and_errors():
         GNNA.SAG(X, rp, ci, deg, pp, p2n, 2, 32)                 # positional arity as in the reference
 
 
+def test_build_part_float_compat_mode():
+    """build_part(..., float_compat=True): the reference's float32 return dtype (GNNAdvisor.cpp:229-230) for callers
+    that depend on it -- same values as the int32 result (sentinel always written: bug A fixed), refused when
+    float32 cannot hold the offsets (bug B flagged instead of silently misplacing groups)."""
+    GNNA = load_extension()
+    rp = torch.tensor([0, 3, 3, 8, 9, 9], dtype=torch.int32)          # last node isolated: the reference drops the sentinel
+    pp_i, p2n_i = GNNA.build_part(2, rp)
+    pp_f, p2n_f = GNNA.build_part(2, rp, float_compat=True)
+    assert pp_f.dtype == torch.float32 and p2n_f.dtype == torch.float32
+    assert torch.equal(pp_f.int(), pp_i) and torch.equal(p2n_f.int(), p2n_i)
+    assert pp_f.tolist() == [0, 2, 3, 5, 7, 8, 9]                      # reference: [..., 8, 0]
+    big = torch.tensor([0, 20000001, 40000003], dtype=torch.int32)    # SURVEY a-6 bug B probe
+    with pytest.raises(RuntimeError, match="float32"):
+        GNNA.build_part(32, big, float_compat=True)
+    assert GNNA.build_part(32, big)[0][-1].item() == 40000003
+
+
 def test_product_has_no_cpu_path():
     g = graph.uniform_graph(10, 40, seed=1)
     pp, p2n = _lib.build_part(4, g.row_pointers)
@@ -95,7 +112,7 @@ def test_tuning_roundtrip():
         _lib.set_tuning(8, 4, 2, 0, 1)
         assert _lib.get_tuning() == dict(groups_per_chunk=8, loads_in_flight=4, blocks_per_cu=2,
                                          xcd_remap=0, trust_canonical=1, column_phases=0, avg_degree=0,
-                                         nonlocal_ids=0, gcn_prescale=0, pad_rows=0)
+                                         nonlocal_ids=0, gcn_prescale=0, pad_rows=0, stream_kernel=0)
         _lib.set_tuning(column_phases=8)
         assert _lib.get_tuning()["column_phases"] == 8
         _lib.set_tuning(groups_per_chunk=32)      # others keep their values

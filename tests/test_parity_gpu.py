@@ -220,6 +220,93 @@ def test_full_size_reddit_like_properties():
         assert bool(((got - want).abs() <= 1e-4 * want.abs().clamp(min=1.0)).all()), r
 
 
+def _check_full_size(g, X, y, rows, what):
+    """`rows` sampled rows of y = A X against the fp64 gather-sum: |err| <= 1e-4 * max(1, sum |x_j|)."""
+    for r in rows:
+        b, e = int(g.row_pointers[r]), int(g.row_pointers[r + 1])
+        xs = X[g.column_index[b:e].long()].double()
+        err = (y[r].double() - xs.sum(0)).abs()
+        assert bool((err <= 1e-4 * xs.abs().sum(0).clamp(min=1.0)).all()), (what, r, float(err.max()))
+
+
+def test_full_size_reddit_like_through_the_auto_path():
+    """BASELINE config 3 exactly as bench.py times it: Decider in auto mode (partSize 64, scheduler knobs), the
+    library's own sliced schedule (several phases, one launch).  X = ones -> exact row nnz; sampled rows of a
+    randn aggregation vs fp64; and the drop-in call sequence (no Decider, no hints) takes the same schedule."""
+    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+        pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
+    from gnnadvisor_osdi21_amd.decider import inputProperty
+    g = graph.make_config_graph("reddit-like", device="cuda")
+    n, D = g.num_nodes, 64
+
+    class DS:
+        num_nodes, avg_degree, avg_edgeSpan, num_features, reorder_flag = g.num_nodes, g.avg_degree, g.avg_edgeSpan, 602, False
+
+        def rabbit_reorder(self):
+            pass
+    info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=DS(), manual_mode=False)
+    info.decider()
+    try:
+        info.apply_tuning()
+        ps = info.partSize
+        assert ps == 64
+        pp, p2n = _lib.build_part(ps, g.row_pointers.cpu())
+        ppd, p2nd = pp.cuda(), p2n.cuda()
+        run = lambda x: _lib.sag(x, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4)
+        cnt = (g.row_pointers[1:] - g.row_pointers[:-1]).float()
+        y1 = run(torch.ones(n, D, device="cuda"))
+        phases = _lib.last_num_phases()
+        assert phases >= 4, phases                               # 59.6 MB of X, scattered ids: sliced
+        assert torch.equal(y1, cnt[:, None].expand(-1, D))
+        X = torch.randn(n, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        y = run(X)
+        rows = [int(torch.argmax(cnt))] + torch.randint(0, n, (255,), generator=torch.Generator().manual_seed(5)).tolist()
+        _check_full_size(g, X, y, rows, "auto path")
+    finally:
+        _lib.reset_tuning()
+    # the reference's own call sequence: nothing but build_part and SAG with its manual knobs (32, 32, 4)
+    pp32, p2n32 = _lib.build_part(32, g.row_pointers.cpu())
+    y32 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, pp32.cuda(), p2n32.cuda(), 32, 32, 4)
+    assert _lib.last_num_phases() == phases
+    _check_full_size(g, X, y32, rows[:64], "drop-in path")
+
+
+def test_config5_papers100M_like_shard():
+    """BASELINE config 5, one GPU's share: 1/8 of a papers100M-like graph (13.9 M rows, ~2e8 edges), D = 128
+    (rect entry, 7.1 GB of features: 64-bit row offsets), schedule chosen by the library.  X = ones -> exact
+    row nnz; sampled rows vs fp64; GCN-weighted form on sampled rows."""
+    g = graph.make_config_graph("papers100M-like", device="cuda", scale=0.125)
+    n, D, ps = g.num_nodes, 128, 16
+    assert n * D * 4 > 2 ** 32
+    pp, p2n = _lib.build_part(ps, g.row_pointers.cpu())
+    ppd, p2nd = pp.cuda(), p2n.cuda()
+    cnt = (g.row_pointers[1:] - g.row_pointers[:-1]).float()
+    X = torch.ones(n, D, device="cuda")
+    y = _lib.agg_rect(_lib.MODE_SAG, X, g.column_index, ppd, p2nd, n, ps)
+    assert torch.equal(y, cnt[:, None].expand(-1, D))
+    del y
+    X.normal_(generator=torch.Generator(device="cuda").manual_seed(11))
+    y = _lib.agg_rect(_lib.MODE_SAG, X, g.column_index, ppd, p2nd, n, ps)
+    rows = [int(torch.argmax(cnt)), n - 1, 0] + torch.randint(0, n, (200,), generator=torch.Generator().manual_seed(6)).tolist()
+    _check_full_size(g, X, y, rows, "papers100M-like shard")
+    try:
+        _lib.set_tuning(column_phases=8)                        # the sliced schedule on 64-bit offsets too
+        y8 = _lib.agg_rect(_lib.MODE_SAG, X, g.column_index, ppd, p2nd, n, ps)
+        assert _lib.last_num_phases() == 8
+        _check_full_size(g, X, y8, rows[:64], "papers100M-like shard, 8 phases")
+    finally:
+        _lib.reset_tuning()
+    del y8
+    yg = _lib.agg_rect(_lib.MODE_GCN, X, g.column_index, ppd, p2nd, n, ps, degrees_out=g.degrees, degrees_in=g.degrees, out=y)
+    for r in rows[:50]:
+        b, e = int(g.row_pointers[r]), int(g.row_pointers[r + 1])
+        nb = g.column_index[b:e].long()
+        coef = (g.degrees[r].double() * g.degrees[nb].double())[:, None]
+        ref = (coef * X[nb].double()).sum(0)
+        scale = (coef * X[nb].double().abs()).sum(0).clamp(min=1.0)
+        assert bool(((yg[r].double() - ref).abs() <= 1e-4 * scale).all()), r
+
+
 @pytest.mark.parametrize("phases", [2, 3, 8, 16])
 @pytest.mark.parametrize("partSize,dim", [(32, 64), (7, 16), (64, 100), (100, 8), (32, 257), (8, 602)])
 def test_column_phased_schedule_matches_single_pass(phases, partSize, dim):
@@ -337,8 +424,38 @@ def test_randomised_configurations():
         _lib.reset_tuning()
 
 
-def test_automatic_phase_selection_follows_the_hints():
-    """column_phases = 0: phases only with the Decider's hints (scattered ids, high degree, big X)."""
+def test_sliced_schedule_is_chosen_from_the_partition_itself():
+    """column_phases = 0 with the streaming kernel: no hints from anybody (the drop-in caller's situation).  The
+    library counts, once per graph, how the column ids of the neighbor-groups spread over 16 source slices and
+    picks the number of phases itself: several for a randomly labelled high-degree graph, one when the rows
+    are already local (community order), one when the rows are too short to be worth slicing."""
+    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+        pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
+    D = 256
+    seen = {}
+    for name, g in (("random", graph.make_config_graph("reddit-like", device="cuda", scale=0.25)),
+                    ("local", graph.make_config_graph("reddit-like", device="cuda", scale=0.25, locality=1.0)),
+                    ("sparse", graph.uniform_graph(60000, 360000, seed=5, device="cuda"))):
+        pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+        ppd, p2nd = pp.cuda(), p2n.cuda()
+        X = torch.randn(g.num_nodes, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+        y = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        seen[name] = _lib.last_num_phases()
+        _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        assert _lib.last_num_phases() == seen[name]            # second call: same choice, from the cached plan
+        try:
+            _lib.set_tuning(column_phases=1)
+            y1 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+        finally:
+            _lib.reset_tuning()
+        scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double()
+        assert bool(((y.double() - y1.double()).abs() <= 1e-5 * scale.clamp(min=1.0)).all()), name
+    assert seen["random"] >= 4 and seen["local"] == 1 and seen["sparse"] == 1, seen
+
+
+def test_chunk_walk_phase_selection_follows_the_hints():
+    """column_phases = 0 on the chunk-walk kernel (stream_kernel = 2; also what the per-edge GCN form and the
+    source windows use): phases only with the Decider's hints (scattered ids, high degree, big X)."""
     if _lib.get_tuning()["column_phases"] != 0:
         pytest.skip("GNNA_TUNE forces a phase count: the automatic choice is not under test")
     g = graph.make_config_graph("reddit-like", device="cuda", scale=0.25)
@@ -346,6 +463,7 @@ def test_automatic_phase_selection_follows_the_hints():
     ppd, p2nd = pp.cuda(), p2n.cuda()
     X = torch.randn(g.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     try:
+        _lib.set_tuning(stream_kernel=2)
         y1 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
         assert _lib.last_num_phases() == 1                     # no hints: single pass
         _lib.set_tuning(avg_degree=int(g.nnz / g.num_nodes), nonlocal_ids=1)
@@ -571,6 +689,7 @@ def test_per_graph_hints_are_keyed_by_the_column_index_array():
     run1 = lambda: _lib.sag(X1, g1.row_pointers, g1.column_index, g1.degrees, *parts[0], 64, 32, 4)
     run2 = lambda: _lib.sag(X2, g2.row_pointers, g2.column_index, g2.degrees, *parts[1], 64, 32, 4)
     try:
+        _lib.set_tuning(stream_kernel=2)                       # the hints drive the chunk-walk kernel's schedule
         y1 = run1(); assert _lib.last_num_phases() == 1
         _lib.set_graph_hints(g1.column_index, g1.nnz / g1.num_nodes, True)
         y1h = run1(); assert _lib.last_num_phases() == 4       # 59.6 MB of X, scattered ids, degree ~490
@@ -582,6 +701,7 @@ def test_per_graph_hints_are_keyed_by_the_column_index_array():
         run2(); assert _lib.last_num_phases() >= 2
         _lib.set_graph_hints(None, 0, False)                   # forget everything
         _lib.reset_tuning()
+        _lib.set_tuning(stream_kernel=2)
         run1(); assert _lib.last_num_phases() == 1
     finally:
         _lib.set_graph_hints(None, 0, False)
