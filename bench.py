@@ -393,7 +393,9 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
         times.append(time.perf_counter() - t0)
     order = list(times)
     times.sort()
-    med = times[len(times) // 2]
+    # the passes on this host fall into two modes (every other pass ~1.8x slower, see pass_ms_in_order); the value
+    # is the median of the faster half -- the typical undisturbed pass -- which repeats from run to run
+    med = times[len(times) // 4]
     # scalar port of the reference algorithm on ~1/16 of the groups
     ppn, p2nn = pp.numpy(), p2n.numpy()
     P = int(p2nn.size)
@@ -405,8 +407,9 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
     e1 = int(ppn[g_end] - ppn[0])
     return {
         "value": nnz / med, "unit": "edges/s", "cores": threads, "kind": "port",
-        "sample": f"full graph ({nnz} edges, D={dim}), median of {len(times)} passes of the OpenMP row-parallel "
-                  f"fp32 CSR SpMM in oracle/gnna_oracle.c (threads pinned, NUMA first-touch)",
+        "sample": f"full graph ({nnz} edges, D={dim}), median of the faster half of {len(times)} passes of the OpenMP "
+                  f"row-parallel fp32 CSR SpMM in oracle/gnna_oracle.c (threads pinned, NUMA first-touch)",
+        "ms_median_all_passes": times[len(times) // 2] * 1e3,
         "ms": med * 1e3, "ms_min": times[0] * 1e3, "ms_max": times[-1] * 1e3,
         "pass_ms_in_order": [round(t * 1e3, 1) for t in order],
         "gather_model_GBs": gather_model_bytes(nnz, len(rp) - 1, P, dim) / med / 1e9,

@@ -38,6 +38,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 
@@ -456,9 +457,9 @@ int choose_row_stride(int dim)
 
 // Number of phases of the sliced schedule from the slice statistics of the partition (st.cells[l] =
 // non-empty (group, slice) cells when the 16 fine slices are merged into 16 >> l).
-//  * not at all when the column ids of a row stay near the row (average |id - row| below two slices: a
-//    locality-ordered graph gathers from a small moving window already) -- measurable when rows and columns
-//    share one numbering; a caller's "scattered ids" hint settles it otherwise;
+//  * not at all when the column ids of a row stay near the row (>= 60 % of the edges within a window of source
+//    rows that fits an XCD's L2: a locality-ordered graph gathers from a small moving window already) --
+//    measurable when rows and columns share one numbering; a caller's "scattered ids" hint settles it otherwise;
 //  * slices of at most 8 MiB of source rows (Reddit-like graph, D = 16 / 32 / 64 / 128: best 4 / 4 / 8 / 16
 //    phases; two slices are live while the chip moves from one to the next, and an XCD's L2 is 4 MiB);
 //  * at least ~12 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses
@@ -468,7 +469,22 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
 {
     if (st.groups <= 0 || st.edges <= 0) return 1;
     if (!hinted_scattered) {
-        if (square && st.span / st.edges < 2.0 * (double)slice_rows) return 1;
+        if (square) {
+            // share of the edges whose source lies within the window around the destination that an XCD's L2 keeps
+            // while it walks the rows in order (+-1.75 MiB of source rows); log-linear between the histogram's
+            // half-octave thresholds.  Measured on Reddit-sized graphs at D = 64: share 0.9 (hidden locality) and
+            // ~0.75 (after gnna_reorder_community_i32) run fastest single pass; a random labelling has ~0.06.
+            const double row_bytes = (double)x_bytes / ((double)slice_rows * S);
+            const double half_rows = 1.75 * 1048576.0 / row_bytes;
+            double share = 0.0;
+            if (half_rows >= 256.0) {
+                const double pos = std::min(23.0, 2.0 * std::log2(half_rows / 256.0));
+                const int k = (int)pos;
+                const double lo = st.near[k], hi = st.near[std::min(23, k + 1)];
+                share = (lo + (hi - lo) * (pos - k)) / st.edges;
+            }
+            if (share >= 0.6) return 1;
+        }
         if (st.cells[0] <= 1.15 * st.groups) return 1;       // every group inside one slice
     }
     int b = 1;

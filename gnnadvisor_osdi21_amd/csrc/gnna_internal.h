@@ -52,6 +52,7 @@ struct SlicePlanStats {
     double cells[4] = {0, 0, 0, 0};  // non-empty (group, slice) cells at S, S/2, S/4, S/8 slices
     double edges = 0, groups = 0;
     double span = 0;                 // sum over the edges of |column id - destination row|
+    double near[24] = {0};           // near[k]: edges with |column id - destination row| < 256 * 2^(k / 2)
 };
 // Slice counts cnt[P][16] of the partition for S slices of slice_rows source rows (library cache; a miss
 // enqueues the counting kernel on `stream`, and with want_stats synchronises it once to read the

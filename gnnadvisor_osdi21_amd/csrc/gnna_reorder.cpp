@@ -7,26 +7,26 @@
 // incremental community aggregation with a lock-free merge protocol (needs boost / numa / tcmalloc, is
 // not reproducible under OpenMP).  This is a different, deterministic algorithm with the same contract:
 //
-//   1. communities: size-capped label propagation on the symmetrised graph.  Every sweep computes, for
-//      all nodes in parallel, the label that carries most of the node's edges (ties -> smallest label);
-//      sweeps alternate between "may only move to a smaller label" and "to a larger one", which rules
-//      out the two-node label swaps of synchronous propagation; moves are then applied in node order
-//      against the size cap (the only sequential O(N) part).
-//   2. order of the communities: the community graph (summed edge weights) is walked greedily -- start
-//      at the heaviest community, always append the unplaced community most strongly tied to the tail
-//      of the chain (falling back to the most strongly tied to anything placed) -- which lays adjacent
-//      regions of a spatial / band-like graph next to each other.
-//   3. order inside and across the community borders: a few barycentre sweeps (position <- mean
-//      position of the neighbours, parallel Jacobi), started from the community ranks, pull every node
-//      to the middle of its own neighbourhood; the final id is the rank of the refined position.
+//   1. backbone: an edge (u, v) is kept when u and v have at least T common neighbours (merge of the two
+//      sorted adjacency lists, all edges in parallel, early exit at T).  Edges inside a community / a
+//      spatial neighbourhood are embedded in many triangles, the long-range edges that make a graph a
+//      small world -- and defeat any breadth-first ordering -- are in none.  Hubs (degree > 16 x average)
+//      are left out of the backbone; they are adjacent to everything.
+//   2. coarse order: breadth-first discovery order over the backbone, component by component (largest
+//      first), started at a peripheral node of the component (the last node of a first sweep).
+//   3. fine order: a few barycentre sweeps over the backbone (position <- mean position of the
+//      neighbours, parallel Jacobi, re-spread to ranks after every sweep) pull every node to the middle of
+//      its own neighbourhood; nodes without backbone edges are then put at the mean position of all their
+//      neighbours.  The final id is the rank of the refined position.
 //
-// Threads: std::thread over contiguous node ranges, results independent of the thread count.
+// Threads: std::thread over contiguous node ranges; the result does not depend on the thread count.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
-#include <queue>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -86,169 +86,147 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         ci.resize((size_t)nnz);
     }
 
-    // ---- 1. size-capped label propagation --------------------------------------------------------------
-    // cap: communities of at most ~N/64 nodes (and at least 256), i.e. the chain of step 2 has >= 64 links
-    const int64_t cap = std::max<int64_t>(256, n / 64);
-    std::vector<int32_t> label((size_t)n), want((size_t)n), csize((size_t)n, 1);
-    std::iota(label.begin(), label.end(), 0);
-    for (int sweep = 0; sweep < 10; sweep++) {
-        const bool to_smaller = (sweep % 2) == 0;
+    // ---- 1. backbone: edges with >= T common neighbours ------------------------------------------------------
+    const double avg_deg = (double)ci.size() / (double)n;
+    const int T = std::getenv("GNNA_REORDER_SUPPORT") ? std::atoi(std::getenv("GNNA_REORDER_SUPPORT"))
+                                                       : (avg_deg < 32 ? 1 : (avg_deg < 128 ? 2 : 3));
+    const int64_t hub = (int64_t)std::max(64.0, 16.0 * avg_deg);
+    // two unrelated nodes of degrees du, dv still share about du * dv * sum_x d_x^2 / (2m)^2 neighbours (the
+    // popular nodes); an edge has to beat that expectation clearly to count as embedded
+    double sum_d2 = 0.0;
+    for (int64_t v = 0; v < n; v++) {
+        const double d = (double)(rp[(size_t)v + 1] - rp[(size_t)v]);
+        if (d <= (double)hub) sum_d2 += d * d;
+    }
+    const double chance = sum_d2 / ((double)ci.size() * (double)ci.size());
+    std::vector<int32_t> brp((size_t)n + 1, 0), bci;
+    {
+        std::vector<uint8_t> keep(ci.size(), 0);
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
-            std::vector<int32_t> nb;
-            for (int64_t v = lo; v < hi; v++) {
-                const int32_t b = rp[(size_t)v], e = rp[(size_t)v + 1];
-                want[(size_t)v] = label[(size_t)v];
-                if (e == b) continue;
-                nb.resize((size_t)(e - b));
-                for (int32_t k = b; k < e; k++) nb[(size_t)(k - b)] = label[(size_t)ci[(size_t)k]];
-                std::sort(nb.begin(), nb.end());
-                // most frequent neighbour label; ties -> smallest label; the node's own label wins ties with it
-                const int32_t own = label[(size_t)v];
-                int32_t best = own, best_cnt = 0, own_cnt = 0;
-                for (size_t i = 0; i < nb.size();) {
-                    size_t j = i;
-                    while (j < nb.size() && nb[j] == nb[i]) j++;
-                    const int32_t cnt = (int32_t)(j - i);
-                    if (nb[i] == own) own_cnt = cnt;
-                    if (cnt > best_cnt) { best_cnt = cnt; best = nb[i]; }
-                    i = j;
+            for (int64_t u = lo; u < hi; u++) {
+                const int32_t ub = rp[(size_t)u], ue = rp[(size_t)u + 1];
+                if (ue - ub > hub) continue;
+                for (int32_t k = ub; k < ue; k++) {
+                    const int32_t v = ci[(size_t)k];
+                    const int32_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
+                    if (ve - vb > hub || v == u) continue;
+                    const int32_t need = std::max<int32_t>(T, (int32_t)std::ceil(3.0 * chance * (double)(ue - ub) * (double)(ve - vb)));
+                    int32_t i = ub, j = vb, common = 0;
+                    while (i < ue && j < ve && common < need) {
+                        const int32_t a = ci[(size_t)i], b2 = ci[(size_t)j];
+                        common += a == b2;
+                        i += a <= b2;
+                        j += b2 <= a;
+                    }
+                    keep[(size_t)k] = common >= need;
                 }
-                if (best != own && best_cnt > own_cnt && (to_smaller ? best < own : best > own)) want[(size_t)v] = best;
             }
         });
-        int64_t moved = 0;
-        for (int64_t v = 0; v < n; v++) {
-            const int32_t w = want[(size_t)v], l = label[(size_t)v];
-            if (w != l && csize[(size_t)w] < cap) {
-                csize[(size_t)w]++; csize[(size_t)l]--;
-                label[(size_t)v] = w;
-                moved++;
+        for (int64_t u = 0; u < n; u++) {
+            int32_t c = 0;
+            for (int32_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++) c += keep[(size_t)k];
+            brp[(size_t)u + 1] = brp[(size_t)u] + c;
+        }
+        bci.resize((size_t)brp[(size_t)n]);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t u = lo; u < hi; u++) {
+                int32_t at = brp[(size_t)u];
+                for (int32_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++)
+                    if (keep[(size_t)k]) bci[(size_t)at++] = ci[(size_t)k];
             }
-        }
-        if (moved * 200 < n && sweep >= 3) break;   // < 0.5 % of the nodes still moving
+        });
     }
+    if (std::getenv("GNNA_REORDER_DEBUG"))
+        std::fprintf(stderr, "[reorder] %lld nodes, %zu adjacency entries, backbone (>= %d common neighbours) keeps %zu\n",
+                     (long long)n, ci.size(), T, bci.size());
 
-    // compact community ids
-    std::vector<int32_t> comm_of((size_t)n, -1);
-    int32_t nc = 0;
-    for (int64_t v = 0; v < n; v++) {
-        int32_t &c = comm_of[(size_t)label[(size_t)v]];
-        if (c < 0) c = nc++;
-    }
-    std::vector<int32_t> comm((size_t)n);
-    std::vector<int64_t> cnodes((size_t)nc, 0);
-    for (int64_t v = 0; v < n; v++) { comm[(size_t)v] = comm_of[(size_t)label[(size_t)v]]; cnodes[(size_t)comm[(size_t)v]]++; }
-
-    // ---- 2. chain of communities ------------------------------------------------------------------------
-    // community graph as sorted (a, b) -> weight triples, built per thread and merged
-    std::vector<std::pair<int64_t, int64_t>> cedges;   // (a * nc + b, weight), a != b
+    // ---- 2. breadth-first discovery order over the backbone ---------------------------------------------------
+    std::vector<double> pos((size_t)n, -1.0), nxt((size_t)n);
+    std::vector<char> in_backbone((size_t)n, 0);
     {
-        std::vector<std::vector<int64_t>> keys((size_t)threads);
-        const int64_t step = (n + threads - 1) / threads;
-        std::vector<std::thread> th;
-        for (int t = 0; t < threads; t++) {
-            th.emplace_back([&, t] {
-                auto &out = keys[(size_t)t];
-                for (int64_t v = t * step; v < std::min(n, (t + 1) * step); v++) {
-                    const int64_t a = comm[(size_t)v];
-                    for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++) {
-                        const int64_t b = comm[(size_t)ci[(size_t)k]];
-                        if (a != b) out.push_back(a * nc + b);
-                    }
+        std::vector<int32_t> comp((size_t)n, -1), queue;
+        queue.reserve((size_t)n);
+        // A node is discovered once `theta` of its backbone neighbours have been walked (the seed's whole
+        // neighbourhood starts the walk): the front advances through a neighbourhood only when it is adjacent to
+        // it in many places, so the odd long-range edge that survived step 1 does not open a second front far away.
+        const int theta = avg_deg < 32 ? 1 : 3;
+        std::vector<int32_t> hits((size_t)n, 0);
+        auto bfs = [&](int32_t seed, int32_t tag, std::vector<int32_t> &out) {   // nodes of comp `tag` in discovery order
+            out.clear();
+            out.push_back(seed);
+            comp[(size_t)seed] = tag;
+            for (int32_t k = brp[(size_t)seed]; k < brp[(size_t)seed + 1]; k++) {
+                const int32_t u = bci[(size_t)k];
+                if (comp[(size_t)u] != tag) { comp[(size_t)u] = tag; out.push_back(u); }
+            }
+            for (size_t head = 0; head < out.size(); head++) {
+                const int32_t v = out[head];
+                for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                    const int32_t u = bci[(size_t)k];
+                    if (comp[(size_t)u] == tag) continue;
+                    if (hits[(size_t)u] < 0 || hits[(size_t)u] / 65536 != tag) hits[(size_t)u] = tag * 65536;   // counter of this walk
+                    if ((++hits[(size_t)u] & 65535) >= theta) { comp[(size_t)u] = tag; out.push_back(u); }
                 }
-                std::sort(out.begin(), out.end());
-            });
-        }
-        for (auto &t : th) t.join();
-        std::vector<int64_t> all;
-        size_t total = 0;
-        for (auto &k : keys) total += k.size();
-        all.reserve(total);
-        for (auto &k : keys) { all.insert(all.end(), k.begin(), k.end()); std::vector<int64_t>().swap(k); }
-        std::sort(all.begin(), all.end());
-        for (size_t i = 0; i < all.size();) {
-            size_t j = i;
-            while (j < all.size() && all[j] == all[i]) j++;
-            cedges.emplace_back(all[i], (int64_t)(j - i));
-            i = j;
-        }
-    }
-    std::vector<int64_t> cstart((size_t)nc + 1, 0);
-    for (auto &e : cedges) cstart[(size_t)(e.first / nc) + 1]++;
-    for (int32_t c = 0; c < nc; c++) cstart[(size_t)c + 1] += cstart[(size_t)c];
-    std::vector<int32_t> order_c;
-    order_c.reserve((size_t)nc);
-    {
-        std::vector<char> placed((size_t)nc, 0);
-        std::vector<double> tie((size_t)nc, 0.0);   // weight between an unplaced community and the placed set
-        std::priority_queue<std::pair<double, int32_t>> heap;   // (tie, community), stale entries skipped
-        auto place = [&](int32_t c) {
-            placed[(size_t)c] = 1;
-            order_c.push_back(c);
-            for (int64_t k = cstart[(size_t)c]; k < cstart[(size_t)c + 1]; k++) {
-                const int32_t b = (int32_t)(cedges[(size_t)k].first % nc);
-                if (placed[(size_t)b]) continue;
-                tie[(size_t)b] += (double)cedges[(size_t)k].second;
-                heap.emplace(tie[(size_t)b], b);
             }
         };
-        int32_t seed = 0;
-        for (int32_t c = 1; c < nc; c++)
-            if (cnodes[(size_t)c] > cnodes[(size_t)seed]) seed = c;
-        place(seed);
-        int32_t scan = 0;   // next candidate among communities tied to nothing placed (isolated ones: id order)
-        while ((int32_t)order_c.size() < nc) {
-            const int32_t tail = order_c.back();
-            int32_t next = -1;
-            double best = 0.0;
-            for (int64_t k = cstart[(size_t)tail]; k < cstart[(size_t)tail + 1]; k++) {   // strongest tie to the tail
-                const int32_t b = (int32_t)(cedges[(size_t)k].first % nc);
-                const double w = (double)cedges[(size_t)k].second / (double)cnodes[(size_t)b];
-                if (!placed[(size_t)b] && (w > best || (w == best && next >= 0 && b < next))) { best = w; next = b; }
-            }
-            while (next < 0 && !heap.empty()) {                                          // else: to anything placed
-                const auto top = heap.top();
-                heap.pop();
-                if (!placed[(size_t)top.second] && top.first == tie[(size_t)top.second]) next = top.second;
-            }
-            if (next < 0) {
-                while (placed[(size_t)scan]) scan++;
-                next = scan;
-            }
-            place(next);
+        // components by a first sweep (tags 0, 2, 4, ...), then re-walked from their last-discovered node
+        // (tags 1, 3, 5, ...): a peripheral start keeps the levels thin
+        std::vector<std::pair<int64_t, int32_t>> comps;   // (-size, first sweep's last node)
+        std::vector<int32_t> walk;
+        int32_t tag = 0;
+        for (int64_t v = 0; v < n; v++) {
+            if (comp[(size_t)v] >= 0 || brp[(size_t)v + 1] == brp[(size_t)v]) continue;
+            bfs((int32_t)v, tag, walk);
+            comps.emplace_back(-(int64_t)walk.size(), walk.back());
+            tag += 2;
         }
+        std::sort(comps.begin(), comps.end());
+        int64_t at = 0;
+        for (auto &c : comps) {
+            const int32_t seed = c.second;
+            bfs(seed, comp[(size_t)seed] + 1, walk);
+            for (int32_t v : walk) { pos[(size_t)v] = (double)at++; in_backbone[(size_t)v] = 1; }
+        }
+        for (int64_t v = 0; v < n; v++)
+            if (pos[(size_t)v] < 0) pos[(size_t)v] = (double)at++;        // no backbone edge: placed in step 3
     }
 
     // ---- 3. barycentre refinement ----------------------------------------------------------------------------
-    std::vector<double> pos((size_t)n), nxt((size_t)n);
-    {
-        std::vector<int64_t> cbase((size_t)nc, 0);
-        int64_t at = 0;
-        for (int32_t c : order_c) { cbase[(size_t)c] = at; at += cnodes[(size_t)c]; }
-        std::vector<int64_t> fill((size_t)nc, 0);
-        for (int64_t v = 0; v < n; v++) {
-            const int32_t c = comm[(size_t)v];
-            pos[(size_t)v] = (double)(cbase[(size_t)c] + fill[(size_t)c]++);
-        }
-    }
     std::vector<int32_t> perm((size_t)n);
-    for (int it = 0; it < 8; it++) {
-        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
-            for (int64_t v = lo; v < hi; v++) {
-                const int32_t b = rp[(size_t)v], e = rp[(size_t)v + 1];
-                if (e == b) { nxt[(size_t)v] = pos[(size_t)v]; continue; }
-                double s = 0.0;
-                for (int32_t k = b; k < e; k++) s += pos[(size_t)ci[(size_t)k]];
-                nxt[(size_t)v] = 0.5 * pos[(size_t)v] + 0.5 * s / (double)(e - b);
-            }
-        });
-        // re-spread to ranks so that the arrangement does not contract (ties: by node id)
+    auto respread = [&] {   // positions -> ranks, so that the arrangement does not contract (ties: by node id)
         std::iota(perm.begin(), perm.end(), 0);
         std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b2) {
             return nxt[(size_t)a] < nxt[(size_t)b2] || (nxt[(size_t)a] == nxt[(size_t)b2] && a < b2);
         });
         for (int64_t r = 0; r < n; r++) pos[(size_t)perm[(size_t)r]] = (double)r;
+    };
+    const int bsweeps = std::getenv("GNNA_REORDER_SWEEPS") ? std::atoi(std::getenv("GNNA_REORDER_SWEEPS")) : 4;
+    for (int it = 0; it < bsweeps; it++) {
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t v = lo; v < hi; v++) {
+                const int32_t b = brp[(size_t)v], e = brp[(size_t)v + 1];
+                if (e == b) { nxt[(size_t)v] = pos[(size_t)v]; continue; }
+                double s = 0.0;
+                for (int32_t k = b; k < e; k++) s += pos[(size_t)bci[(size_t)k]];
+                nxt[(size_t)v] = s / (double)(e - b);
+            }
+        });
+        respread();
     }
+    // nodes outside the backbone (hubs, nodes whose edges are all unsupported): mean position of all neighbours
+    // that are inside it
+    parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t v = lo; v < hi; v++) {
+            nxt[(size_t)v] = pos[(size_t)v];
+            if (in_backbone[(size_t)v]) continue;
+            double s = 0.0;
+            int64_t cnt = 0;
+            for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
+                if (in_backbone[(size_t)ci[(size_t)k]]) { s += pos[(size_t)ci[(size_t)k]]; cnt++; }
+            if (cnt) nxt[(size_t)v] = s / (double)cnt;
+        }
+    });
+    respread();
     for (int64_t v = 0; v < n; v++) new_id[(size_t)v] = (int32_t)pos[(size_t)v];
     return GNNA_OK;
 }

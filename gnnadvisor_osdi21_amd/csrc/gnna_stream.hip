@@ -91,6 +91,7 @@ struct SliceStats {
     unsigned long long edges;
     unsigned long long groups;     // non-empty groups
     unsigned long long span;       // sum over the edges of |column id - destination row|
+    unsigned long long near[24];   // near[k]: edges with |column id - destination row| < 256 * 2^(k / 2)
 };
 
 __global__ void __launch_bounds__(kBlock)
@@ -101,18 +102,31 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long cells[4] = {0, 0, 0, 0}, edges = 0, groups = 0, span = 0;
+    unsigned long long near_l = 0;   // lane k < 24 accumulates near[k]
     for (int64_t g = wave; g < P; g += nwaves) {
         const int beg = pp[g], end = pp[g + 1];
         const int row = p2n[g];
         int mine = 0;  // lane f < 16 accumulates the count of slice f
         for (int t = beg; t < end; t += kWave) {
             const bool valid = t + lane < end;
-            int f = -1;
+            int f = -1, bucket = 99;
             if (valid) {
                 const uint32_t id = (uint32_t)__builtin_nontemporal_load(col + t + lane);
                 f = (int)min(id / slice_rows, (uint32_t)(S - 1));
                 const int dist = (int)id - row;
-                span += (unsigned long long)(dist < 0 ? -dist : dist);
+                const unsigned ad = (unsigned)(dist < 0 ? -dist : dist);
+                span += (unsigned long long)ad;
+                if (ad < 256u) {
+                    bucket = 0;
+                } else {   // smallest k with ad < 256 * 2^(k/2): half-octave thresholds
+                    const int m = 31 - __builtin_clz(ad);
+                    bucket = 2 * (m - 8) + (ad < (((1u << m) * 181u) >> 7) ? 1 : 2);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < 24; b++) {
+                const int c = __popcll(__ballot(bucket <= b));
+                if (lane == b) near_l += (unsigned long long)c;
             }
 #pragma unroll
             for (int b = 0; b < kMaxSlices; b++) {
@@ -146,6 +160,7 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
     }
     // span was accumulated per lane: reduce over the wavefront
     for (int d = 32; d > 0; d >>= 1) span += __shfl_down(span, d);
+    if (stats && lane < 24 && near_l) atomicAdd(&stats->near[lane], near_l);
     if (stats && lane == 0) {
         if (span) atomicAdd(&stats->span, span);
         for (int i = 0; i < 4; i++)
@@ -591,6 +606,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
         stats_out->edges = (double)hit->stats.edges;
         stats_out->groups = (double)hit->stats.groups;
         stats_out->span = (double)hit->stats.span;
+        for (int i = 0; i < 24; i++) stats_out->near[i] = (double)hit->stats.near[i];
     }
     return GNNA_OK;
 }

@@ -338,6 +338,14 @@ class ShardedAggregator:
             n_in = sum(self._recv_splits[k])
             recv = buf[k * self.window_rows: k * self.window_rows + n_in]
             keep.append(send)
+            if send.is_cuda and self._comm_device().type == "cpu":
+                # debug / test path (gloo moves host memory): stage the piece through the host, synchronously
+                got = torch.empty(recv.shape, dtype=recv.dtype)
+                dist.all_to_all_single(got, send.cpu(), output_split_sizes=self._recv_splits[k],
+                                       input_split_sizes=self._send_splits[k], group=self.group)
+                recv.copy_(got)
+                works.append(None)
+                continue
             works.append(dist.all_to_all_single(recv, send, output_split_sizes=self._recv_splits[k],
                                                 input_split_sizes=self._send_splits[k], group=self.group,
                                                 async_op=True))
@@ -412,7 +420,8 @@ class ShardedAggregator:
             buf = torch.ones(self.remote_rows, dtype=degrees_local.dtype, device=degrees_local.device)
             _, works = self.exchange_halo(degrees_local.contiguous(), buf)
             for w in works:
-                w.wait()
+                if w is not None:
+                    w.wait()
             self._deg_all = buf
         elif self.world == 1 and self.chunks == 1:
             self._deg_all = degrees_local

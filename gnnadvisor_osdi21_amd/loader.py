@@ -8,9 +8,10 @@ line, or an ``.npz`` with keys ``src_li``, ``dst_li``, ``num_nodes``.
 
 What is this package's own: CSR, degrees and edge statistics come from the native host
 builders of libgnna (counting sort + per-row sort/unique instead of scipy; ``sqrt(max(deg,1))``),
-renumbering is the native reverse Cuthill-McKee of ``gnna_reorder_rcm_i32`` instead of the
-third-party Rabbit Order module (same contract: a relabelled ``[2, E]`` int32 edge list whose CSR
-and degrees are then rebuilt, dataset.py:147-172), and tensors go to ``device`` instead of an
+renumbering is the native community renumbering ``gnna_reorder_community_i32`` (label propagation +
+community chain + barycentre sweeps, multi-threaded; ``reorder_method = "rcm"`` selects the reverse
+Cuthill-McKee sweep instead) in place of the third-party Rabbit Order module (same contract: a relabelled
+``[2, E]`` int32 edge list whose CSR and degrees are then rebuilt, dataset.py:147-172), and tensors go to ``device`` instead of an
 unconditional ``.cuda()``.  ``from_edges`` / ``from_synthetic`` build datasets without files (no
 dataset ships with the reference and there is no network here).
 """
@@ -38,6 +39,7 @@ class custom_dataset(torch.nn.Module):
         self.num_classes = num_class
         self.edge_index = None
         self.reorder_flag = False
+        self.reorder_method = "community"                      # or "rcm" (reverse Cuthill-McKee)
         self.verbose_flag = verbose
         self.avg_degree = -1
         self.avg_edgeSpan = -1
@@ -129,7 +131,9 @@ class custom_dataset(torch.nn.Module):
                 print("Reorder flag is not set. Skipped...")
             return
         start = time.perf_counter()
-        new_id = _lib.reorder_rcm(self.edge_index[0], self.edge_index[1], self.num_nodes).numpy().astype(np.int64)
+        renumber = _lib.reorder_rcm if self.reorder_method == "rcm" else _lib.reorder_community
+        new_id = renumber(self.edge_index[0], self.edge_index[1], self.num_nodes).numpy().astype(np.int64)
+        self.new_id = new_id                                   # new_id[old] (kept for callers that hold per-node data)
         self.edge_index = np.stack([new_id[self.edge_index[0]], new_id[self.edge_index[1]]])
         if self.verbose_flag:
             print("# Reorder time (s): {}".format(time.perf_counter() - start))

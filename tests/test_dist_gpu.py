@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, chunks, q):
+def _worker(rank, world, port, chunks, q, exchange="allgather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,12 +33,16 @@ def _worker(rank, world, port, chunks, q):
                                                 balanced_row_splits, shard_csr)
         torch.cuda.set_device(0)
         n, e, D, ps = 5000, 400000, 64, 32
-        g = graph.powerlaw_graph(n, e, 1500, seed=5)
+        if exchange == "halo":      # low degree, id-local: few of the peer's rows are referenced at all
+            n, e = 20000, 200000
+        g = graph.powerlaw_graph(n, e, 1500, seed=5, locality=0.97 if exchange == "halo" else 0.0, window=300)
         bounds = balanced_row_splits(g.row_pointers, world)
         lo, hi = bounds[rank], bounds[rank + 1]
         rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
-        agg = ShardedAggregator(rp, ci, bounds, ps, device="cuda", pipeline_chunks=chunks)
-        assert agg.overlap and agg.chunks == chunks
+        agg = ShardedAggregator(rp, ci, bounds, ps, device="cuda", pipeline_chunks=chunks, exchange=exchange)
+        assert agg.overlap and agg.chunks == chunks and agg.exchange == exchange
+        if exchange == "halo":      # id-local graph: the halo is a small part of the peer's block
+            assert agg.bytes_received_per_step(D) < 0.5 * agg.allgather_bytes_per_step(D)
         X = torch.randn(n, D, generator=torch.Generator().manual_seed(8))
         Xl = X[lo:hi].contiguous().cuda()
         degl = g.degrees[lo:hi].contiguous().cuda()
@@ -74,18 +78,22 @@ def _worker(rank, world, port, chunks, q):
         Fr = F.cuda().requires_grad_(True)
         (r2(torch.relu(r1(Fr, info)), info) * wgt).sum().backward()
         for a, b in ((Fl.grad, Fr.grad[lo:hi]), (l1.weights.grad, r1.weights.grad), (l2.weights.grad, r2.weights.grad)):
-            ok &= bool(torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max())))
+            ok &= bool(torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())))
         q.put((rank, bool(ok), worst))
+    except Exception as exc:                                   # surface the failure instead of a queue timeout
+        import traceback
+        q.put((rank, False, traceback.format_exc()))
+        raise exc
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("chunks", [1, 3])
-def test_two_ranks_sharing_the_gpu(chunks):
+@pytest.mark.parametrize("chunks,exchange", [(1, "allgather"), (3, "allgather"), (1, "halo"), (3, "halo")])
+def test_two_ranks_sharing_the_gpu(chunks, exchange):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunks, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunks, q, exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]

@@ -431,11 +431,11 @@ def test_sliced_schedule_is_chosen_from_the_partition_itself():
     are already local (community order), one when the rows are too short to be worth slicing."""
     if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
         pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
-    D = 256
     seen = {}
-    for name, g in (("random", graph.make_config_graph("reddit-like", device="cuda", scale=0.25)),
-                    ("local", graph.make_config_graph("reddit-like", device="cuda", scale=0.25, locality=1.0)),
-                    ("sparse", graph.uniform_graph(60000, 360000, seed=5, device="cuda"))):
+    for name, D, g in (("random", 256, graph.make_config_graph("reddit-like", device="cuda", scale=0.25)),
+                       # local: every edge within +-4096 ids, a 2 MB window of 64-float rows
+                       ("local", 64, graph.make_config_graph("reddit-like", device="cuda", scale=0.5, locality=1.0)),
+                       ("sparse", 256, graph.uniform_graph(60000, 360000, seed=5, device="cuda"))):
         pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
         ppd, p2nd = pp.cuda(), p2n.cuda()
         X = torch.randn(g.num_nodes, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
