@@ -696,11 +696,10 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             mode = MODE_GIN;  // unweighted gather + per-row factor at the flush
         }
     }
-    // Streaming kernel (gnna_stream.hip): unweighted gathers of rows of >= 4 floats that are not part of a
-    // windowed sequence.  Its sliced schedule is stateless and a single launch; the number of phases is
+    // Streaming kernel (gnna_stream.hip): rows of >= 4 floats that are not part of a windowed sequence.  Its sliced schedule is stateless and a single launch; the number of phases is
     // tune.column_phases when set (process-wide or measured per graph), otherwise chosen from the slice
     // statistics of the partition (first sight of a graph: one counting pass + one stream synchronisation).
-    if (vec == 4 && mode != MODE_GCN && num_windows == 1 && tune.stream_kernel != 2) {
+    if (vec == 4 && num_windows == 1 && tune.stream_kernel != 2) {
         int B = 1;
         const uint8_t *cnt = nullptr;
         const int S = 16;
@@ -721,7 +720,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         t_last_phases = B;
         StreamLaunch a;
         a.mode = mode; a.X = p.X; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node; a.Y = out;
-        a.cnt = cnt; a.row_scale = p.row_scale; a.flag = flag; a.seq = seq; a.trust = p.trust; a.P = num_parts;
+        a.cnt = cnt; a.row_scale = p.row_scale; a.deg_row = p.deg_row; a.deg_col = p.deg_col; a.flag = flag; a.seq = seq; a.trust = p.trust; a.P = num_parts;
         // a work item is (chunk, slice): keep its edge count about what `groups_per_chunk` groups are in one pass
         a.D = dim; a.ldx = ldx; a.G = std::min(64, tune.groups_per_chunk * B); a.U = tune.loads_in_flight; a.S = S; a.B = B;
         t_last_launches = 1;

@@ -63,10 +63,11 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
 void drop_slice_plans();
 
 struct StreamLaunch {
-    int mode;                 // MODE_SAG or MODE_GIN (the pre-scaled GCN form arrives as GIN + row_scale)
+    int mode;                 // MODE_SAG, MODE_GIN (also the pre-scaled GCN form: GIN + row_scale) or MODE_GCN (per-edge)
     const float *X; const int32_t *col; const int32_t *pp; const int32_t *p2n; float *Y;
     const uint8_t *cnt;       // slice counts or nullptr (single phase)
     const float *row_scale;
+    const float *deg_row; const float *deg_col;   // MODE_GCN
     const int32_t *flag; int32_t seq; int32_t trust;
     int64_t P;
     int D, ldx, G, U, S, B;

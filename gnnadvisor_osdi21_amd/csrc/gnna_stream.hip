@@ -63,6 +63,8 @@ struct StreamParams {
     float *Y;
     const uint8_t *cnt;        // [S-1][P] cumulative slice counts, or nullptr: one phase takes everything
     const float *row_scale;    // MODE_GIN: optional per-destination-row factor on top of eps
+    const float *deg_row;      // MODE_GCN (per-edge coefficients): degree norm per destination row ...
+    const float *deg_col;      // ... and per source row
     const int32_t *flag;       // *flag == seq  <=>  partition is NOT canonical
     int64_t P;
     int64_t num_chunks;
@@ -270,6 +272,8 @@ stream_kernel(const StreamParams p)
     static_assert(RL % U == 0, "a round is a whole number of batches");
     // per wavefront: the round's list slots as row offsets into X (bytes; row index when X > 4 GiB)
     __shared__ uint32_t s_off[kWavesPerBlock][RL * RPI];
+    // MODE_GCN: the per-edge coefficient round(deg_i * deg_j) of every list slot (reference .cu:355,389)
+    __shared__ float s_cf[kWavesPerBlock][MODE == MODE_GCN ? RL * RPI : 1];
     // folded rows waiting to be written: the float atomics of the sliced schedule are memory-side round
     // trips that sit in the same in-order vmcnt queue as the row loads, so a flush in the middle of the
     // stream would stall the ring until it retires.  Rows are parked here (2 KiB per wavefront) and
@@ -287,6 +291,7 @@ stream_kernel(const StreamParams p)
     const char *xbase = reinterpret_cast<const char *>(p.X);
     const uint32_t row_bytes32 = (uint32_t)p.ldx * 4u;
     uint32_t *offs = s_off[wib];
+    float *cfs = s_cf[wib];
     float *pend = s_pend[wib];
     int pend_meta = 0;      // lane q: (row << 2 | atomic) of parked row q
     int npend = 0;
@@ -440,6 +445,11 @@ stream_kernel(const StreamParams p)
                         if (s > 0 && s < v_j) o[s] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + s);
                     }
                 }
+                if constexpr (MODE == MODE_GCN) {
+                    const float row_deg = v_j > 0 ? p.deg_row[k_meta >> 2] : 0.f;
+#pragma unroll
+                    for (int s = 0; s < RPI; s++) cfs[lane * RPI + s] = s < v_j ? row_deg * p.deg_col[o[s]] : 0.f;
+                }
 #pragma unroll
                 for (int s = 0; s < RPI; s++) {
                     if constexpr (!WIDE) o[s] *= row_bytes32;
@@ -470,7 +480,14 @@ stream_kernel(const StreamParams p)
                             const int vj = __builtin_amdgcn_readlane(v_j, j);
                             if (slot >= vj) v[u] = vzero<4>();
                         }
-                        acc += v[u];
+                        if constexpr (MODE == MODE_GCN) {
+                            // the reference rounds coef * x and the accumulation separately (__fmaf_rn(c, x, 0) then +=,
+                            // .cu:405); this file is built with -ffp-contract=off
+                            const VT tmp = v[u] * cfs[j * RPI + slot];
+                            acc += tmp;
+                        } else {
+                            acc += v[u];
+                        }
                         if (((FL >> j) & 1ull) && !p.dbg_noflush) {
                             const int meta = __builtin_amdgcn_readlane(k_meta, j);
                             float scale = p.eps;
@@ -560,6 +577,10 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
         if (!pl.cnt) { if (victim->cnt) victim = &pl; }
         else if (victim->cnt && pl.stamp < victim->stamp) victim = &pl;
     }
+    if (hit && want_stats && !hit->have_stats) {   // built without statistics (forced phase count): count again
+        victim = hit;
+        hit = nullptr;
+    }
     if (!hit) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
@@ -625,6 +646,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
 {
     StreamParams p;
     p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
+    p.deg_row = a.deg_row; p.deg_col = a.deg_col;
     p.flag = a.flag; p.P = a.P; p.seq = a.seq; p.trust = a.trust; p.D = a.D; p.ldx = a.ldx;
     p.G = std::max(1, std::min(a.G, kWave));
     p.num_chunks = (a.P + p.G - 1) / p.G;
@@ -641,7 +663,8 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     int lpr = 4;
     const int pieces = (a.D + 3) / 4;
     while (lpr < 64 && lpr < pieces) lpr <<= 1;
-    StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U);
+    StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U)
+                     : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));

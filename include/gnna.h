@@ -28,7 +28,11 @@
  *   - inputs are borrowed and never written; `out` is fully overwritten (the reference
  *     returns a fresh zeros_like + accumulate, .cu:121).
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls only
- *     enqueue work; they never synchronise the device.
+ *     enqueue work.  One exception: the first aggregation on a partition the library has not
+ *     seen yet (and that is large enough to be worth slicing) runs a counting pass over the
+ *     column ids and synchronises `stream` once to read its statistics; never while the stream
+ *     is being captured.  Library scratch is allocated on first use and never grown during capture
+ *     (GNNA_ERR_UNSUPPORTED instead): warm a path up once before capturing it.
  *   - return value: GNNA_OK or a negative gnna_status; gnna_last_error() gives the
  *     message for the calling thread.  (The reference printf()s and exit(-1)s on launch
  *     failure, .cu:177-181; this library reports instead.)
@@ -191,9 +195,10 @@ typedef struct gnna_tuning {
                              0: one wavefront per work item (hardware scheduled)          */
     int xcd_remap;        /* 1: consecutive work items stay on one XCD's L2; 0: off       */
     int trust_canonical;  /* 1: skip the partition validation pass (build_part output)    */
-    int column_phases;    /* 1: single pass; 2..16: gather X in that many source-id ranges, one
-                             launch each (cache-resident slices); 0: automatic from the size
-                             of X and the two graph hints below (single pass without hints) */
+    int column_phases;    /* 1: single pass; 2..16: gather X in that many source-id ranges (cache-resident
+                             slices; the streaming kernel runs them as one launch, the chunk-walk kernel one
+                             launch each); 0: automatic -- streaming kernel: from the library's own statistics of
+                             the partition; chunk-walk kernel: from the size of X and the two hints below */
     int avg_degree;       /* hint: average edges per destination row (0 = unknown)           */
     int nonlocal_ids;     /* hint: 1 = source ids of a row are scattered over the whole id
                              range (no community ordering), 0 = unknown / locality-ordered  */

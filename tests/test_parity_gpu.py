@@ -453,6 +453,33 @@ def test_sliced_schedule_is_chosen_from_the_partition_itself():
     assert seen["random"] >= 4 and seen["local"] == 1 and seen["sparse"] == 1, seen
 
 
+def test_stale_slice_plan_costs_locality_not_correctness():
+    """The library caches the slice counts of a partition by the device addresses of its arrays.  Overwriting the
+    column ids IN PLACE (same addresses, same partition, different graph) leaves a stale plan behind: the sliced
+    schedule must still consume every edge exactly once (the stored counts are prefixes, so the phases partition
+    each group's positions whatever they hold) -- also with unsorted ids."""
+    g, X, pp, p2n = make_case(3000, 240000, 64, 16, seed=77, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    try:
+        _lib.set_tuning(column_phases=8)
+        y0 = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+        assert _lib.last_num_phases() == 8
+        assert_close_f64(y0.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                         what="fresh plan")
+        gen = torch.Generator().manual_seed(5)
+        for what, new_ci in (("other sorted ids", torch.sort(torch.randint(0, g.num_nodes, (g.nnz,), generator=gen)).values),
+                             ("unsorted ids", torch.randint(0, g.num_nodes, (g.nnz,), generator=gen)),
+                             ("all ids in the last slice", torch.full((g.nnz,), g.num_nodes - 1))):
+            ci.copy_(new_ci.to(torch.int32))                       # in place: the cached plan now describes another graph
+            y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+            assert _lib.last_num_phases() == 8
+            ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), new_ci.to(torch.int32).numpy())
+            scale = oracle.csr_f64(0, X.abs().numpy(), g.row_pointers.numpy(), new_ci.to(torch.int32).numpy())
+            assert_close_f64(y.cpu().numpy(), ref, what=what, scale=scale)
+    finally:
+        _lib.reset_tuning()
+
+
 def test_chunk_walk_phase_selection_follows_the_hints():
     """column_phases = 0 on the chunk-walk kernel (stream_kernel = 2; also what the per-edge GCN form and the
     source windows use): phases only with the Decider's hints (scattered ids, high degree, big X)."""
