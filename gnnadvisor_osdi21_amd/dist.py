@@ -176,10 +176,20 @@ class ShardedAggregator:
             self.overlap = True                                  # the halo buffer holds remote rows only
         K = int(pipeline_chunks)
         if K <= 0:
-            # every rank must arrive at the same K (it fixes the layout and the number of collectives
-            # per step), so the decision is taken on the largest shard
-            remote_edges = self._agree_max(column_index.numel() * (self.world - 1) // max(1, self.world))
-            K = 4 if (self.world > 1 and remote_edges >= (16 << 20)) else 1
+            # Pipelining the exchange pays when the exchange is long next to the aggregation it feeds: the windowed
+            # aggregation hides all but the last piece's work behind the wire, but it runs on the chunk-walk kernel,
+            # which is ~20 % slower than the one-call streaming kernel on the remote part (one-GPU emulation of an
+            # 8-rank Reddit-sized shard: 2.85 vs 2.29 ms).  Both times scale with the feature width, so the ratio is
+            # a graph property: received rows per remote edge.  xGMI ingress ~0.6 TB/s against ~12 TB/s of gather
+            # rate puts the break-even near 1 received row per 40 remote edges (Reddit-like shards: 1 per 65 ->
+            # one piece; papers100M-like: 1 per 1.8 -> four pieces).
+            # Every rank must arrive at the same K (it fixes the layout and the number of collectives per step), so
+            # the decision is taken collectively on the most exchange-heavy and the largest shard.
+            remote_edges = column_index.numel() * (self.world - 1) // max(1, self.world)
+            received_rows = (self.world - 1) * self.rows_per_rank
+            heaviness = self._agree_max(int(1000.0 * received_rows / max(1, remote_edges)))
+            largest = self._agree_max(remote_edges)
+            K = 4 if (self.world > 1 and largest >= (16 << 20) and heaviness > 25) else 1
         self.chunks = max(1, min(K, 16, self.rows_per_rank)) if self.overlap else 1
         assert self._agree_max(self.chunks) == self.chunks == -self._agree_max(-self.chunks), \
             "ranks disagree on the number of exchange pieces"
