@@ -666,7 +666,9 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     // applied at the flush; (b) a padded row stride for widths whose rows straddle 128-byte lines or
     // are not 16-byte aligned (the class counts of GCN output layers: 41, 47, 22, 7 ...).
     const int64_t est_edges = num_parts * (int64_t)(tune.avg_degree > 0 ? std::min(partSize, tune.avg_degree) : partSize / 2 + 1);
-    const bool hot_rows = est_edges >= 32 * num_in_rows;
+    // (automatic staging only while the copy stays small next to the 288 GB of HBM: a staged copy of a multi-GB
+    // feature matrix would silently double the resident set -- the per-edge form runs on the same kernel)
+    const bool hot_rows = est_edges >= 32 * num_in_rows && (size_t)num_in_rows * (size_t)dim * sizeof(float) <= ((size_t)1 << 30);
     const bool prescale = mode == MODE_GCN && (tune.gcn_prescale == 1 || (tune.gcn_prescale == 0 && hot_rows));
     int ldx = dim;
     if (tune.pad_rows == 1 || (tune.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);

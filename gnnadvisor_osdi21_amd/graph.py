@@ -91,14 +91,15 @@ def _powerlaw_weights(num_nodes: int, avg_degree: float, max_degree: float, expo
 
 def powerlaw_graph(num_nodes: int, num_edges: int, max_degree: int, *, exponent: float = 2.1,
                    locality: float = 0.0, window: int = 4096, seed: int = 0,
-                   device="cpu") -> CSRGraph:
+                   device="cpu", wrap: bool = True) -> CSRGraph:
     """Seeded symmetric, self-loop-free power-law (Chung-Lu) graph with ~num_edges CSR entries.
 
     ``num_edges // 2`` undirected pairs are drawn with endpoint probability proportional
     to a clipped power-law expected-degree sequence; node ids are randomly permuted
     ("natural" order: hubs scattered).  ``locality`` in [0, 1] redraws that fraction of
     second endpoints uniformly within ``window`` ids of the first endpoint (a
-    community-ordered variant, as after Rabbit reordering).  Pairs are symmetrised, then
+    community-ordered variant, as after Rabbit reordering); ``wrap=False`` makes the id space a
+    line instead of a ring.  Pairs are symmetrised, then
     deduplicated by ``csr_from_edges`` exactly like the reference's loader.
     """
     dev = torch.device(device)
@@ -119,7 +120,10 @@ def powerlaw_graph(num_nodes: int, num_edges: int, max_degree: int, *, exponent:
     if locality > 0.0:
         local = torch.rand(m, generator=g, device=dev) < locality
         off = torch.randint(-window, window + 1, (m,), generator=g, device=dev)
-        v = torch.where(local, (u + off).remainder(num_nodes), v)
+        near = (u + off).remainder(num_nodes) if wrap else (u + off).abs()
+        if not wrap:                                   # a line of neighbourhoods instead of a ring: reflect at the ends
+            near = torch.where(near >= num_nodes, 2 * (num_nodes - 1) - near, near).clamp_(0, num_nodes - 1)
+        v = torch.where(local, near, v)
     keep = u != v
     u, v = u[keep], v[keep]
     src = torch.cat([u, v])
@@ -182,10 +186,10 @@ CONFIGS = {
 }
 
 
-def make_config_graph(name: str, device="cpu", locality: float = 0.0, scale: float = 1.0) -> CSRGraph:
+def make_config_graph(name: str, device="cpu", locality: float = 0.0, scale: float = 1.0, wrap: bool = True) -> CSRGraph:
     c = CONFIGS[name]
     n = max(2, int(c["num_nodes"] * scale))
     # symmetrisation + dedup lose a few percent of the draws on hub-hub pairs; the per-config
     # oversampling factor (calibrated on the full-size graph) brings nnz back to the dataset card's
     e = int(c["num_edges"] * scale * c.get("oversample", 1.0))
-    return powerlaw_graph(n, e, min(c["max_degree"], n - 1), seed=c["seed"], locality=locality, device=device)
+    return powerlaw_graph(n, e, min(c["max_degree"], n - 1), seed=c["seed"], locality=locality, device=device, wrap=wrap)

@@ -8,7 +8,9 @@ from gnnadvisor_osdi21_amd import _lib, graph
 dev = torch.device("cuda:0")
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-g = graph.make_config_graph("reddit-like", device=dev, locality=0.9, scale=scale)
+wrap = (sys.argv[3] if len(sys.argv) > 3 else "ring") == "ring"
+g = graph.make_config_graph("reddit-like", device=dev, locality=0.9, scale=scale, wrap=wrap)
+print(json.dumps({"hidden_topology": "ring" if wrap else "line"}))
 n = g.num_nodes
 rows = torch.repeat_interleave(torch.arange(n, device=dev), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
 cols = g.column_index.long()
