@@ -18,9 +18,9 @@ DIMS = [1, 3, 4, 6, 16, 31, 64, 100, 129, 256, 257, 300]
 
 
 def _rand_tuning(rng):
-    _lib.set_tuning(int(rng.integers(1, 64)), int(rng.choice([4, 8, 16])), int(rng.choice([0, 0, 2])),
-                    int(rng.integers(0, 2)), 0, int(rng.choice([1, 1, 2, 3, 7])), gcn_prescale=int(rng.choice([0, 1, 2])),
-                    pad_rows=int(rng.choice([0, 1, 2])))
+    _lib.set_tuning(int(rng.integers(1, 65)), int(rng.choice([4, 8, 16])), int(rng.choice([0, 0, 2])),
+                    int(rng.integers(0, 2)), 0, int(rng.choice([1, 1, 2, 3, 7, 16])), gcn_prescale=int(rng.choice([0, 1, 2])),
+                    pad_rows=int(rng.choice([0, 1, 2])), stream_kernel=int(rng.choice([0, 0, 2])))
 
 
 def test_rect_accumulate_random():
@@ -94,22 +94,29 @@ def test_module_forward_backward_random():
             a = [t.cuda() for t in (g.row_pointers, g.column_index, g.degrees, pp, p2n)]
             ci, deg, ppn, p2nn = g.column_index.numpy(), g.degrees.numpy(), pp.numpy(), p2n.numpy()
             _rand_tuning(rng)
+            # bound for every output: 1e-4 * max(1, sum of |terms|), everything evaluated in fp64 from the formulas
+            rp = g.row_pointers.numpy()
+            X64, W64, dY64 = X.double().numpy(), W.double().numpy(), dY.double().numpy()
+            f32 = lambda a_: np.ascontiguousarray(a_, dtype=np.float32)
+            gcn = lambda M: oracle.csr_f64(1, f32(M), rp, ci, deg)
+            gin = lambda M: oracle.csr_f64(2, f32(M), rp, ci, None, 0.5)
+            tag = f"case {k}: n={n} e={e} fin={fin} fout={fout} ps={ps} {_lib.get_tuning()}"
             y = GNNA.forward(X.cuda(), W.cuda(), *a, ps, 32, 4)[0].cpu().numpy()
-            ry = oracle.np_forward(X.numpy(), W.numpy(), ci, deg, ppn, p2nn)
-            np.testing.assert_allclose(y, ry, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ry).max()), err_msg=f"fwd case {k}")
+            assert_close_f64(y, gcn(X64 @ W64), scale=gcn(np.abs(X64) @ np.abs(W64)), rtol=2e-4, what="forward " + tag)
             dX, dW = GNNA.backward(dY.cuda(), X.cuda(), W.cuda(), *a, ps, 32, 4)
-            rdX, rdW = oracle.np_backward(dY.numpy(), X.numpy(), W.numpy(), ci, deg, ppn, p2nn)
-            np.testing.assert_allclose(dX.cpu().numpy(), rdX, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdX).max()))
-            np.testing.assert_allclose(dW.cpu().numpy(), rdW, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdW).max()))
+            G64, Ga = gcn(dY64), gcn(np.abs(dY64))
+            assert_close_f64(dX.cpu().numpy(), G64 @ W64.T, scale=Ga @ np.abs(W64).T, what="d_input " + tag)
+            assert_close_f64(dW.cpu().numpy(), X64.T @ G64, scale=np.abs(X64).T @ Ga, what="d_weight " + tag)
             ag = [a[0], a[1], 0.5, a[3], a[4]]
             yo, t = GNNA.forward_gin(X.cuda(), W.cuda(), *ag, ps, 32, 4)
-            ryo, rt = oracle.np_forward_gin(X.numpy(), W.numpy(), ci, 0.5, ppn, p2nn)
-            np.testing.assert_allclose(t.cpu().numpy(), rt, rtol=1e-4, atol=1e-4 * max(1.0, np.abs(rt).max()))
-            np.testing.assert_allclose(yo.cpu().numpy(), ryo, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(ryo).max()))
+            T64, Ta = gin(X64), gin(np.abs(X64))
+            assert_close_f64(t.cpu().numpy(), T64, scale=Ta, what="gin aggregated " + tag)
+            assert_close_f64(yo.cpu().numpy(), T64 @ W64, scale=Ta @ np.abs(W64), what="gin output " + tag)
             dXg, dWg = GNNA.backward_gin(dY.cuda(), t, W.cuda(), *ag, ps, 32, 4)
-            rdXg, rdWg = oracle.np_backward_gin(dY.numpy(), rt, W.numpy(), ci, 0.5, ppn, p2nn)
-            np.testing.assert_allclose(dXg.cpu().numpy(), rdXg, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdXg).max()))
-            np.testing.assert_allclose(dWg.cpu().numpy(), rdWg, rtol=2e-3, atol=2e-3 * max(1.0, np.abs(rdWg).max()))
+            t64 = t.double().cpu().numpy()
+            assert_close_f64(dXg.cpu().numpy(), gin(dY64 @ W64.T), scale=gin(np.abs(dY64) @ np.abs(W64).T), rtol=2e-4,
+                             what="gin d_input " + tag)
+            assert_close_f64(dWg.cpu().numpy(), t64.T @ dY64, scale=np.abs(t64).T @ np.abs(dY64), what="gin d_weight " + tag)
     finally:
         _lib.reset_tuning()
 

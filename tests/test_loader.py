@@ -87,6 +87,28 @@ def test_community_reorder_recovers_locality_where_a_bfs_sweep_cannot():
     assert _lib.reorder_community(np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32), 3).tolist() == [0, 1, 2]
 
 
+def test_community_reorder_groups_the_blocks_of_a_block_model():
+    """Planted communities (stochastic block model: 90 % of the edges inside blocks of ~500 nodes), ids scrambled:
+    after gnna_reorder_community_i32 the nodes of a block are contiguous -- most edges end within one block size."""
+    rng = np.random.default_rng(4)
+    n, blocks, m = 16000, 32, 400000
+    block = rng.permutation(n) % blocks                      # scrambled ids: block membership is arbitrary in id space
+    members = [np.flatnonzero(block == b) for b in range(blocks)]
+    u = rng.integers(0, n, m)
+    inside = rng.random(m) < 0.9
+    v = np.where(inside, [members[block[x]][rng.integers(0, len(members[block[x]]))] for x in u], rng.integers(0, n, m))
+    src, dst = np.concatenate([u, v]), np.concatenate([v, u])
+    new = _lib.reorder_community(src, dst, n).numpy().astype(np.int64)
+    assert sorted(new.tolist()) == list(range(n))
+    size = n // blocks
+    near_before = np.mean(np.abs(src - dst) <= size)
+    near_after = np.mean(np.abs(new[src] - new[dst]) <= size)
+    assert near_before < 0.1 and near_after > 0.8, (near_before, near_after)
+    # every block occupies (almost) one contiguous range of new ids
+    spans = [np.percentile(new[mem], 95) - np.percentile(new[mem], 5) for mem in members]
+    assert np.median(spans) < 1.5 * size, np.median(spans)
+
+
 def test_dataset_formats_and_fields(tmp_path):
     src, dst = _edges(5, 60, 500)
     np.savez(tmp_path / "g.npz", src_li=src, dst_li=dst, num_nodes=60)
