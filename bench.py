@@ -621,6 +621,18 @@ def run_sharded(args, result_fd, world, rank, local_rank):
     calls_per_step = prof["calls"] / max(1, args.steps)
     kern_ms = prof["main_ms"] * calls_per_step
 
+    # the two halves of a step on their own (same buffers, after the timed loop): exchange only, kernels only
+    def timed_ms(fn, n=5):
+        fn()
+        sync_all()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync_all()
+        return (time.perf_counter() - t) * 1e3 / n
+    exchange_ms = timed_ms(lambda: agg.exchange_only(X))
+    aggregate_ms = timed_ms(lambda: agg.aggregate_only(X, out=out))
+
     # verification of the timed configuration: X = ones everywhere -> exact row nnz on every rank
     ones = torch.ones_like(X)
     y1 = agg.sag(ones)
@@ -629,7 +641,7 @@ def run_sharded(args, result_fd, world, rank, local_rank):
     del ones, y1
 
     stats = torch.tensor([elapsed, kern_ms, float(agg.bytes_received_per_step(D)),
-                          float(agg.allgather_bytes_per_step(D))], dtype=torch.float64, device=dev)
+                          float(agg.allgather_bytes_per_step(D)), exchange_ms, aggregate_ms], dtype=torch.float64, device=dev)
     sums = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
     cpu = args.backend != "nccl"
     if cpu:
@@ -662,6 +674,8 @@ def run_sharded(args, result_fd, world, rank, local_rank):
                        "bytes_received_per_rank_per_step": float(stats[2]),
                        "allgather_bytes_per_rank_per_step": float(stats[3]),
                        "exchange_volume_vs_allgather": float(stats[2]) / float(stats[3]) if float(stats[3]) else None,
+                       "exchange_only_ms": float(stats[4]), "aggregate_only_ms": float(stats[5]),
+                       "exchange_GBs_per_rank": float(stats[2]) / (float(stats[4]) * 1e-3) / 1e9 if float(stats[4]) > 0 else None,
                        "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
                        "calibrated_phases": calibrated, "tuning": _lib.get_tuning()},
             "roofline": {"bound": "l2-fabric", "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -496,6 +496,40 @@ class ShardedAggregator:
                                     windows=(self.chunks, k, k + 1) if self.chunks > 1 else None)
         return out
 
+    # ---- the two halves of a step on their own (bench.py reports them beside the overlapped step) ----------------
+    def exchange_only(self, X_local: torch.Tensor) -> None:
+        """The source-feature exchange of one aggregation, waited for, without any aggregation."""
+        if self.world == 1:
+            return
+        if self.exchange == "halo":
+            _, works = self.exchange_halo(X_local.contiguous())
+        elif self.chunks > 1:
+            _, works = self.gather_feature_chunks(X_local)
+        else:
+            _, work = self.gather_features(X_local, async_op=True)
+            works = [work]
+        for w in works:
+            if w is not None:
+                w.wait()
+
+    def aggregate_only(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The kernels of one (sum) aggregation on the buffers as the last exchange left them: no collective."""
+        if not self.overlap:
+            X_all = X_local if self.world == 1 else self._gather_buf
+            return self.aggregate_fn(0, X_all, self.column_index, self.part_pointers, self.part2Node, self.n_local,
+                                     self.partSize, None, None, 1.0, out)
+        X_all = self._halo_buf if self.exchange == "halo" else (self._gather_buf if self.world > 1 else
+                                                                (self._pad_buf if self._pad_buf is not None else X_local))
+        ci_l, pp_l, p2n_l = self.local_part
+        out = self.aggregate_fn(0, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize, None, None, 1.0, out)
+        ci_r, pp_r, p2n_r = self.remote_part
+        if X_all is None or not ci_r.numel():
+            return out
+        for k in range(self.chunks):
+            out = self.aggregate_fn(0, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize, None, None, 1.0, out,
+                                    accumulate=True, windows=(self.chunks, k, k + 1) if self.chunks > 1 else None)
+        return out
+
     def calibrate(self, dims, reps: int = 3) -> dict:
         """Measured phase counts for the parts of this shard (no collective involved: every rank tunes its
         own kernels on random features).  Local part and, without pipelining, the remote / whole part go
