@@ -13,11 +13,12 @@
 //      small world -- and defeat any breadth-first ordering -- are in none.  Hubs (degree > 16 x average)
 //      are left out of the backbone; they are adjacent to everything.
 //   2. coarse order: breadth-first discovery order over the backbone, component by component (largest
-//      first), started at a peripheral node of the component (the last node of a first sweep).
-//   3. fine order: a few barycentre sweeps over the backbone (position <- mean position of the
-//      neighbours, parallel Jacobi, re-spread to ranks after every sweep) pull every node to the middle of
-//      its own neighbourhood; nodes without backbone edges are then put at the mean position of all their
-//      neighbours.  The final id is the rank of the refined position.
+//      first), started at a peripheral node of the component (the last node of a first sweep); a walk that
+//      advances on two fronts (a ring of neighbourhoods) is unfolded into arm - core - arm.
+//   3. fine order: a few median sweeps over the backbone (position <- median position of the neighbours,
+//      parallel Jacobi, re-spread to ranks after every sweep) pull every node to the middle of its own
+//      neighbourhood without being dragged by a stray long-range neighbour; nodes without backbone edges
+//      are then put at the median position of all their neighbours.  The final id is the rank of the refined position.
 //
 // Threads: std::thread over contiguous node ranges; the result does not depend on the thread count.
 #include <algorithm>
@@ -151,13 +152,15 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         // it in many places, so the odd long-range edge that survived step 1 does not open a second front far away.
         const int theta = avg_deg < 32 ? 1 : 3;
         std::vector<int32_t> hits((size_t)n, 0);
+        std::vector<int32_t> depth((size_t)n, 0);
         auto bfs = [&](int32_t seed, int32_t tag, std::vector<int32_t> &out) {   // nodes of comp `tag` in discovery order
             out.clear();
             out.push_back(seed);
             comp[(size_t)seed] = tag;
+            depth[(size_t)seed] = 0;
             for (int32_t k = brp[(size_t)seed]; k < brp[(size_t)seed + 1]; k++) {
                 const int32_t u = bci[(size_t)k];
-                if (comp[(size_t)u] != tag) { comp[(size_t)u] = tag; out.push_back(u); }
+                if (comp[(size_t)u] != tag) { comp[(size_t)u] = tag; depth[(size_t)u] = 0; out.push_back(u); }
             }
             for (size_t head = 0; head < out.size(); head++) {
                 const int32_t v = out[head];
@@ -165,8 +168,85 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                     const int32_t u = bci[(size_t)k];
                     if (comp[(size_t)u] == tag) continue;
                     if (hits[(size_t)u] < 0 || hits[(size_t)u] / 65536 != tag) hits[(size_t)u] = tag * 65536;   // counter of this walk
-                    if ((++hits[(size_t)u] & 65535) >= theta) { comp[(size_t)u] = tag; out.push_back(u); }
+                    if ((++hits[(size_t)u] & 65535) >= theta) {
+                        comp[(size_t)u] = tag;
+                        depth[(size_t)u] = depth[(size_t)v] + 1;
+                        out.push_back(u);
+                    }
                 }
+            }
+        };
+        // A walk that starts inside a ring (or in the middle of a long strip) advances on two fronts, and its
+        // discovery order interleaves the two arms -- the ring comes out folded.  If, a few levels in, the level
+        // set falls into two backbone-connected parts of comparable size, the nodes beyond are told apart by
+        // which part they descend from and the order becomes: arm B reversed, the core, arm A.
+        std::vector<int32_t> arm((size_t)n, 0), stack;
+        auto unfold = [&](std::vector<int32_t> &w) {
+            if (w.size() < 4096) return;
+            const int32_t maxd = depth[(size_t)w.back()];
+            size_t lo = 0;
+            for (int32_t L = 1; L <= std::min(maxd / 2, 16); L++) {
+                while (lo < w.size() && depth[(size_t)w[lo]] < L) lo++;
+                size_t hi = lo;
+                while (hi < w.size() && depth[(size_t)w[hi]] == L) hi++;
+                if (hi - lo < 64) continue;
+                // connected parts of level L (arm = -1 - part while exploring)
+                for (size_t i = lo; i < hi; i++) arm[(size_t)w[i]] = -1;
+                std::vector<std::pair<int64_t, int32_t>> parts;   // (size, id)
+                int32_t np = 0;
+                for (size_t i = lo; i < hi; i++) {
+                    if (arm[(size_t)w[i]] != -1) continue;
+                    const int32_t id = -2 - np;
+                    int64_t sz = 0;
+                    stack.assign(1, w[i]);
+                    arm[(size_t)w[i]] = id;
+                    while (!stack.empty()) {
+                        const int32_t v = stack.back();
+                        stack.pop_back();
+                        sz++;
+                        for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                            const int32_t u = bci[(size_t)k];
+                            if (arm[(size_t)u] == -1 && depth[(size_t)u] == L) { arm[(size_t)u] = id; stack.push_back(u); }
+                        }
+                    }
+                    parts.emplace_back(sz, id);
+                    np++;
+                }
+                std::sort(parts.rbegin(), parts.rend());
+                const bool split = parts.size() >= 2 && 4 * parts[1].first >= parts[0].first &&
+                                   5 * (parts[0].first + parts[1].first) >= 4 * (int64_t)(hi - lo);
+                if (!split) {
+                    for (size_t i = lo; i < hi; i++) arm[(size_t)w[i]] = 0;
+                    continue;
+                }
+                // arms: 1 = descends from the largest part, 2 = from the second; earlier levels are the core (0)
+                for (size_t i = 0; i < lo; i++) arm[(size_t)w[i]] = 0;
+                for (size_t i = lo; i < w.size(); i++) {
+                    const int32_t v = w[i];
+                    int32_t a = 0;
+                    if (i < hi) a = arm[(size_t)v] == parts[0].second ? 1 : (arm[(size_t)v] == parts[1].second ? 2 : 0);
+                    if (a == 0) {
+                        int64_t c1 = 0, c2 = 0;
+                        for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                            const int32_t u = bci[(size_t)k];
+                            if (depth[(size_t)u] <= depth[(size_t)v] && comp[(size_t)u] == comp[(size_t)v]) {
+                                c1 += arm[(size_t)u] == 1;
+                                c2 += arm[(size_t)u] == 2;
+                            }
+                        }
+                        a = c2 > c1 ? 2 : 1;
+                    }
+                    arm[(size_t)v] = a;
+                }
+                std::vector<int32_t> out;
+                out.reserve(w.size());
+                for (size_t i = w.size(); i-- > lo;)
+                    if (arm[(size_t)w[i]] == 2) out.push_back(w[i]);
+                for (size_t i = 0; i < lo; i++) out.push_back(w[i]);
+                for (size_t i = lo; i < w.size(); i++)
+                    if (arm[(size_t)w[i]] == 1) out.push_back(w[i]);
+                w.swap(out);
+                return;
             }
         };
         // components by a first sweep (tags 0, 2, 4, ...), then re-walked from their last-discovered node
@@ -185,6 +265,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         for (auto &c : comps) {
             const int32_t seed = c.second;
             bfs(seed, comp[(size_t)seed] + 1, walk);
+            unfold(walk);
             for (int32_t v : walk) { pos[(size_t)v] = (double)at++; in_backbone[(size_t)v] = 1; }
         }
         for (int64_t v = 0; v < n; v++)
@@ -203,12 +284,15 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     const int bsweeps = std::getenv("GNNA_REORDER_SWEEPS") ? std::atoi(std::getenv("GNNA_REORDER_SWEEPS")) : 4;
     for (int it = 0; it < bsweeps; it++) {
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            std::vector<double> nbp;
             for (int64_t v = lo; v < hi; v++) {
                 const int32_t b = brp[(size_t)v], e = brp[(size_t)v + 1];
                 if (e == b) { nxt[(size_t)v] = pos[(size_t)v]; continue; }
-                double s = 0.0;
-                for (int32_t k = b; k < e; k++) s += pos[(size_t)bci[(size_t)k]];
-                nxt[(size_t)v] = s / (double)(e - b);
+                // the MEDIAN position of the neighbours: a stray long-range neighbour must not drag the node away
+                nbp.resize((size_t)(e - b));
+                for (int32_t k = b; k < e; k++) nbp[(size_t)(k - b)] = pos[(size_t)bci[(size_t)k]];
+                std::nth_element(nbp.begin(), nbp.begin() + (e - b) / 2, nbp.end());
+                nxt[(size_t)v] = nbp[(size_t)((e - b) / 2)];
             }
         });
         respread();
@@ -219,11 +303,13 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         for (int64_t v = lo; v < hi; v++) {
             nxt[(size_t)v] = pos[(size_t)v];
             if (in_backbone[(size_t)v]) continue;
-            double s = 0.0;
-            int64_t cnt = 0;
+            std::vector<double> nbp;
             for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
-                if (in_backbone[(size_t)ci[(size_t)k]]) { s += pos[(size_t)ci[(size_t)k]]; cnt++; }
-            if (cnt) nxt[(size_t)v] = s / (double)cnt;
+                if (in_backbone[(size_t)ci[(size_t)k]]) nbp.push_back(pos[(size_t)ci[(size_t)k]]);
+            if (!nbp.empty()) {
+                std::nth_element(nbp.begin(), nbp.begin() + nbp.size() / 2, nbp.end());
+                nxt[(size_t)v] = nbp[nbp.size() / 2];
+            }
         }
     });
     respread();

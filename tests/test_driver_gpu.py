@@ -169,7 +169,7 @@ def test_community_renumbering_speeds_up_the_aggregation():
     mode would run -- and equals the permuted result of the scrambled graph."""
     from gnnadvisor_osdi21_amd import _lib, graph
     dev = torch.device("cuda")
-    g = graph.make_config_graph("reddit-like", device=dev, locality=0.9, wrap=False)   # a line of neighbourhoods
+    g = graph.make_config_graph("reddit-like", device=dev, locality=0.9)   # a ring of neighbourhoods (generator's default)
     n, D = g.num_nodes, 64
     rows = torch.repeat_interleave(torch.arange(n, device=dev), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
     perm = torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
