@@ -575,14 +575,16 @@ def run_sharded(args, result_fd, world, rank, local_rank):
     e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
     n_global = n_local * world
     rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
-                                  seed=cfg["seed"] * 1000 + rank, device=dev)
+                                  seed=cfg["seed"] * 1000 + rank, device=dev, locality=args.locality,
+                                  block_start=rank * n_local)
     bounds = [i * n_local for i in range(world + 1)]
 
     class _Profile:
         pass
     prof_obj = _Profile()
-    # sources are drawn from all ranks' nodes with no locality: span ~ n_global / 3
-    prof_obj.num_nodes, prof_obj.avg_degree, prof_obj.avg_edgeSpan = n_local, float(ci.numel()) / n_local, n_global / 3.0
+    # sources are drawn from all ranks' nodes (span ~ n_global / 3) unless --locality keeps a share of them near
+    prof_obj.num_nodes, prof_obj.avg_degree = n_local, float(ci.numel()) / n_local
+    prof_obj.avg_edgeSpan = (1.0 - args.locality) * n_global / 3.0
     prof_obj.num_features, prof_obj.reorder_flag = cfg["feat"], False
     prof_obj.rabbit_reorder = lambda: None
     info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=prof_obj,
@@ -663,7 +665,8 @@ def run_sharded(args, result_fd, world, rank, local_rank):
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "verified": bool(float(exact[0]) == 1.0),
             "verification": {"ones_exact_on_every_rank": bool(float(exact[0]) == 1.0)},
-            "config": {"workload": f"{args.config} power-law graph, random node order"
+            "config": {"workload": f"{args.config} power-law graph, "
+                                   + (f"id-local partition (locality={args.locality})" if args.locality else "random node order")
                                    + (f", scale={args.scale}" if args.scale != 1.0 else ""),
                        "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
                        "num_parts_per_gpu": P, "source_nodes": n_global,

@@ -132,10 +132,11 @@ def powerlaw_graph(num_nodes: int, num_edges: int, max_degree: int, *, exponent:
 
 
 def powerlaw_shard(num_local: int, num_global: int, num_edges: int, max_degree: int, *,
-                   exponent: float = 2.1, seed: int = 0, device="cpu"):
+                   exponent: float = 2.1, seed: int = 0, device="cpu", locality: float = 0.0, block_start: int = 0):
     """One destination-range shard of a large power-law graph, generated independently per
     rank: ``num_local`` destination rows whose ``~num_edges`` sources are drawn from all
-    ``num_global`` nodes with power-law popularity.  Returns (row_pointers int32 [num_local+1],
+    ``num_global`` nodes with power-law popularity (``locality``: that fraction of the sources lies near the
+    destination's own global id ``block_start + row`` instead).  Returns (row_pointers int32 [num_local+1],
     column_index int32 with GLOBAL ids), duplicates merged / columns sorted as in the loader."""
     dev = torch.device(device)
     g = torch.Generator(device=dev)
@@ -148,6 +149,14 @@ def powerlaw_shard(num_local: int, num_global: int, num_edges: int, max_degree: 
     perm_c = torch.randperm(num_global, generator=g, device=dev)
     rows = perm_r[torch.searchsorted(cdf_r, torch.rand(num_edges, generator=g, device=dev, dtype=torch.float64)).clamp_(max=num_local - 1)]
     cols = perm_c[torch.searchsorted(cdf_c, torch.rand(num_edges, generator=g, device=dev, dtype=torch.float64)).clamp_(max=num_global - 1)]
+    if locality > 0.0:
+        # an id-local partition (what a graph partitioner / the community renumbering produces): this fraction of
+        # the sources lies within +-window ids of the destination's global id instead of anywhere
+        window = max(1, min(4096, num_local // 4))
+        local = torch.rand(num_edges, generator=g, device=dev) < locality
+        off = torch.randint(-window, window + 1, (num_edges,), generator=g, device=dev)
+        near = (rows + block_start + off).clamp_(0, num_global - 1)
+        cols = torch.where(local, near, cols)
     key = torch.unique(rows * num_global + cols, sorted=True)
     r = torch.div(key, num_global, rounding_mode="floor")
     c = key - r * num_global
