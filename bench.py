@@ -329,6 +329,7 @@ def measure_traffic(workloads, args):
                       "fetch_calibration": kf, "write_calibration": kw,
                       "calibrated_in_this_run": bool(cp_f and cp_w),
                       "l2_hit_rate": (hit[i] / (hit[i] + miss[i])) if hit[i] and miss[i] is not None else None,
+                      "l2_requests_per_step": (hit[i] + miss[i]) if hit[i] and miss[i] is not None else None,
                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this bench.py invocation "
                                 "(3 steps each, same partition and phase schedule as the timed loop)"}
     except Exception as exc:  # profiler missing / refused: report, never fake
@@ -360,6 +361,15 @@ def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
                     "traffic": fabric / max(1, w.launches), "traffic_per_step": fabric,
                     "traffic_over_compulsory": fabric / comp,
                     "l2_hit_rate": traffic.get("l2_hit_rate"), "traffic_detail": traffic})
+        # the two ceilings the kernel runs against at the same time (a lower `frac` than an earlier build's can mean
+        # less traffic for the same work, not a slower kernel: compare these and kernel_ms)
+        req = traffic.get("l2_requests_per_step")
+        rec["ceilings"] = {
+            "fabric_time_floor_ms": fabric / 6.3e12 * 1e3, "fabric_share_of_kernel_time": fabric / 6.3e12 / t,
+            "fabric_ceiling": "6.3 TB/s measured copy ceiling (MI355X_MICROARCH.md)",
+            "l2_time_floor_ms": req * 128 / 34.5e12 * 1e3 if req else None,
+            "l2_share_of_kernel_time": req * 128 / 34.5e12 / t if req else None,
+            "l2_ceiling": "34.5 TB/s aggregate L2 (128-byte requests)"}
     else:
         rec.update({"achieved": comp / t / 1e9 if t > 0 else 0.0,
                     "frac": comp / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
