@@ -1,0 +1,70 @@
+"""bench.py host logic that needs no GPU: the driver's contract (defaults, the self-launch command for
+`--gpus N`), the byte models of SURVEY.md 8(d), and the bookkeeping that turns a rocprofv3 counter CSV into
+per-step traffic (dispatch order, calibration copies)."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_defaults_follow_the_driver_contract():
+    a = bench.parse_args([])
+    assert a.gpus == 1 and a.steps > 0 and a.warmup > 0 and a.dim == 64 and a.config == "reddit-like"
+    a = bench.parse_args(["--gpus", "8", "--steps", "5", "--warmup", "2"])
+    assert (a.gpus, a.steps, a.warmup) == (8, 5, 2) and a.backend == "nccl" and a.exchange == "auto"
+
+
+def test_gpus_n_launches_n_ranks_on_localhost(monkeypatch):
+    seen = {}
+
+    def fake_execv(path, argv):
+        seen["path"], seen["argv"] = path, list(argv)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "3"])
+    with pytest.raises(SystemExit):
+        bench.self_launch(4)
+    argv = seen["argv"]
+    assert seen["path"] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(argv[argv.index("--master-port") + 1]) < 65536
+    tail = argv[argv.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "3"]      # the ranks get the caller's flags unchanged
+
+
+def test_byte_models():
+    nnz, n, parts, dim = 114623790, 232965, 1901647, 64
+    assert bench.gather_model_bytes(nnz, n, parts, dim) == nnz * 260 + n * 260 + parts * 8 == 29877969476
+    assert bench.compulsory_bytes(nnz, n, n, dim) == nnz * 4 + (n + 1) * 4 + 2 * n * dim * 4
+
+
+def test_counter_rows_are_split_by_workload_and_calibrated_on_the_last_copies():
+    manifest = {"workloads": [{"warmup": 1, "steps": 3, "launches_per_step": 1, "phases": 8},
+                              {"warmup": 1, "steps": 3, "launches_per_step": 2, "phases": 2}],
+                "calib_copies": 3}
+    rows = []
+
+    def add(kernel, value):
+        rows.append({"Dispatch_Id": str(len(rows) + 1), "Kernel_Name": kernel, "Counter_Name": "FETCH_SIZE",
+                     "Counter_Value": str(value)})
+    add("__amd_rocclr_copyBuffer", 7.0)                       # host-to-device transfers of the set-up: not calibration
+    add("slice_count_kernel", 999.0)
+    for v in (50.0, 100.0, 100.0, 100.0):                     # workload 0: warm-up + 3 steps, one launch each
+        add("stream_kernel", v)
+    add("__amd_rocclr_copyBuffer", 9.0)
+    for v in (1.0, 1.0, 10.0, 20.0, 10.0, 20.0, 10.0, 20.0):  # workload 1: two launches per step
+        add("agg_kernel", v)
+    for _ in range(3):
+        add("__amd_rocclr_copyBuffer", 524288.0)              # the 1 GiB calibration copies (KiB, half-counted)
+    per_step, copies = bench.split_counters(manifest, rows, "FETCH_SIZE")
+    assert per_step == [100.0, 30.0]
+    assert copies == [524288.0] * 3
+    assert bench.CALIB_BYTES / (1024.0 * sum(copies) / len(copies)) == 2.0
+    # a child whose dispatch count does not match the schedule is not trusted
+    short, _ = bench.split_counters(manifest, rows[:-6], "FETCH_SIZE")
+    assert short[1] is None
