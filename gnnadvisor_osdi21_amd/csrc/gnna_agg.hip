@@ -745,6 +745,8 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     p.cursor = nullptr; p.phase = 0; p.num_phases = 1; p.phase_hi = 0x7fffffff;
     p.acc_in = accumulate_into_out ? 1 : 0;
     if (phases > 1) {
+        rc = claim_cursors(ds, stream, column_index, part_pointers, num_windows, win_begin, win_end);
+        if (rc != GNNA_OK) return rc;
         void *ws = nullptr;
         rc = get_workspace(ds, stream, 0, (size_t)num_parts * sizeof(int32_t), &ws);
         if (rc != GNNA_OK) return rc;

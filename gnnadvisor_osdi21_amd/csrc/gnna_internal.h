@@ -31,11 +31,19 @@ struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
 };
+// Who owns the run cursors (scratch slot 0) of a stream: the multi-launch schedules of the chunk-walk kernel keep
+// per-run state there between launches -- and, for a windowed aggregation, between library CALLS.
+struct CursorOwner {
+    const void *col = nullptr, *pp = nullptr;
+    int windows = 0;       // number of source windows of the sequence (1 = a whole aggregation in one call)
+    int next_window = 0;   // the window the next call has to start at (== windows: sequence complete)
+};
 struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
     int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
     std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
+    std::map<hipStream_t, CursorOwner> cursor_owner;
 };
 constexpr int kFlagSlots = 1024;
 
@@ -43,6 +51,12 @@ constexpr int kFlagSlots = 1024;
 int get_device_state(DeviceState **out);
 // Grow-only scratch buffer `slot` of `stream`.
 int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out);
+// Claims the stream's run cursors for the windows [win_begin, win_end) of a `num_windows`-window sequence on the
+// partition (column_index, part_pointers).  A sequence starts at window 0; a later window is accepted only as the
+// continuation of the sequence that is in progress on this stream -- if anything else used the cursors in between
+// (another phased aggregation, an SDDMM, a different graph's windows) the call fails instead of summing wrongly.
+int claim_cursors(DeviceState *ds, hipStream_t stream, const void *column_index, const void *part_pointers,
+                  int num_windows, int win_begin, int win_end);
 // Fresh non-zero sequence number of an aggregation call and its slot in the flag ring.
 int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
 

@@ -214,6 +214,8 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     if (tune.column_phases == 0) phases = (phases >= 4) ? 2 : 1;
     p.cursor = nullptr; p.phase = 0; p.num_phases = phases; p.phase_hi = 0x7fffffff;
     if (phases > 1) {
+        rc = claim_cursors(ds, stream, column_index, part_pointers, 1, 0, 1);
+        if (rc != GNNA_OK) return rc;
         void *ws = nullptr;
         rc = get_workspace(ds, stream, 0, (size_t)num_parts * sizeof(int32_t), &ws);
         if (rc != GNNA_OK) return rc;

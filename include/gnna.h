@@ -154,8 +154,9 @@ GNNA_API int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows
  * lies in windows [window_begin, window_end) and must only read those rows of `input`.
  * Contract: the calls of one aggregation are issued on one stream in increasing window order,
  * starting at window 0 and ending at window num_windows-1, with identical other arguments and no
- * other libgnna aggregation on that stream in between (per-run cursors live in the stream's
- * scratch).  The first call overwrites `out` unless accumulate != 0; later calls add.  Column
+ * other multi-launch (chunk-walk phased) aggregation or SDDMM on that stream in between (per-run
+ * cursors live in the stream's scratch).  A window call that does not continue the sequence in
+ * progress on its stream is refused with GNNA_ERR_INVALID_ARGUMENT instead of summing wrongly.  The first call overwrites `out` unless accumulate != 0; later calls add.  Column
  * ids need not be sorted; an id below the current windows that was skipped earlier is consumed
  * by a later call, and the last window consumes everything that is left.
  */

@@ -665,6 +665,22 @@ def test_windowed_calls_pipeline_with_arriving_source_rows(K, dim, partSize, sor
         _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 1, 1))
     with pytest.raises(_lib.GnnaError):
         _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(17, 0, 1))
+    if K >= 2:
+        # the run cursors live in the stream's scratch between the calls of a windowed aggregation: a window that
+        # does not continue the sequence in progress (skipped window, or another phased call in between) is refused
+        # instead of summing wrongly
+        _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 0, 1))
+        if K >= 3:
+            with pytest.raises(_lib.GnnaError, match="does not continue"):
+                _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 2, 3))
+        _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 0, 1))
+        try:
+            _lib.set_tuning(stream_kernel=2, column_phases=2)
+            _lib.sag(X, None, cid, None, pp, p2n, partSize, 32, 4)          # a phased chunk-walk call takes the cursors
+        finally:
+            _lib.reset_tuning()
+        with pytest.raises(_lib.GnnaError, match="does not continue"):
+            _lib.agg_rect(0, X, cid, pp, p2n, n, partSize, out=out, windows=(K, 1, 2))
 
 
 @pytest.mark.parametrize("dim", [3, 5, 7, 22, 41, 47, 56, 60, 100, 172])
