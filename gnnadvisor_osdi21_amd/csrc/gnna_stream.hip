@@ -617,7 +617,11 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
         (void)hipEventRecord(pl.ready, stream);
         hit = &pl;
     } else if (hit->made_on != stream) {
-        (void)hipStreamWaitEvent(stream, hit->ready, 0);   // built on another stream: order after it
+        // built on another stream: order after it (not from inside a capture: the counting pass was enqueued before the
+        // capture began -- a capture needs its warm-up anyway -- and an outside event must not leak into the graph)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, hit->ready, 0);
     }
     hit->stamp = ++g_plan_clock;
     *out = hit->cnt;
