@@ -79,7 +79,6 @@ struct StreamParams {
     int32_t phase_lo;          // first phase of this launch
     int32_t plain_ok;          // 1: rows owned by one work item may be written with plain stores
     int32_t xcd_remap;
-    int32_t dbg_noflush;
     float eps;
 };
 
@@ -488,7 +487,7 @@ stream_kernel(const StreamParams p)
                         } else {
                             acc += v[u];
                         }
-                        if (((FL >> j) & 1ull) && !p.dbg_noflush) {
+                        if ((FL >> j) & 1ull) {
                             const int meta = __builtin_amdgcn_readlane(k_meta, j);
                             float scale = p.eps;
                             if constexpr (MODE == MODE_GIN) {
@@ -661,7 +660,6 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     p.S = a.cnt ? a.S : 1; p.B = a.cnt ? a.B : 1; p.phase_lo = 0;
     p.plain_ok = a.plain_ok ? 1 : 0;
     p.eps = a.eps;
-    { static const int dbg = std::getenv("GNNA_DEBUG_NOFLUSH") ? 1 : 0; p.dbg_noflush = dbg; }
     const int64_t grid = items * (int64_t)p.B;
     if (grid > 0x7fffffffLL) return fail(GNNA_ERR_UNSUPPORTED, "aggregation grid too large (%lld blocks)", (long long)grid);
     int lpr = 4;
