@@ -455,6 +455,8 @@ int choose_row_stride(int dim)
     return best;
 }
 
+}  // namespace
+
 // Number of phases of the sliced schedule from the slice statistics of the partition (st.cells[l] =
 // non-empty (group, slice) cells when the 16 fine slices are merged into 16 >> l).
 //  * not at all when the column ids of a row stay near the row (>= 60 % of the edges within a window of source
@@ -498,8 +500,6 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     while (b > 1 && lvl < 4 && piece(lvl) < 12.0) { b >>= 1; lvl++; }
     return (lvl >= 4 && b > 1 && piece(3) < 12.0) ? 1 : std::max(b, 1);
 }
-
-}  // namespace
 
 int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size)
 {

@@ -16,7 +16,7 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kXcds = 8;
 
-enum { MODE_SAG = 0, MODE_GCN = 1, MODE_GIN = 2 };
+enum { MODE_SAG = 0, MODE_GCN = 1, MODE_GIN = 2, MODE_SDDMM = 3 };
 
 // T: register type; M: the same vector as it sits in memory.  Feature rows are only 4-byte
 // aligned in general (row stride = D floats, D arbitrary), and gfx950 global_load/store_dwordx4
@@ -59,6 +59,26 @@ __device__ __forceinline__ float slot_reduce(float v)
     if constexpr (LPR <= 4) v += row_ror<4>(v);
     if constexpr (LPR <= 16) v = fold_xor16(v);
     if constexpr (LPR <= 32) v = fold_xor32(v);
+    return v;
+}
+
+// DPP data movement inside a 16-lane row.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the LPR consecutive lanes of a slot (lanes sharing lane / LPR); result in every lane of the slot.
+template <int LPR>
+__device__ __forceinline__ float lane_group_sum(float v)
+{
+    v += dpp_move<0xB1>(v);                          // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E>(v);                          // quad_perm [2,3,0,1]
+    if constexpr (LPR >= 8) v += dpp_move<0x141>(v);  // row_half_mirror: the other quad of the 8
+    if constexpr (LPR >= 16) v += dpp_move<0x140>(v); // row_mirror: the other half of the 16
+    if constexpr (LPR >= 32) v = fold_xor16(v);
+    if constexpr (LPR >= 64) v = fold_xor32(v);
     return v;
 }
 

@@ -75,6 +75,9 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
                    const int32_t *part2Node, int64_t num_parts, int S, uint32_t slice_rows, bool want_stats, const uint8_t **out,
                    SlicePlanStats *stats_out);
 void drop_slice_plans();
+// Number of phases of the sliced schedule from the statistics of the partition (gnna_agg.hip).
+int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
+                  bool square, bool hinted_scattered);
 
 struct StreamLaunch {
     int mode;                 // MODE_SAG, MODE_GIN (also the pre-scaled GCN form: GIN + row_scale) or MODE_GCN (per-edge)
@@ -82,6 +85,7 @@ struct StreamLaunch {
     const uint8_t *cnt;       // slice counts or nullptr (single phase)
     const float *row_scale;
     const float *deg_row; const float *deg_col;   // MODE_GCN
+    const float *A = nullptr;                      // MODE_SDDMM: destination-side features (Y = edge_out)
     const int32_t *flag; int32_t seq; int32_t trust;
     int64_t P;
     int D, ldx, G, U, S, B;

@@ -18,25 +18,6 @@ namespace {
 // owns a chunk of groups, a run keeps the destination row's piece in registers, source rows are
 // gathered RPI per wave-wide load, and the LPR lanes of a slot fold their 4-float partial dot
 // products with DPP (quad_perm / row_half_mirror / row_mirror) and permlane swaps.
-template <int CTRL>
-__device__ __forceinline__ float dpp_move(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
-}
-
-// Sum over the LPR consecutive lanes of a slot; result in every lane of the slot.
-template <int LPR>
-__device__ __forceinline__ float lane_group_sum(float v)
-{
-    v += dpp_move<0xB1>(v);                          // quad_perm [1,0,3,2]
-    v += dpp_move<0x4E>(v);                          // quad_perm [2,3,0,1]
-    if constexpr (LPR >= 8) v += dpp_move<0x141>(v);  // row_half_mirror: the other quad of the 8
-    if constexpr (LPR >= 16) v += dpp_move<0x140>(v); // row_mirror: the other half of the 16
-    if constexpr (LPR >= 32) v = fold_xor16(v);
-    if constexpr (LPR >= 64) v = fold_xor32(v);
-    return v;
-}
-
 struct SddmmParams {
     const float *A;       // [n_out, D] destination-side features
     const float *B;       // [n_in, D] source-side features
@@ -206,6 +187,36 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     p.num_chunks = (num_parts + p.G - 1) / p.G;
     const size_t b_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
     const bool wide = b_bytes > 0xffffffffull;
+    if (tune.stream_kernel != 2) {
+        // streaming kernel (gnna_stream.hip, MODE_SDDMM): same work items and sliced schedule as the aggregation; an
+        // edge belongs to exactly one slice, so the phases need neither atomics nor a zero-filled output
+        int B = 1;
+        const uint8_t *cnt = nullptr;
+        const int S = 16;
+        const uint32_t slice_rows = (uint32_t)std::max<int64_t>(1, (num_in_rows + S - 1) / S);
+        if (tune.column_phases >= 2 && num_in_rows >= S) {
+            B = std::min(tune.column_phases, S);
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, false, &cnt, nullptr);
+            if (rc != GNNA_OK) return rc;
+        } else if (tune.column_phases == 0 && num_parts >= 1024 && num_in_rows >= 64 && b_bytes >= ((size_t)6 << 20)) {
+            SlicePlanStats st;
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, true, &cnt, &st);
+            if (rc != GNNA_OK) return rc;
+            if (cnt && st.valid)
+                B = choose_slices(st, b_bytes, S, slice_rows, num_out_rows, num_in_rows == num_out_rows, tune.nonlocal_ids == 1);
+        }
+        if (!cnt || B < 2) { B = 1; cnt = nullptr; }
+        StreamLaunch a;
+        a.mode = MODE_SDDMM; a.X = src_feat; a.A = dst_feat; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node;
+        a.Y = edge_out; a.cnt = cnt; a.row_scale = nullptr; a.deg_row = nullptr; a.deg_col = nullptr;
+        // the canonical-partition flag only decides between stores and atomics for shared rows; SDDMM shares nothing
+        int32_t *flag = nullptr;
+        a.seq = next_call_seq(ds, &flag);
+        a.flag = flag; a.trust = 1; a.P = num_parts; a.D = dim; a.ldx = dim;
+        a.G = std::min(64, std::max(1, tune.groups_per_chunk) * B); a.U = 4; a.S = S; a.B = B;
+        a.wide = wide; a.plain_ok = true; a.xcd_remap = tune.xcd_remap != 0; a.eps = 1.f;
+        return launch_stream(a, stream);
+    }
     // the source-side rows are gathered like the aggregation's, so the same column-phase rule applies,
     // but a phase costs more here (per-edge dot-product fold, cursor scan) and the gain is smaller:
     // measured on the Reddit-like graph (D = 64) 1 / 2 / 4 / 6 phases = 2.91 / 2.66 / 3.03 / 3.36 ms,

@@ -65,6 +65,7 @@ struct StreamParams {
     const float *row_scale;    // MODE_GIN: optional per-destination-row factor on top of eps
     const float *deg_row;      // MODE_GCN (per-edge coefficients): degree norm per destination row ...
     const float *deg_col;      // ... and per source row
+    const float *A;            // MODE_SDDMM: destination-side features [num_out_rows, D]; Y is then edge_out [nnz]
     const int32_t *flag;       // *flag == seq  <=>  partition is NOT canonical
     int64_t P;
     int64_t num_chunks;
@@ -279,7 +280,9 @@ stream_kernel(const StreamParams p)
     // emitted in a batch between rounds.
     constexpr int PEND = LPR <= 16 ? 8 : (LPR == 32 ? 4 : 2);          // rows parked per wavefront
     constexpr int PEND_FLOATS = LPR * 4;                               // floats per parked row (one dimension sweep)
-    __shared__ float s_pend[kWavesPerBlock][PEND * PEND_FLOATS];
+    // (MODE_SDDMM parks the round's dot products there instead: one float per list slot)
+    constexpr int PEND_TOTAL = MODE == MODE_SDDMM ? RL * RPI : PEND * PEND_FLOATS;
+    __shared__ float s_pend[kWavesPerBlock][PEND_TOTAL];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -415,6 +418,7 @@ stream_kernel(const StreamParams p)
             int v_j = active ? k_n - i * RPI : 0;
             const bool fl_j = active && (k_meta & 2) && v_j <= RPI;   // last load of the last piece of its row
             v_j = v_j > RPI ? RPI : v_j;
+            const int row_j = active ? (k_meta >> 2) : 0;     // MODE_SDDMM: destination row of lane j's load
             const unsigned long long FL = __ballot(fl_j);
             const unsigned long long TM = __ballot(active && v_j < RPI);   // loads with padded slots
             const int nr = (L - r0) < RL ? (L - r0) : RL;
@@ -463,6 +467,56 @@ stream_kernel(const StreamParams p)
             };
             const int nb = (nr + U - 1) / U;
             VT v[U];
+            if constexpr (MODE == MODE_SDDMM) {
+                // edge_out[e] = < A[row(e), :], X[col(e), :] >: every ring slot carries the destination row's piece of its
+                // load (consecutive loads of a piece re-read the same 4 * LPR floats: L1 hits), no accumulation, no flush --
+                // every edge is written once, in the one phase that owns it
+                const float *abase = p.A + dcol;
+                auto a_ptr = [&](int j) -> const MT * {
+                    return reinterpret_cast<const MT *>(abase + (size_t)__builtin_amdgcn_readlane(row_j, j) * (size_t)D);
+                };
+                VT a[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) { a[u] = *a_ptr(u); v[u] = *row_ptr(offs[u * RPI + slot]); }
+#pragma unroll 1
+                for (int b = 0; b < nb; b++) {
+                    const int jn = (b + 1 < nb ? b + 1 : nb - 1) * U;
+                    uint32_t nn[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) nn[u] = offs[(jn + u) * RPI + slot];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int j = b * U + u;
+                        if (j < nr) {
+                            VT av = a[u];
+                            // components that overlap the previous piece (ragged D) and lanes past the row end do not count
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (!cvalid || k < shift) av[k] = 0.f;
+                            const VT prod = v[u] * av;
+                            float dot = lane_group_sum<LPR>((prod[0] + prod[1]) + (prod[2] + prod[3]));
+                            // parked in LDS (the round's list slot of the edge) and written out after the round: a
+                            // 16-byte store per load in the middle of the stream would sit in the ring's vmcnt queue
+                            if (c == 0) pend[j * RPI + slot] = dot;
+                        }
+                        a[u] = *a_ptr(jn + u);
+                        v[u] = *row_ptr(nn[u]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < (RL * RPI + kWave - 1) / kWave; q++) {
+                    const int f = q * kWave + lane;
+                    const int j = f / RPI, sl = f % RPI;
+                    const int ej = __shfl(e_j, j), vj = __shfl(v_j, j);
+                    if (f < RL * RPI && j < nr && sl < vj) {
+                        float dot = pend[f];
+                        float *dst = p.Y + ej + sl;
+                        if (d0 > 0) dot += *dst;   // wider than one lane sweep: add to the earlier sweeps' part
+                        *dst = dot;
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < U; u++) v[u] = *row_ptr(offs[u * RPI + slot]);
 #pragma unroll 1
@@ -649,7 +703,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
 {
     StreamParams p;
     p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
-    p.deg_row = a.deg_row; p.deg_col = a.deg_col;
+    p.deg_row = a.deg_row; p.deg_col = a.deg_col; p.A = a.A;
     p.flag = a.flag; p.P = a.P; p.seq = a.seq; p.trust = a.trust; p.D = a.D; p.ldx = a.ldx;
     p.G = std::max(1, std::min(a.G, kWave));
     p.num_chunks = (a.P + p.G - 1) / p.G;
@@ -666,7 +720,8 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     const int pieces = (a.D + 3) / 4;
     while (lpr < 64 && lpr < pieces) lpr <<= 1;
     StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U)
-                     : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U));
+                     : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
+                     : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, 4) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
