@@ -578,7 +578,8 @@ struct Plan {
     bool have_stats = false;
     uint64_t stamp = 0;
 };
-constexpr int kMaxPlans = 8;
+constexpr int kMaxPlans = 32;   // 15 bytes per neighbor-group each (Reddit-like: 28 MB): small next to 288 GB, and a
+                                // working set of graphs larger than the table would recount on every call
 Plan g_plans[kMaxPlans];
 std::mutex g_plan_mutex;
 uint64_t g_plan_clock = 0;
