@@ -20,8 +20,11 @@ backend "nccl" == RCCL over xGMI):
   output (``gnna_agg_rect_f32(..., accumulate=1)``).
 
 * pipelined exchange (``pipeline_chunks = K``): the blocks are cut into K sub-blocks, the gather buffer is
-  sub-block-major, K asynchronous all-gathers are in flight at once and source window k of the
-  remote part is aggregated as soon as piece k has arrived (``gnna_agg_rect_windows_f32``).
+  sub-block-major, K asynchronous all-gathers are in flight at once and the part of the remote CSR whose
+  sources travel in piece k is aggregated as soon as piece k has arrived.  (Round 1 used one CSR and the
+  windowed entry ``gnna_agg_rect_windows_f32``, whose per-run cursors live in library scratch between the K
+  calls; the remote part is now split into K small CSRs at construction, each an ordinary stateless
+  aggregation on the streaming kernel.)
 * halo exchange (``exchange="halo"``; ``"auto"`` picks it when it moves clearly fewer bytes): instead of
   whole blocks, every rank receives only the remote source rows its shard actually references.  The
   unique remote ids per owner are found once, the owners learn which of their rows each peer needs
@@ -231,6 +234,21 @@ class ShardedAggregator:
             if self.chunks > 1:
                 ci_r = sort_columns_within_rows(rp_r, ci_r)
             self.remote_part = (ci_r.contiguous(), pp_r.to(self.device), p2n_r.to(self.device))
+            # pipelined exchange: the remote part is split once more, by the piece of the exchange its source arrives
+            # with; piece k is then an ordinary aggregation (accumulate) over its own small CSR -- it reads nothing but
+            # rows of piece k by construction, runs on the streaming kernel and keeps no state between the K calls
+            self.remote_pieces = []
+            if self.chunks > 1:
+                win = self.remote_rows // self.chunks
+                rows_r = torch.repeat_interleave(torch.arange(self.n_local, device=self.device),
+                                                 (rp_r[1:] - rp_r[:-1]).to(torch.int64).to(self.device))
+                piece_of = torch.div(ci_r.to(torch.int64), win, rounding_mode="floor")
+                for k in range(self.chunks):
+                    m = piece_of == k
+                    rp_k = torch.zeros(self.n_local + 1, dtype=torch.int64, device=self.device)
+                    rp_k[1:] = torch.cumsum(torch.bincount(rows_r[m], minlength=self.n_local), 0)
+                    pp_k, p2n_k = build_part_fn(self.partSize, rp_k.to(torch.int32).cpu().contiguous())
+                    self.remote_pieces.append((ci_r[m].contiguous(), pp_k.to(self.device), p2n_k.to(self.device)))
         else:
             self.exchange = "allgather"
         self.avg_degree_all = column_index.numel() / max(1, self.n_local)
@@ -239,6 +257,8 @@ class ShardedAggregator:
             if self.overlap:
                 self.hint_fn(self.local_part[0], self.avg_degree_local, self.scattered_sources)
                 self.hint_fn(self.remote_part[0], self.avg_degree_remote, self.scattered_sources)
+                for ci_k, _, _ in self.remote_pieces:
+                    self.hint_fn(ci_k, self.avg_degree_remote / self.chunks, self.scattered_sources)
         self._gather_buf: Optional[torch.Tensor] = None
         self._pad_buf: Optional[torch.Tensor] = None
         self._deg_all: Optional[torch.Tensor] = None
@@ -487,13 +507,13 @@ class ShardedAggregator:
         ci_l, pp_l, p2n_l = self.local_part
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
                                 degrees_local, degrees_local, epsilon, out)
-        ci_r, pp_r, p2n_r = self.remote_part
-        for k, work in enumerate(works):
+        parts = self.remote_pieces if self.chunks > 1 else [self.remote_part]
+        for (ci_k, pp_k, p2n_k), work in zip(parts, works):
             if work is not None:
                 work.wait()
-            out = self.aggregate_fn(mode, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize,
-                                    degrees_local, deg_in, epsilon, out, accumulate=True,
-                                    windows=(self.chunks, k, k + 1) if self.chunks > 1 else None)
+            if ci_k.numel():
+                out = self.aggregate_fn(mode, X_all, ci_k, pp_k, p2n_k, self.n_local, self.partSize,
+                                        degrees_local, deg_in, epsilon, out, accumulate=True)
         return out
 
     # ---- the two halves of a step on their own (bench.py reports them beside the overlapped step) ----------------
@@ -522,19 +542,18 @@ class ShardedAggregator:
                                                                 (self._pad_buf if self._pad_buf is not None else X_local))
         ci_l, pp_l, p2n_l = self.local_part
         out = self.aggregate_fn(0, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize, None, None, 1.0, out)
-        ci_r, pp_r, p2n_r = self.remote_part
-        if X_all is None or not ci_r.numel():
+        if X_all is None:
             return out
-        for k in range(self.chunks):
-            out = self.aggregate_fn(0, X_all, ci_r, pp_r, p2n_r, self.n_local, self.partSize, None, None, 1.0, out,
-                                    accumulate=True, windows=(self.chunks, k, k + 1) if self.chunks > 1 else None)
+        for ci_k, pp_k, p2n_k in (self.remote_pieces if self.chunks > 1 else [self.remote_part]):
+            if ci_k.numel():
+                out = self.aggregate_fn(0, X_all, ci_k, pp_k, p2n_k, self.n_local, self.partSize, None, None, 1.0, out,
+                                        accumulate=True)
         return out
 
     def calibrate(self, dims, reps: int = 3) -> dict:
         """Measured phase counts for the parts of this shard (no collective involved: every rank tunes its
-        own kernels on random features).  Local part and, without pipelining, the remote / whole part go
-        through ``decider.calibrate_phases``; the windowed remote part is timed as K window calls for total
-        phase counts K, 2K, 3K, 4K.  Only with the real kernel (no injected aggregate_fn)."""
+        own kernels on random features).  Every part -- local, remote, or the K pieces of the remote part -- goes
+        through ``decider.calibrate_phases``.  Only with the real kernel (no injected aggregate_fn)."""
         if self.aggregate_fn is not _default_aggregate or self.device.type != "cuda":
             return {}
         from . import _lib
@@ -554,35 +573,8 @@ class ShardedAggregator:
         if self.chunks == 1:
             res["remote"] = calibrate_phases(ci_r, pp_r, p2n_r, self.n_local, self.partSize, dims, num_in_rows=n_all)
             return res
-        res["remote"] = {}
-        K = self.chunks
-        for D in sorted({int(d) for d in dims}):
-            X = torch.randn(n_all, D, device=self.device)
-            out = torch.zeros(self.n_local, D, device=self.device)
-
-            def run():
-                for k in range(K):
-                    _lib.agg_rect(_lib.MODE_SAG, X, ci_r, pp_r, p2n_r, self.n_local, self.partSize, out=out,
-                                  accumulate=True, windows=(K, k, k + 1))
-            _lib.set_graph_phases(ci_r, D, 0)
-            run()
-            rule = _lib.last_num_phases()
-            timing = {}
-            for total in sorted({rule, *[m * K for m in (1, 2, 3, 4) if m * K <= 16]}):
-                _lib.set_graph_phases(ci_r, D, total)
-                run(); run()
-                torch.cuda.synchronize()
-                _lib.profile_begin(reps * K)
-                for _ in range(reps):
-                    run()
-                torch.cuda.synchronize()
-                timing[total] = _lib.profile_end()["main_ms"] * K
-            best = min(timing, key=timing.get)
-            if timing[best] > 0.98 * timing[rule]:
-                best = rule
-            _lib.set_graph_phases(ci_r, D, best)
-            res["remote"][D] = best
-            del X, out
+        res["remote"] = [calibrate_phases(ci_k, pp_k, p2n_k, self.n_local, self.partSize, dims, num_in_rows=n_all)
+                         if ci_k.numel() else {} for ci_k, pp_k, p2n_k in self.remote_pieces]
         return res
 
     def sag(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
