@@ -31,7 +31,8 @@ The gather-model rate of SURVEY.md 8(d) (bytes = nnz*(4D+4) + N*(4D+4) + P*8 per
 counts every gathered row whether it came from L2, Infinity Cache or HBM and therefore may exceed
 the HBM peak) and the compulsory-model rate are reported beside it, never as `frac`.
 `hbm_resident` repeats the measurement on a workload whose features (627 MB) exceed the 256 MiB
-Infinity Cache (products-like, D = 64).  `cpu_baseline` times the oracle (CPU port) on the host.
+Infinity Cache (products-like, D = 64), `config5_shard` on one GPU's share of BASELINE config 5 (1/8 of a
+papers100M-like graph, D = 128, 7.1 GB of features, 64-bit offsets).  `cpu_baseline` times the oracle (CPU port) on the host.
 """
 from __future__ import annotations
 
@@ -75,6 +76,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HBM-resident second workload")
     ap.add_argument("--secondary-config", default="products-like")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the third workload (BASELINE config 5's per-GPU shape: 1/8 of a papers100M-like graph, D = 128)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed headline workload: no calibration, other modes, PMC children, second "
                          "workload or CPU baseline (used for rocprofv3 kernel-trace runs)")
@@ -133,7 +136,7 @@ class Workload:
         import torch
         from gnnadvisor_osdi21_amd import _lib, graph
         from gnnadvisor_osdi21_amd.decider import inputProperty, calibrate_phases
-        self.config, self.dim, self.dev = config, dim, dev
+        self.config, self.dim, self.dev, self.scale = config, dim, dev, scale
         cfg = graph.CONFIGS[config]
         g = graph.make_config_graph(config, device=dev, locality=locality, scale=scale)
         self.g = g
@@ -234,8 +237,8 @@ def pmc_child(args):
     torch.cuda.set_device(dev)
     manifest = {"workloads": [], "calib_bytes": CALIB_BYTES, "calib_copies": 3}
     for spec in args.pmc_workloads.split(","):
-        cfg, dim, ps, phases = spec.split(":")
-        w = Workload(cfg, int(dim), dev, scale=args.scale, locality=args.locality, manual=args.manual,
+        cfg, dim, ps, phases, scale = spec.split(":")
+        w = Workload(cfg, int(dim), dev, scale=float(scale), locality=args.locality, manual=args.manual,
                      part_size=int(ps), calibrate=False, force_phases=0 if args.manual else int(phases))
         warm, steps = 1, 3
         for _ in range(warm + steps):
@@ -302,7 +305,7 @@ def measure_traffic(workloads, args):
     a 1 GiB device copy in the same child, as MI355X_MICROARCH.md prescribes).  -> list of dicts."""
     if shutil.which("rocprofv3") is None:
         return [{"error": "rocprofv3 not found"} for _ in workloads]
-    specs = [f"{w.config}:{w.dim}:{w.ps}:{w.phases}" for w in workloads]
+    specs = [f"{w.config}:{w.dim}:{w.ps}:{w.phases}:{w.scale}" for w in workloads]
     workdir = tempfile.mkdtemp(prefix="gnna_pmc_", dir="/tmp")
     res = [dict() for _ in workloads]
     try:
@@ -509,12 +512,16 @@ def run_single(args, result_fd):
         w2 = Workload(args.secondary_config, 64, dev, manual=args.manual)
         e2, p2 = w2.time(max(5, args.steps // 2), 3)
         second = (w2, e2, p2, max(5, args.steps // 2), w2.verify(64))
-    traffic = [None, None]
+    third = None
+    if extras and not args.no_config5 and args.scale == 1.0:
+        w3 = Workload("papers100M-like", 128, dev, scale=0.125, manual=args.manual)
+        e3, p3 = w3.time(5, 2)
+        third = (w3, e3, p3, 5, w3.verify(32))
+    traffic = {}
     if extras and not args.no_pmc:
-        ws = [w] + ([second[0]] if second else [])
-        # the children build their own copies of the graphs: release this process's big buffers first
-        t = measure_traffic(ws, args)
-        traffic = t + [None] * (2 - len(t))
+        ws = [w] + ([second[0]] if second else []) + ([third[0]] if third else [])
+        for wl, t in zip(ws, measure_traffic(ws, args)):
+            traffic[id(wl)] = t
 
     ms_per_step = elapsed * 1e3 / args.steps
     wl_name = (f"{args.config} power-law graph, random node order"
@@ -532,7 +539,7 @@ def run_single(args, result_fd):
                    "feature_MB": x_mb, "parallelism": "single GPU", "world_size": 1, "device": str(dev),
                    "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
                    "column_phases_used": w.phases, "calibrated_phases": w.calibrated, "tuning": tuning},
-        "roofline": roofline_record(w, kern_ms, pro_ms, traffic[0],
+        "roofline": roofline_record(w, kern_ms, pro_ms, traffic.get(id(w)),
                                     "l2-fabric" if x_mb * 1e6 < (256 << 20) else "hbm"),
     }
     if modes:
@@ -547,9 +554,22 @@ def run_single(args, result_fd):
             "num_nodes": g2.num_nodes, "nnz": g2.nnz, "dim": 64, "partSize": w2.ps, "num_parts": w2.P,
             "column_phases_used": w2.phases, "calibrated_phases": w2.calibrated,
             "verified": chk2["verified"], "verification": chk2,
-            "roofline": roofline_record(w2, p2["main_ms"], p2["prologue_ms"], traffic[1], "hbm"),
+            "roofline": roofline_record(w2, p2["main_ms"], p2["prologue_ms"], traffic.get(id(w2)), "hbm"),
         }
         del w2
+    if third:
+        w3, e3, p3, k3, chk3 = third
+        g3 = w3.g
+        rec["config5_shard"] = {
+            "workload": "papers100M-like power-law graph, scale 1/8 = one GPU's destination shard of BASELINE config 5 "
+                        f"(features {g3.num_nodes * 128 * 4 / 1e9:.1f} GB, 64-bit row offsets)",
+            "value": g3.nnz * k3 / e3, "unit": "edges/s", "steps": k3, "ms_per_step": e3 * 1e3 / k3,
+            "num_nodes": g3.num_nodes, "nnz": g3.nnz, "dim": 128, "partSize": w3.ps, "num_parts": w3.P,
+            "column_phases_used": w3.phases, "calibrated_phases": w3.calibrated,
+            "verified": chk3["verified"], "verification": chk3,
+            "roofline": roofline_record(w3, p3["main_ms"], p3["prologue_ms"], traffic.get(id(w3)), "hbm"),
+        }
+        del w3
     if extras and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.X.cpu(), w.pp, w.p2n, args.dim)
     os.write(result_fd, (json.dumps(rec) + "\n").encode())
