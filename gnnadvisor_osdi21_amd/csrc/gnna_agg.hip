@@ -109,6 +109,86 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
     }
 }
 
+// ---- sparse prologue: zero only the rows nobody overwrites --------------------------------------
+// A single pass of the streaming kernel over a canonical partition STORES every destination row that
+// has an edge and is not shared between two work items; the zero-fill of such a row is written once and
+// overwritten once.  For an output of several GB (BASELINE config 5: 7.1 GB per shard) that is the
+// whole prologue.  This kernel walks the partition instead (it is read for the validation anyway) and
+// zeroes only
+//   * the rows between the rows of consecutive groups (rows without a group: no edges),
+//   * the row of a group without edges (a caller-made partition may hold one),
+//   * a row that continues from the previous work item (both items add to it atomically).
+// One wavefront per 64 consecutive groups; every gap is cleared by the whole wavefront (coalesced).
+// The result is only meaningful for a canonical partition: the validation raises the flag as before and
+// zero_if_flag_kernel, launched behind this kernel, then clears the whole output.
+__global__ void __launch_bounds__(kBlock)
+sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *__restrict__ p2n,
+                       const int32_t *__restrict__ pp, int64_t P, int G, int32_t *flag, int32_t seq, int validate)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const bool vec_ok = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;
+    auto clear_rows = [&](int64_t lo, int64_t cnt) {      // wave-uniform arguments
+        float *base = Y + (size_t)lo * (size_t)D;
+        const size_t n = (size_t)cnt * (size_t)D;
+        if (vec_ok) {
+            f32x4 *b4 = reinterpret_cast<f32x4 *>(base);
+            const f32x4 z = (f32x4)(0.f);
+            for (size_t i = lane; i < (n >> 2); i += kWave) b4[i] = z;
+        } else {
+            for (size_t i = lane; i < n; i += kWave) base[i] = 0.f;
+        }
+    };
+    if (wave == 0) {                                      // rows before the first group's row
+        int64_t first = p2n[0];
+        first = first < 0 ? 0 : (first > N ? N : first);
+        if (first > 0) clear_rows(0, first);
+    }
+    bool bad = false;
+    for (int64_t g0 = wave * kWave; g0 < P; g0 += nwaves * kWave) {
+        const int64_t g = g0 + lane;
+        const bool valid = g < P;
+        int64_t lo = 0, cnt = 0;
+        if (valid) {
+            const int64_t r = p2n[g];
+            const int64_t nxt = g + 1 < P ? (int64_t)p2n[g + 1] : N;
+            const int a = pp[g], b = pp[g + 1];
+            if (b < a || (g + 1 < P && nxt < r)) bad = true;
+            const bool continues = g > 0 && (g % G) == 0 && p2n[g - 1] == r;
+            const bool self = b <= a || continues;
+            lo = self ? r : r + 1;
+            int64_t hi = (self && nxt < r + 1) ? r + 1 : nxt;    // (the next group may belong to the same row)
+            lo = lo < 0 ? 0 : lo;
+            hi = hi > N ? N : hi;
+            cnt = hi > lo ? hi - lo : 0;
+        }
+        unsigned long long m = __ballot(cnt > 0);
+        while (m) {
+            const int l = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t lo_s = ((int64_t)__builtin_amdgcn_readlane((int)(lo >> 32), l) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readlane((int)lo, l);
+            const int64_t cnt_s = ((int64_t)__builtin_amdgcn_readlane((int)(cnt >> 32), l) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)cnt, l);
+            clear_rows(lo_s, cnt_s);
+        }
+    }
+    if (validate && bad) *flag = seq;
+}
+
+// whole-output zero-fill when the validation behind a sparse prologue found the partition not canonical
+// (the streaming kernel then adds every row atomically); returns at once otherwise
+__global__ void __launch_bounds__(kBlock)
+zero_if_flag_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *flag, int32_t seq)
+{
+    if (*flag != seq) return;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n_floats; i += nthreads) Y[i] = 0.f;
+}
+
 // ---- GCN pre-scaling: Xs[j, :] = deg[j] * X[j, :] -------------------------------------------
 // Lets the degree-weighted aggregation run as an unweighted gather of Xs with one multiply by
 // deg[i] at the flush (deg_i * sum_j deg_j x_j), instead of one extra 4-byte gather plus a
@@ -620,21 +700,33 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     const int prof_call = profile_acquire_call(num_parts > 0);
     profile_record(prof_call, 0, stream);
 
-    // prologue: zero-fill + validation
+    // prologue: zero-fill + validation.  `sparse_G` > 0: the streaming kernel is about to run a single pass with
+    // `sparse_G` groups per work item and stores every row it owns, so only the other rows are cleared.
     const size_t n_floats = (size_t)num_nodes * (size_t)dim;
-    {
-        size_t work = std::max(n_floats / 4, (size_t)num_parts);
-        int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);
-        blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
-        hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
-                           part2Node, part_pointers, num_parts, flag, seq,
-                           (num_parts > 0 && !tune.trust_canonical) ? 1 : 0,
-                           (accumulate_into_out || win_begin > 0) ? 0 : 1);
+    auto run_prologue = [&](int sparse_G) -> int {
+        const int validate = (num_parts > 0 && !tune.trust_canonical) ? 1 : 0;
+        const int zero_fill = (accumulate_into_out || win_begin > 0) ? 0 : 1;
+        if (sparse_G > 0 && zero_fill && num_parts > 0) {
+            int64_t blocks = (num_parts + kBlock - 1) / kBlock;
+            blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
+            hipLaunchKernelGGL(sparse_prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, num_nodes, dim,
+                               part2Node, part_pointers, num_parts, sparse_G, flag, seq, validate);
+            if (validate)
+                hipLaunchKernelGGL(zero_if_flag_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(kBlock), 0, stream, out,
+                                   n_floats, flag, seq);
+        } else {
+            size_t work = std::max(n_floats / 4, (size_t)num_parts);
+            int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);
+            blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
+            hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
+                               part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill);
+        }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
-    }
-    if (num_parts == 0) return GNNA_OK;
-    profile_record(prof_call, 1, stream);
+        profile_record(prof_call, 1, stream);
+        return GNNA_OK;
+    };
+    if (num_parts == 0) return run_prologue(0);
 
     // vector width / lane layout: one lane per 4 consecutive floats of a row (dword-aligned
     // dwordx4 accesses, ragged tail handled by the shifted last piece), LPR lanes per row
@@ -728,11 +820,19 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         t_last_launches = 1;
         a.wide = wide; a.plain_ok = (B == 1 && !accumulate_into_out); a.xcd_remap = tune.xcd_remap != 0;
         a.eps = p.eps;
+        // single pass, nothing to add to: only the rows the kernel does not store need clearing -- worth a second
+        // (empty) launch once the output is tens of MB
+        const bool sparse = a.plain_ok && tune.zero_fill != 2 &&
+                            (tune.zero_fill == 1 || n_floats * sizeof(float) >= ((size_t)32 << 20));
+        rc = run_prologue(sparse ? std::max(1, std::min(a.G, kWave)) : 0);
+        if (rc != GNNA_OK) return rc;
         rc = launch_stream(a, stream);
         if (rc != GNNA_OK) return rc;
         profile_record(prof_call, 2, stream);
         return GNNA_OK;
     }
+    rc = run_prologue(0);
+    if (rc != GNNA_OK) return rc;
 
     // phases: `sub` launches per source window (one window == the whole source range unless the caller
     // pipelines a chunked feature exchange); this call runs the launches of windows [win_begin, win_end)

@@ -215,6 +215,10 @@ typedef struct gnna_tuning {
                              where it applies (rows of >= 4 floats, unweighted or pre-scaled gather, no
                              source windows), 2 = always the chunk-walk kernel with per-launch column
                              phases (round-1 schedule; kept for the per-edge GCN form and the windows) */
+    int zero_fill;        /* what the prologue clears before a single pass of the streaming kernel that overwrites
+                             `out`: 1 = only the rows that pass does not store (rows without edges, rows shared by
+                             two work items), 2 = the whole output, 0 = automatic (1 once `out` is >= 32 MiB).
+                             Every other schedule adds into `out` and always clears all of it */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */

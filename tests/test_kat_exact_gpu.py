@@ -27,6 +27,8 @@ SCHEDULES = {
     "gcn_per_edge": dict(gcn_prescale=2),
     "gcn_prescaled": dict(gcn_prescale=1, pad_rows=1),
     "one_group_per_item": dict(groups_per_chunk=1),
+    "sparse_zero_fill": dict(zero_fill=1),
+    "sparse_zero_fill_g3": dict(zero_fill=1, groups_per_chunk=3),
 }
 
 

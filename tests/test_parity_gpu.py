@@ -178,6 +178,68 @@ def test_output_is_fully_overwritten_and_repeatable():
     assert torch.equal(out.cpu(), want)
 
 
+@pytest.mark.parametrize("G", [1, 3, 16, 64])
+@pytest.mark.parametrize("dim", [4, 6, 64, 100, 300])
+def test_sparse_zero_fill_clears_exactly_the_rows_nobody_stores(G, dim):
+    """zero_fill = 1 (automatic from 32 MiB of output): a single pass of the streaming kernel stores the rows it
+    owns, the prologue clears only rows without edges, rows of empty groups and rows that continue from the previous
+    work item.  Every output starts as NaN: a row neither cleared nor stored -- or cleared after being stored --
+    shows."""
+    rng = np.random.default_rng(100 * G + dim)
+    n = 700
+    deg = rng.choice([0, 0, 1, 2, 5, 40], size=n)
+    deg[:3] = 0; deg[-4:] = 0; deg[300:340] = 0                     # runs of rows without edges: first, last, middle
+    deg[50] = 600                                                   # a hub that spans many work items
+    rp = np.zeros(n + 1, dtype=np.int32); rp[1:] = np.cumsum(deg)
+    ci = np.concatenate([np.sort(rng.choice(n, size=d, replace=False)) for d in deg]).astype(np.int32)
+    X = torch.randn(n, dim, generator=torch.Generator().manual_seed(dim))
+    Xn = X.numpy()
+    ref = oracle.csr_f64(0, Xn, rp, ci)
+    rpt, cit = torch.from_numpy(rp), torch.from_numpy(ci)
+    degrees = graph.degrees_from_rowptr(rpt)
+    try:
+        _lib.set_tuning(groups_per_chunk=G, zero_fill=1)
+        for ps in (1, 4, 32):
+            pp, p2n = _lib.build_part(ps, rpt)
+            Xd, rpd, cid, degd, ppd, p2nd = dev(X, rpt, cit, degrees, pp, p2n)
+            out = torch.full((n, dim), float("nan"), device="cuda")
+            _lib.sag(Xd, rpd, cid, degd, ppd, p2nd, ps, 32, 4, out=out)
+            assert_close_f64(out.cpu().numpy(), ref, what=f"sparse zero-fill ps={ps}")
+            out.fill_(float("nan"))
+            _lib.agg_gcn(Xd, rpd, cid, degd, ppd, p2nd, ps, 32, 4, out=out)
+            assert_close_f64(out.cpu().numpy(), oracle.csr_f64(1, Xn, rp, ci, degrees.numpy()), what=f"sparse zero-fill gcn ps={ps}",
+                             scale=oracle.csr_f64(1, np.abs(Xn), rp, ci, degrees.numpy()))
+            # an output view that is only 4-byte aligned
+            buf = torch.full((n * dim + 1,), float("nan"), device="cuda")
+            ou = buf[1:].view(n, dim)
+            _lib.sag(Xd, rpd, cid, degd, ppd, p2nd, ps, 32, 4, out=ou)
+            assert_close_f64(ou.cpu().numpy(), ref, what=f"sparse zero-fill, unaligned out, ps={ps}")
+            assert torch.isnan(buf[0])
+        # a caller-made partition with groups that hold no edge: one on a row without edges, one in the middle of a
+        # row that has edges, one behind the last group
+        pp, p2n = (t.numpy() for t in _lib.build_part(4, rpt))
+        k = int(np.searchsorted(p2n, 50)) + 2                         # inside the hub's groups
+        pp2 = np.concatenate([pp[:1], pp[:1], pp[1:k + 1], pp[k:k + 1], pp[k + 1:], pp[-1:]]).astype(np.int32)
+        p2n2 = np.concatenate([[1], p2n[:k], [50], p2n[k:], [n - 2]]).astype(np.int32)
+        assert np.all(np.diff(p2n2) >= 0) and np.all(np.diff(pp2) >= 0) and len(pp2) == len(p2n2) + 1
+        Xd, rpd, cid, degd, ppd, p2nd = dev(X, rpt, cit, degrees, torch.from_numpy(pp2), torch.from_numpy(p2n2))
+        out = torch.full((n, dim), float("nan"), device="cuda")
+        _lib.sag(Xd, rpd, cid, degd, ppd, p2nd, 4, 32, 4, out=out)
+        assert_close_f64(out.cpu().numpy(), ref, what="sparse zero-fill, groups without edges")
+        # groups out of row order: the validation finds it, the whole output is cleared behind the sparse pass
+        perm = rng.permutation(len(p2n))
+        segs = [ci[pp[j]:pp[j + 1]] for j in perm]
+        ci3 = np.concatenate(segs).astype(np.int32)
+        pp3 = np.concatenate([[0], np.cumsum([len(s) for s in segs])]).astype(np.int32)
+        p2n3 = p2n[perm].astype(np.int32)
+        Xd, rpd, cid, degd, ppd, p2nd = dev(X, rpt, torch.from_numpy(ci3), degrees, torch.from_numpy(pp3), torch.from_numpy(p2n3))
+        out = torch.full((n, dim), float("nan"), device="cuda")
+        _lib.sag(Xd, rpd, cid, degd, ppd, p2nd, 4, 32, 4, out=out)
+        assert_close_f64(out.cpu().numpy(), ref, what="sparse zero-fill, shuffled groups")
+    finally:
+        _lib.reset_tuning()
+
+
 def test_invalid_arguments_are_reported():
     g, X, pp, p2n = make_case(10, 40, 8, 4, seed=1)
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)

@@ -38,7 +38,7 @@ def assert_close_f64(got, ref64, rtol=1e-4, what="", scale=None):
     assert got.shape == ref64.shape, (got.shape, ref64.shape)
     err = np.abs(got - ref64)
     tol = rtol * np.maximum(1.0, np.abs(ref64) if scale is None else np.asarray(scale, dtype=np.float64))
-    bad = err > tol
+    bad = ~(err <= tol)                 # (a NaN in `got` compares false both ways: it must count as off)
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} elements off, max err {err.max():.3e}"
 
 
