@@ -262,6 +262,14 @@ def build_part(partSize: int, indptr: torch.Tensor):
     return pp, p2n
 
 
+def _fresh_output(shape, device) -> torch.Tensor:
+    """A new output tensor: the library writes every element.  GNNA_DEBUG_POISON=1 (the test suite sets it) starts it
+    as NaN, so that an element the library fails to write cannot hide behind whatever the allocator hands back."""
+    if os.environ.get("GNNA_DEBUG_POISON", "0") not in ("", "0"):
+        return torch.full(tuple(shape), float("nan"), dtype=torch.float32, device=device)
+    return torch.empty(tuple(shape), dtype=torch.float32, device=device)
+
+
 def _agg(fn, X, row_pointers, column_index, extra, part_pointers, part2Node, partSize, dimWorker,
          warpPerBlock, out):
     if not X.is_cuda:
@@ -270,7 +278,7 @@ def _agg(fn, X, row_pointers, column_index, extra, part_pointers, part2Node, par
     for t in (column_index, part_pointers, part2Node):
         assert t.dtype == torch.int32 and t.is_contiguous() and t.device == X.device
     if out is None:
-        out = torch.empty_like(X)
+        out = _fresh_output(X.shape, X.device)
     with torch.cuda.device(X.device):
         _check(fn(X.data_ptr(), _ptr(row_pointers), column_index.data_ptr(), extra,
                   part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
@@ -312,7 +320,7 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
     assert X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2
     if out is None:
         assert not accumulate, "accumulate needs an existing `out`"
-        out = torch.empty(num_out_rows, X.shape[1], dtype=torch.float32, device=X.device)
+        out = _fresh_output((num_out_rows, X.shape[1]), X.device)
     if windows is not None:
         K, wb, we = (int(v) for v in windows)
         assert wb == 0 or out is not None

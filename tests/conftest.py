@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("GNNA_DEBUG_POISON", "1")   # fresh outputs start as NaN: an element left unwritten must show
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
