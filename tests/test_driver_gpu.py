@@ -124,6 +124,8 @@ def test_drop_in_call_sequence_is_as_fast_as_the_tuned_path():
     """The reference's own call sequence -- build_part(32) and SAG(..., 32, 32, 4), no Decider, no hints, no
     calibration (GNNA_main.py:75-110 in manual mode) -- gets the sliced schedule from the library's own
     statistics and reaches >= 90 % of the Decider-tuned, calibrated configuration bench.py times."""
+    if os.environ.get("GNNA_TUNE"):
+        pytest.skip("a timing comparison of the default schedules; GNNA_TUNE forces the knobs process-wide")
     import gnnadvisor_osdi21_amd as pkg
     from gnnadvisor_osdi21_amd import _lib, graph
     from gnnadvisor_osdi21_amd.decider import calibrate_phases
@@ -167,6 +169,8 @@ def test_community_renumbering_speeds_up_the_aggregation():
     (native community renumbering) the aggregation is clearly faster than on the scrambled ids -- against the
     library's best schedule there (sliced) and, by a wide margin, against the single pass the reference's manual
     mode would run -- and equals the permuted result of the scrambled graph."""
+    if os.environ.get("GNNA_TUNE"):
+        pytest.skip("a timing comparison of the default schedules; GNNA_TUNE forces the knobs process-wide")
     from gnnadvisor_osdi21_amd import _lib, graph
     dev = torch.device("cuda")
     g = graph.make_config_graph("reddit-like", device=dev, locality=0.9)   # a ring of neighbourhoods (generator's default)
