@@ -214,7 +214,7 @@ typedef struct gnna_tuning {
     int stream_kernel;    /* 0/1 = the streaming kernel with the sliced (single-launch, stateless) schedule
                              where it applies (rows of >= 4 floats, unweighted or pre-scaled gather, no
                              source windows), 2 = always the chunk-walk kernel with per-launch column
-                             phases (round-1 schedule; kept for the per-edge GCN form and the windows) */
+                             phases (round-1 schedule; what source windows and rows narrower than 4 floats always use) */
     int zero_fill;        /* what the prologue clears before a single pass of the streaming kernel that overwrites
                              `out`: 1 = only the rows that pass does not store (rows without edges, rows shared by
                              two work items), 2 = the whole output, 0 = automatic (1 once `out` is >= 32 MiB).

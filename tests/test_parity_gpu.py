@@ -543,8 +543,8 @@ def test_stale_slice_plan_costs_locality_not_correctness():
 
 
 def test_chunk_walk_phase_selection_follows_the_hints():
-    """column_phases = 0 on the chunk-walk kernel (stream_kernel = 2; also what the per-edge GCN form and the
-    source windows use): phases only with the Decider's hints (scattered ids, high degree, big X)."""
+    """column_phases = 0 on the chunk-walk kernel (stream_kernel = 2; also what the source windows and rows
+    narrower than 4 floats use): phases only with the Decider's hints (scattered ids, high degree, big X)."""
     if _lib.get_tuning()["column_phases"] != 0:
         pytest.skip("GNNA_TUNE forces a phase count: the automatic choice is not under test")
     g = graph.make_config_graph("reddit-like", device="cuda", scale=0.25)
