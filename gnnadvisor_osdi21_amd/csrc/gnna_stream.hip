@@ -260,8 +260,14 @@ __device__ __forceinline__ int wave_inclusive_scan(int v)
     return v;
 }
 
+#ifndef GNNA_STREAM_BLOCK
+#define GNNA_STREAM_BLOCK 256
+#endif
+constexpr int kSBlock = GNNA_STREAM_BLOCK;        // threads per block of stream_kernel
+constexpr int kSWaves = kSBlock / kWave;
+
 template <int LPR, int MODE, int U, bool WIDE>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kSBlock)
 stream_kernel(const StreamParams p)
 {
     typedef typename VecOf<4>::T VT;
@@ -271,9 +277,9 @@ stream_kernel(const StreamParams p)
     constexpr int RL = (kIdSlots / RPI < kWave) ? kIdSlots / RPI : kWave;  // loads per round
     static_assert(RL % U == 0, "a round is a whole number of batches");
     // per wavefront: the round's list slots as row offsets into X (bytes; row index when X > 4 GiB)
-    __shared__ uint32_t s_off[kWavesPerBlock][RL * RPI];
+    __shared__ uint32_t s_off[kSWaves][RL * RPI];
     // MODE_GCN: the per-edge coefficient round(deg_i * deg_j) of every list slot (reference .cu:355,389)
-    __shared__ float s_cf[kWavesPerBlock][MODE == MODE_GCN ? RL * RPI : 1];
+    __shared__ float s_cf[kSWaves][MODE == MODE_GCN ? RL * RPI : 1];
     // folded rows waiting to be written: the float atomics of the sliced schedule are memory-side round
     // trips that sit in the same in-order vmcnt queue as the row loads, so a flush in the middle of the
     // stream would stall the ring until it retires.  Rows are parked here (2 KiB per wavefront) and
@@ -282,7 +288,7 @@ stream_kernel(const StreamParams p)
     constexpr int PEND_FLOATS = LPR * 4;                               // floats per parked row (one dimension sweep)
     // (MODE_SDDMM parks the round's dot products there instead: one float per list slot)
     constexpr int PEND_TOTAL = MODE == MODE_SDDMM ? RL * RPI : PEND * PEND_FLOATS;
-    __shared__ float s_pend[kWavesPerBlock][PEND_TOTAL];
+    __shared__ float s_pend[kSWaves][PEND_TOTAL];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -304,7 +310,7 @@ stream_kernel(const StreamParams p)
     const int phase = p.phase_lo + (int)((int64_t)blockIdx.x / bpp);
     int64_t item = (int64_t)blockIdx.x % bpp;
     if (p.xcd_remap) item = (item % kXcds) * (bpp / kXcds) + item / kXcds;
-    const int64_t chunk = item * kWavesPerBlock + wib;
+    const int64_t chunk = item * kSWaves + wib;
     if (chunk >= p.num_chunks) return;
     const int G = p.G;
     const int64_t g0 = chunk * G;
@@ -708,7 +714,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     p.flag = a.flag; p.P = a.P; p.seq = a.seq; p.trust = a.trust; p.D = a.D; p.ldx = a.ldx;
     p.G = std::max(1, std::min(a.G, kWave));
     p.num_chunks = (a.P + p.G - 1) / p.G;
-    int64_t items = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t items = (p.num_chunks + kSWaves - 1) / kSWaves;
     p.xcd_remap = a.xcd_remap ? 1 : 0;
     if (p.xcd_remap) items = (items + kXcds - 1) / kXcds * kXcds;
     p.blocks_per_phase = items;
@@ -723,7 +729,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, 4) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
-    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kSBlock), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
     return GNNA_OK;
