@@ -54,6 +54,14 @@ namespace {
 
 constexpr int kMaxSlices = 16;   // bytes of slice counts per group
 constexpr int kIdSlots = 512;    // at most this many column ids parked in LDS per wavefront and round
+#ifndef GNNA_NARROW_SLOTS
+#define GNNA_NARROW_SLOTS 1024
+#endif
+// (rows of <= 16 floats: 16 rows per load, so 512 slots would be only 32 loads per round; with 1024 a round holds 64
+// like every other width -- Reddit-like D = 16: 0.900 -> 0.860 ms, D = 8: 0.857 -> 0.810 ms.  Not for the modes that
+// park a second per-slot array in LDS: 3 x 16 KiB per block would cost occupancy)
+template <int LPR, int MODE>
+constexpr int id_slots() { return (LPR == 4 && MODE != MODE_GCN && MODE != MODE_SDDMM) ? GNNA_NARROW_SLOTS : kIdSlots; }
 
 struct StreamParams {
     const float *X;
@@ -274,7 +282,7 @@ stream_kernel(const StreamParams p)
     typedef typename VecOf<4>::M MT;
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
     constexpr int RPI = kWave / LPR;                                   // neighbor rows per wave-wide load
-    constexpr int RL = (kIdSlots / RPI < kWave) ? kIdSlots / RPI : kWave;  // loads per round
+    constexpr int RL = (id_slots<LPR, MODE>() / RPI < kWave) ? id_slots<LPR, MODE>() / RPI : kWave;  // loads per round
     static_assert(RL % U == 0, "a round is a whole number of batches");
     // per wavefront: the round's list slots as row offsets into X (bytes; row index when X > 4 GiB)
     __shared__ uint32_t s_off[kSWaves][RL * RPI];
@@ -597,7 +605,7 @@ template <int LPR, int MODE>
 StreamKernel pick_stream_wide(bool wide, int u)
 {
     constexpr int RPI = kWave / LPR;
-    constexpr int RL = (kIdSlots / RPI < kWave) ? kIdSlots / RPI : kWave;
+    constexpr int RL = (id_slots<LPR, MODE>() / RPI < kWave) ? id_slots<LPR, MODE>() / RPI : kWave;
     if constexpr (RL % 8 == 0) {
         if (u >= 8) return wide ? stream_kernel<LPR, MODE, 8, true> : stream_kernel<LPR, MODE, 8, false>;
     }
