@@ -544,8 +544,9 @@ int choose_row_stride(int dim)
 //    measurable when rows and columns share one numbering; a caller's "scattered ids" hint settles it otherwise;
 //  * slices of at most 8 MiB of source rows (Reddit-like graph, D = 16 / 32 / 64 / 128: best 4 / 4 / 8 / 16
 //    phases; two slices are live while the chip moves from one to the next, and an XCD's L2 is 4 MiB);
-//  * at least ~12 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses
-//    (products-like, average degree 50: best 4 phases; amazon0505-like, degree 12: none).
+//  * at least ~16 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses -- ~8 are
+//    enough for the split that makes a slice fit the Infinity Cache (products-like, average degree 50, X = 627 MB: best
+//    4 phases; amazon0505-like, degree 12: none).
 int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
                   bool square, bool hinted_scattered)
 {
@@ -577,8 +578,17 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     auto piece = [&](int l) {   // edges per (row, slice) piece: cells of one row that are adjacent merge
         return st.edges / std::max(rows, st.cells[l] - (st.groups - rows));
     };
-    while (b > 1 && lvl < 4 && piece(lvl) < 12.0) { b >>= 1; lvl++; }
-    return (lvl >= 4 && b > 1 && piece(3) < 12.0) ? 1 : std::max(b, 1);
+    // Two regimes (measured, D = 64).  Slices that fit an XCD's L2 pay from ~16 edges per (row, slice) piece -- every
+    // piece costs a flush of the row: Reddit-like shards of a 2- / 4- / 8-GPU job (246 / 369 / 430 remote edges per
+    // row, X = 119 / 238 / 477 MB) run fastest with 12-16 / 16 / 16 slices, an exchange piece with 184 edges per row
+    // in 119 MB with 8 (23 per piece), not 16 (11.5).  Slices that only fit the 256 MiB Infinity Cache still pay
+    // from ~8 edges per piece, because a miss there goes to HBM: products-like (50 edges per row, X = 627 MB) 4
+    // slices of 157 MB (12.5 per piece): 3.39 ms against 3.55 with 2 and 3.70 single pass.
+    int b_mall = 1;
+    while (b_mall < S && x_bytes / b_mall > ((size_t)160 << 20)) b_mall <<= 1;
+    while (b > 1 && lvl < 4 && piece(lvl) < 16.0 && !(b <= b_mall && piece(lvl) >= 8.0)) { b >>= 1; lvl++; }
+    if (lvl >= 4 || b <= 1) return 1;
+    return piece(lvl) >= (b <= b_mall ? 8.0 : 16.0) ? b : 1;
 }
 
 int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size)

@@ -236,10 +236,15 @@ class ShardedAggregator:
             self.remote_part = (ci_r.contiguous(), pp_r.to(self.device), p2n_r.to(self.device))
             # pipelined exchange: the remote part is split once more, by the piece of the exchange its source arrives
             # with; piece k is then an ordinary aggregation (accumulate) over its own small CSR -- it reads nothing but
-            # rows of piece k by construction, runs on the streaming kernel and keeps no state between the K calls
+            # rows of piece k by construction, runs on the streaming kernel and keeps no state between the K calls.
+            # Its column ids are relative to the piece's window of the receive buffer and the call gets that window as
+            # its source matrix: the library then slices 1/K of the buffer, not K times the range the ids cover
+            # (which made 1 - 1/K of a piece's phases empty passes over its descriptors).
             self.remote_pieces = []
+            self.piece_rows = 0
             if self.chunks > 1:
                 win = self.remote_rows // self.chunks
+                self.piece_rows = win
                 rows_r = torch.repeat_interleave(torch.arange(self.n_local, device=self.device),
                                                  (rp_r[1:] - rp_r[:-1]).to(torch.int64).to(self.device))
                 piece_of = torch.div(ci_r.to(torch.int64), win, rounding_mode="floor")
@@ -248,7 +253,8 @@ class ShardedAggregator:
                     rp_k = torch.zeros(self.n_local + 1, dtype=torch.int64, device=self.device)
                     rp_k[1:] = torch.cumsum(torch.bincount(rows_r[m], minlength=self.n_local), 0)
                     pp_k, p2n_k = build_part_fn(self.partSize, rp_k.to(torch.int32).cpu().contiguous())
-                    self.remote_pieces.append((ci_r[m].contiguous(), pp_k.to(self.device), p2n_k.to(self.device)))
+                    self.remote_pieces.append(((ci_r[m] - k * win).to(torch.int32).contiguous(), pp_k.to(self.device),
+                                               p2n_k.to(self.device)))
         else:
             self.exchange = "allgather"
         self.avg_degree_all = column_index.numel() / max(1, self.n_local)
@@ -508,13 +514,21 @@ class ShardedAggregator:
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize,
                                 degrees_local, degrees_local, epsilon, out)
         parts = self.remote_pieces if self.chunks > 1 else [self.remote_part]
-        for (ci_k, pp_k, p2n_k), work in zip(parts, works):
+        for k, ((ci_k, pp_k, p2n_k), work) in enumerate(zip(parts, works)):
             if work is not None:
                 work.wait()
             if ci_k.numel():
-                out = self.aggregate_fn(mode, X_all, ci_k, pp_k, p2n_k, self.n_local, self.partSize,
-                                        degrees_local, deg_in, epsilon, out, accumulate=True)
+                X_k, deg_k = self._piece_window(X_all, deg_in, k)
+                out = self.aggregate_fn(mode, X_k, ci_k, pp_k, p2n_k, self.n_local, self.partSize,
+                                        degrees_local, deg_k, epsilon, out, accumulate=True)
         return out
+
+    def _piece_window(self, X_all, deg_in, k):
+        """Source rows (and their degree norms) of exchange piece k: the window of the receive buffer its ids index."""
+        if self.chunks <= 1:
+            return X_all, deg_in
+        lo, hi = k * self.piece_rows, (k + 1) * self.piece_rows
+        return X_all[lo:hi], (deg_in[lo:hi] if deg_in is not None else None)
 
     # ---- the two halves of a step on their own (bench.py reports them beside the overlapped step) ----------------
     def exchange_only(self, X_local: torch.Tensor) -> None:
@@ -544,10 +558,10 @@ class ShardedAggregator:
         out = self.aggregate_fn(0, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize, None, None, 1.0, out)
         if X_all is None:
             return out
-        for ci_k, pp_k, p2n_k in (self.remote_pieces if self.chunks > 1 else [self.remote_part]):
+        for k, (ci_k, pp_k, p2n_k) in enumerate(self.remote_pieces if self.chunks > 1 else [self.remote_part]):
             if ci_k.numel():
-                out = self.aggregate_fn(0, X_all, ci_k, pp_k, p2n_k, self.n_local, self.partSize, None, None, 1.0, out,
-                                        accumulate=True)
+                out = self.aggregate_fn(0, self._piece_window(X_all, None, k)[0], ci_k, pp_k, p2n_k, self.n_local,
+                                        self.partSize, None, None, 1.0, out, accumulate=True)
         return out
 
     def calibrate(self, dims, reps: int = 3) -> dict:
@@ -573,7 +587,7 @@ class ShardedAggregator:
         if self.chunks == 1:
             res["remote"] = calibrate_phases(ci_r, pp_r, p2n_r, self.n_local, self.partSize, dims, num_in_rows=n_all)
             return res
-        res["remote"] = [calibrate_phases(ci_k, pp_k, p2n_k, self.n_local, self.partSize, dims, num_in_rows=n_all)
+        res["remote"] = [calibrate_phases(ci_k, pp_k, p2n_k, self.n_local, self.partSize, dims, num_in_rows=self.piece_rows)
                          if ci_k.numel() else {} for ci_k, pp_k, p2n_k in self.remote_pieces]
         return res
 

@@ -94,12 +94,12 @@ for W in worlds:
             rp_p = torch.zeros(n_local + 1, dtype=torch.int64, device=dev)
             rp_p[1:] = torch.cumsum(torch.bincount(rows_r[m], minlength=n_local), 0)
             pp_p, p2n_p = _lib.build_part(ps, rp_p.to(torch.int32).cpu())
-            pieces.append((ci_k[m].contiguous(), pp_p.to(dev), p2n_p.to(dev)))
+            pieces.append(((ci_k[m] - k * win).to(torch.int32).contiguous(), pp_p.to(dev), p2n_p.to(dev)))
             _lib.set_graph_hints(pieces[-1][0], max(1, int(nr / n_local / K)), True)
 
         def piecewise():
-            for ci_p, pp_p, p2n_p in pieces:
-                _lib.agg_rect(0, X_k, ci_p, pp_p, p2n_p, n_local, ps, out=out, accumulate=True)
+            for k, (ci_p, pp_p, p2n_p) in enumerate(pieces):     # ids relative to the piece's window of the buffer
+                _lib.agg_rect(0, X_k[k * win:(k + 1) * win], ci_p, pp_p, p2n_p, n_local, ps, out=out, accumulate=True)
         rec[f"remote_pieces_K{K}"] = {"ms": round(timed(piecewise) * K, 3), "phases_last": _lib.last_num_phases()}
         del X_k, ci_k, pieces
     _lib.reset_tuning()
