@@ -580,15 +580,20 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     };
     // Two regimes (measured, D = 64).  Slices that fit an XCD's L2 pay from ~16 edges per (row, slice) piece -- every
     // piece costs a flush of the row: Reddit-like shards of a 2- / 4- / 8-GPU job (246 / 369 / 430 remote edges per
-    // row, X = 119 / 238 / 477 MB) run fastest with 12-16 / 16 / 16 slices, an exchange piece with 184 edges per row
-    // in 119 MB with 8 (23 per piece), not 16 (11.5).  Slices that only fit the 256 MiB Infinity Cache still pay
-    // from ~8 edges per piece, because a miss there goes to HBM: products-like (50 edges per row, X = 627 MB) 4
-    // slices of 157 MB (12.5 per piece): 3.39 ms against 3.55 with 2 and 3.70 single pass.
-    int b_mall = 1;
-    while (b_mall < S && x_bytes / b_mall > ((size_t)160 << 20)) b_mall <<= 1;
-    while (b > 1 && lvl < 4 && piece(lvl) < 16.0 && !(b <= b_mall && piece(lvl) >= 8.0)) { b >>= 1; lvl++; }
-    if (lvl >= 4 || b <= 1) return 1;
-    return piece(lvl) >= (b <= b_mall ? 8.0 : 16.0) ? b : 1;
+    // row, X = 119 / 238 / 477 MB) run fastest with 12-16 / 16 / 16 slices (15-27 edges per piece).  Slices that
+    // only fit the 256 MiB Infinity Cache still pay from ~8 edges per piece, because a miss there goes to HBM:
+    // products-like (50 edges per row, X = 627 MB) 4 slices of 157 MB (12.5 per piece): 3.39 ms against 3.55 with 2
+    // and 3.70 single pass.  A matrix no 16 slices can bring under the Infinity Cache (BASELINE config 5's shard:
+    // 7.1 GB, 14.5 edges per row) stays single pass: 13.1 ms against 14.5 with two phases.
+    while (b > 1 && lvl < 4 && piece(lvl) < 16.0) { b >>= 1; lvl++; }
+    if (lvl >= 4) b = 1;
+    const size_t mall = (size_t)160 << 20;
+    if (x_bytes > mall) {
+        int bm = 2, lm = 3;                       // fewest slices that fit the Infinity Cache (cells[3] <-> 2 slices)
+        while (bm < S && x_bytes / bm > mall) { bm <<= 1; lm--; }
+        if (x_bytes / bm <= mall && lm >= 0 && piece(lm) >= 8.0) b = std::max(b, bm);
+    }
+    return std::max(b, 1);
 }
 
 int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size)
