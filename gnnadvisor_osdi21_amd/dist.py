@@ -117,6 +117,20 @@ def _default_aggregate(mode, X_all, column_index, part_pointers, part2Node, num_
                          degrees_out, degrees_in, epsilon, out, accumulate, windows=windows)
 
 
+def exposed_exchange_us(world: int, nnz: int, rows_per_rank: int):
+    """The time model behind the automatic piece count of the pipelined exchange (see ShardedAggregator): microseconds
+    of an all-gather of every rank's `rows_per_rank` rows that neither the local-source aggregation hides nor the
+    extra flushes of a piece-wise remote aggregation (+12 %) would eat up again; > 0 -> pipeline in pieces.
+    Width-independent (256-byte rows on both sides).  -> (microseconds, remote edges of this shard)."""
+    remote_edges = nnz * (world - 1) // max(1, world)
+    local_edges = nnz - remote_edges
+    received_rows = (world - 1) * rows_per_rank
+    t_exchange = received_rows * 256.0 / (60e9 * max(1, min(world - 1, 7)))
+    t_local = local_edges / 60e9
+    t_remote = remote_edges / 45e9
+    return int(1e6 * (t_exchange - t_local - 0.12 * t_remote)), remote_edges
+
+
 def _default_hints(column_index: torch.Tensor, avg_degree: float, nonlocal_ids: bool) -> None:
     """Tell libgnna what kind of CSR this column_index array belongs to (enables its column-phased
     schedule for high-degree parts whose sources are scattered).  Registered once per part."""
@@ -179,20 +193,24 @@ class ShardedAggregator:
             self.overlap = True                                  # the halo buffer holds remote rows only
         K = int(pipeline_chunks)
         if K <= 0:
-            # Pipelining the exchange pays when the exchange is long next to the aggregation it feeds: the windowed
-            # aggregation hides all but the last piece's work behind the wire, but it runs on the chunk-walk kernel,
-            # which is ~20 % slower than the one-call streaming kernel on the remote part (one-GPU emulation of an
-            # 8-rank Reddit-sized shard: 2.85 vs 2.29 ms).  Both times scale with the feature width, so the ratio is
-            # a graph property: received rows per remote edge.  xGMI ingress ~0.6 TB/s against ~12 TB/s of gather
-            # rate puts the break-even near 1 received row per 40 remote edges (Reddit-like shards: 1 per 65 ->
-            # one piece; papers100M-like: 1 per 1.8 -> four pieces).
-            # Every rank must arrive at the same K (it fixes the layout and the number of collectives per step), so
-            # the decision is taken collectively on the most exchange-heavy and the largest shard.
-            remote_edges = column_index.numel() * (self.world - 1) // max(1, self.world)
-            received_rows = (self.world - 1) * self.rows_per_rank
-            heaviness = self._agree_max(int(1000.0 * received_rows / max(1, remote_edges)))
+            # Pipelining the exchange pays when the wire time the local-source part cannot hide exceeds what the pieces
+            # cost: K piece calls flush every destination row K times (one-GPU emulation of Reddit-sized shards,
+            # tools/probe_dist_emul.py: remote part in one call / in 4 pieces 1.01 / 1.12 ms at 2 ranks, 1.62 / 1.91
+            # at 4, 2.28 / 2.36 at 8 -- taken as +12 %).  A time model, in units that do not depend on the feature
+            # width (both sides scale with it; 256-byte rows): the exchange moves `received_rows` rows over
+            # min(world - 1, 7) xGMI links at ~60 GB/s each (76.8 GB/s per direction, RCCL reaches ~80 %); the
+            # local part gathers ~60 G edges/s, the remote part, whose source matrix is world times larger, ~45.
+            #   2 ranks: 0.99 ms of exchange behind 0.95 ms of local work -> one piece;
+            #   4 ranks: 0.99 vs 0.48 ms, the remaining 0.5 ms exceed the pieces' 0.23 ms -> four pieces;
+            #   8 ranks: 0.99 vs 0.24 ms -> four pieces (2.7 instead of ~3.3 ms per step in the model);
+            #   papers100M-like shards (14.5 edges per row): the exchange dwarfs the aggregation -> four pieces.
+            # The constants are estimates until a multi-GPU run measures the exchange (`exchange_only_ms` in the
+            # bench line).  Every rank must arrive at the same K (it fixes the layout and the number of collectives
+            # per step), so the decision is taken collectively on the most exchange-bound and the largest shard.
+            mine_us, remote_edges = exposed_exchange_us(self.world, int(column_index.numel()), self.rows_per_rank)
+            exposed_us = self._agree_max(mine_us)
             largest = self._agree_max(remote_edges)
-            K = 4 if (self.world > 1 and largest >= (16 << 20) and heaviness > 25) else 1
+            K = 4 if (self.world > 1 and largest >= (16 << 20) and exposed_us > 0) else 1
         self.chunks = max(1, min(K, 16, self.rows_per_rank)) if self.overlap else 1
         assert self._agree_max(self.chunks) == self.chunks == -self._agree_max(-self.chunks), \
             "ranks disagree on the number of exchange pieces"

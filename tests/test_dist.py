@@ -179,6 +179,19 @@ def test_automatic_piece_count_is_agreed_between_ranks():
     assert all(ok for _, ok in _run_ranks(_uneven_k_worker, ()))
 
 
+def test_piece_count_model_on_the_bench_shapes():
+    """The automatic piece count of the pipelined exchange (time model, dist.exposed_exchange_us): Reddit-sized
+    weak-scaling shards hide the exchange behind the local-source part at 2 ranks and do not at 4 and 8;
+    a papers100M-like shard (14.5 edges per row) is exchange-bound at any size."""
+    from gnnadvisor_osdi21_amd.dist import exposed_exchange_us
+    n, nnz = 232965, 114623790
+    assert exposed_exchange_us(2, nnz, n)[0] <= 0
+    assert exposed_exchange_us(4, nnz, n)[0] > 0 and exposed_exchange_us(8, nnz, n)[0] > 0
+    assert exposed_exchange_us(8, 196094012, 13882494)[0] > 0
+    assert exposed_exchange_us(2, 196094012, 13882494)[0] > 0
+    assert exposed_exchange_us(1, nnz, n) == (int(-1e6 * nnz / 60e9), 0)
+
+
 def test_balanced_splits_and_remap():
     rp = torch.tensor([0, 10, 10, 11, 30, 31, 40], dtype=torch.int32)
     b = balanced_row_splits(rp, 2)
