@@ -693,6 +693,10 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     if (num_windows < 1 || num_windows > 16 || win_begin < 0 || win_end > num_windows || win_begin >= win_end)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "bad source window range [%d, %d) of %d (at most 16 windows)",
                     win_begin, win_end, num_windows);
+    // (the kernels carry a destination row together with two flag bits in one 32-bit register)
+    if (num_nodes >= ((int64_t)1 << 29))
+        return fail(GNNA_ERR_UNSUPPORTED, "%lld destination rows in one call (at most 536870911): shard the rows",
+                    (long long)num_nodes);
     if (num_nodes == 0 || dim == 0) return GNNA_OK;
     if (!out || !input) return fail(GNNA_ERR_INVALID_ARGUMENT, "null feature pointer");
     if (num_parts > 0 && (!column_index || !part_pointers || !part2Node))

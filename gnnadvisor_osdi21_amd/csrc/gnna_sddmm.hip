@@ -166,6 +166,9 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
 {
     if (num_out_rows < 0 || num_in_rows < 0 || dim < 0 || num_parts < 0)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size");
+    if (num_out_rows >= ((int64_t)1 << 29))   // (a destination row travels with two flag bits in one 32-bit register)
+        return fail(GNNA_ERR_UNSUPPORTED, "%lld destination rows in one call (at most 536870911): shard the rows",
+                    (long long)num_out_rows);
     if (num_parts == 0 || dim == 0) return GNNA_OK;
     if (dim < 4) return fail(GNNA_ERR_UNSUPPORTED, "sddmm needs dim >= 4 (got %d)", dim);
     if (!dst_feat || !src_feat || !column_index || !part_pointers || !part2Node || !edge_out)

@@ -117,6 +117,8 @@ GNNA_API int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, 
  * row_pointers and (for sag) degrees are accepted for signature parity and unused, as
  * in the reference kernels.
  */
+/* Limits of one call (GNNA_ERR_UNSUPPORTED beyond them): fewer than 2^29 destination rows, fewer than 2^31 edges
+ * (int32 CSR), source matrices of any size (64-bit row offsets above 4 GiB). */
 GNNA_API int gnna_sag_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
                  const float *degrees, const int32_t *part_pointers, const int32_t *part2Node,
                  float *out, int64_t num_nodes, int dim, int64_t num_parts,

@@ -249,6 +249,11 @@ def test_invalid_arguments_are_reported():
         _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 4, 32, 4, out=Xd)
     with pytest.raises(_lib.GnnaError):
         _lib.sag(X, rp, ci, deg, ppd, p2nd, 4, 32, 4)   # CPU tensor: no CPU path
+    # more destination rows than a call can carry: refused before anything is touched
+    L = _lib.load()
+    rc = L.gnna_sag_f32(Xd.data_ptr(), rp.data_ptr(), ci.data_ptr(), deg.data_ptr(), ppd.data_ptr(), p2nd.data_ptr(),
+                        Xd.data_ptr() + 4096, 1 << 29, 8, p2nd.numel(), 4, 32, 4, None)
+    assert rc == -3 and b"536870911" in L.gnna_last_error()
 
 
 def test_full_size_reddit_like_properties():
