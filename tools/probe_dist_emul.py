@@ -101,6 +101,12 @@ for W in worlds:
             for k, (ci_p, pp_p, p2n_p) in enumerate(pieces):     # ids relative to the piece's window of the buffer
                 _lib.agg_rect(0, X_k[k * win:(k + 1) * win], ci_p, pp_p, p2n_p, n_local, ps, out=out, accumulate=True)
         rec[f"remote_pieces_K{K}"] = {"ms": round(timed(piecewise) * K, 3), "phases_last": _lib.last_num_phases()}
+        sweep = {}
+        for B in (1, 2, 4, 8, 16):
+            _lib.set_tuning(column_phases=B)
+            sweep[B] = round(timed(piecewise, reps=4) * K, 3)
+        rec[f"remote_pieces_K{K}_sweep"] = sweep
+        _lib.reset_tuning()
         del X_k, ci_k, pieces
     _lib.reset_tuning()
     rec["edges_per_s_overlap_kernels_only"] = nnz / ((rec["local_auto"]["ms"] + rec["remote_auto"]["ms"]) * 1e-3)
