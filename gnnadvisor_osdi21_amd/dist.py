@@ -24,7 +24,8 @@ backend "nccl" == RCCL over xGMI):
   sources travel in piece k is aggregated as soon as piece k has arrived.  (Round 1 used one CSR and the
   windowed entry ``gnna_agg_rect_windows_f32``, whose per-run cursors live in library scratch between the K
   calls; the remote part is now split into K small CSRs at construction, each an ordinary stateless
-  aggregation on the streaming kernel.)
+  aggregation on the streaming kernel whose column ids index the piece's own window of the receive buffer.)
+  ``pipeline_chunks = 0`` decides K from a time model of the exchange (``exposed_exchange_us``).
 * halo exchange (``exchange="halo"``; ``"auto"`` picks it when it moves clearly fewer bytes): instead of
   whole blocks, every rank receives only the remote source rows its shard actually references.  The
   unique remote ids per owner are found once, the owners learn which of their rows each peer needs
