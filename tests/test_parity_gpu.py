@@ -375,10 +375,11 @@ def test_config5_papers100M_like_shard():
 
 
 @pytest.mark.parametrize("phases", [2, 3, 8, 16])
-@pytest.mark.parametrize("partSize,dim", [(32, 64), (7, 16), (64, 100), (100, 8), (32, 257), (8, 602)])
+@pytest.mark.parametrize("partSize,dim", [(32, 64), (7, 16), (64, 100), (100, 8), (32, 257), (8, 602), (700, 64), (2000, 16)])
 def test_column_phased_schedule_matches_single_pass(phases, partSize, dim):
     """The column-phased schedule (X gathered in `phases` source-id ranges, one launch each)
-    must give the same answer as the single pass, in every mode."""
+    must give the same answer as the single pass, in every mode.  (partSize 700 / 2000: groups of more than 255
+    edges -- the sliced plan's cumulative byte counts saturate there, which may only cost locality.)"""
     g, X, pp, p2n = make_case(1500, 90000, dim, partSize, seed=phases * 100 + dim, kind="powerlaw")
     try:
         _lib.set_tuning(column_phases=phases)
