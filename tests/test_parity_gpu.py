@@ -837,7 +837,8 @@ def test_weight_gradient_kernel_matches_fp64(M, K, N):
 
 
 @pytest.mark.parametrize("dim,partSize,phases,sorted_ids", [(64, 32, 3, True), (16, 8, 5, True), (41, 64, 2, True),
-                                                            (300, 16, 4, True), (64, 32, 4, False), (64, 1, 16, True)])
+                                                            (300, 16, 4, True), (64, 32, 4, False), (64, 1, 16, True),
+                                                            (64, 600, 8, True), (16, 600, 16, False)])
 def test_sddmm_column_phases_match_single_pass(dim, partSize, phases, sorted_ids):
     """SDDMM with the column-phased schedule (per-run cursors): every edge written exactly once, for
     sorted and shuffled column ids, partitions whose rows span several groups, and empty rows."""
