@@ -533,44 +533,51 @@ stream_kernel(const StreamParams p)
             }
 #pragma unroll
             for (int u = 0; u < U; u++) v[u] = *row_ptr(offs[u * RPI + slot]);
+            auto consume = [&](int u, int j) {
+                if ((TM >> j) & 1ull) {
+                    const int vj = __builtin_amdgcn_readlane(v_j, j);
+                    if (slot >= vj) v[u] = vzero<4>();
+                }
+                if constexpr (MODE == MODE_GCN) {
+                    // the reference rounds coef * x and the accumulation separately (__fmaf_rn(c, x, 0) then +=,
+                    // .cu:405); this file is built with -ffp-contract=off
+                    const VT tmp = v[u] * cfs[j * RPI + slot];
+                    acc += tmp;
+                } else {
+                    acc += v[u];
+                }
+                if ((FL >> j) & 1ull) {
+                    const int meta = __builtin_amdgcn_readlane(k_meta, j);
+                    float scale = p.eps;
+                    if constexpr (MODE == MODE_GIN) {
+                        if (p.row_scale) scale *= p.row_scale[meta >> 2];
+                    }
+                    const VT r = fold_row<LPR, MODE>(acc, scale);
+                    if (npend == PEND) { drain(); }
+                    park_row<LPR>(r, pend + npend * PEND_FLOATS, dcol - d0, cvalid, lane, slot);
+                    pend_meta = lane == npend ? meta : pend_meta;
+                    npend++;
+                    acc = vzero<4>();
+                }
+            };
+            // all batches but the last: consume a load, request the one U positions ahead
 #pragma unroll 1
-            for (int b = 0; b < nb; b++) {
-                const int jn = (b + 1 < nb ? b + 1 : nb - 1) * U;   // the last batch re-requests its own (hot) rows
+            for (int b = 0; b + 1 < nb; b++) {
+                const int jn = (b + 1) * U;
                 uint32_t nn[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) nn[u] = offs[(jn + u) * RPI + slot];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    const int j = b * U + u;
-                    if (j < nr) {
-                        if ((TM >> j) & 1ull) {
-                            const int vj = __builtin_amdgcn_readlane(v_j, j);
-                            if (slot >= vj) v[u] = vzero<4>();
-                        }
-                        if constexpr (MODE == MODE_GCN) {
-                            // the reference rounds coef * x and the accumulation separately (__fmaf_rn(c, x, 0) then +=,
-                            // .cu:405); this file is built with -ffp-contract=off
-                            const VT tmp = v[u] * cfs[j * RPI + slot];
-                            acc += tmp;
-                        } else {
-                            acc += v[u];
-                        }
-                        if ((FL >> j) & 1ull) {
-                            const int meta = __builtin_amdgcn_readlane(k_meta, j);
-                            float scale = p.eps;
-                            if constexpr (MODE == MODE_GIN) {
-                                if (p.row_scale) scale *= p.row_scale[meta >> 2];
-                            }
-                            const VT r = fold_row<LPR, MODE>(acc, scale);
-                            if (npend == PEND) { drain(); }
-                            park_row<LPR>(r, pend + npend * PEND_FLOATS, dcol - d0, cvalid, lane, slot);
-                            pend_meta = lane == npend ? meta : pend_meta;
-                            npend++;
-                            acc = vzero<4>();
-                        }
-                    }
+                    consume(u, b * U + u);
                     v[u] = *row_ptr(nn[u]);
                 }
+            }
+            // the last batch only consumes (its slots past the round's end hold row 0 and are skipped)
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int j = (nb - 1) * U + u;
+                if (j < nr) consume(u, j);
             }
             if (npend > PEND / 2 || r0 + RL >= L) drain();   // between rounds: nothing of the ring waits behind these
         }
