@@ -492,30 +492,35 @@ stream_kernel(const StreamParams p)
                 VT a[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) { a[u] = *a_ptr(u); v[u] = *row_ptr(offs[u * RPI + slot]); }
+                auto dot_of = [&](int u, int j) {
+                    VT av = a[u];
+                    // components that overlap the previous piece (ragged D) and lanes past the row end do not count
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (!cvalid || k < shift) av[k] = 0.f;
+                    const VT prod = v[u] * av;
+                    float dot = lane_group_sum<LPR>((prod[0] + prod[1]) + (prod[2] + prod[3]));
+                    // parked in LDS (the round's list slot of the edge) and written out after the round: a
+                    // 16-byte store per load in the middle of the stream would sit in the ring's vmcnt queue
+                    if (c == 0) pend[j * RPI + slot] = dot;
+                };
 #pragma unroll 1
-                for (int b = 0; b < nb; b++) {
-                    const int jn = (b + 1 < nb ? b + 1 : nb - 1) * U;
+                for (int b = 0; b + 1 < nb; b++) {
+                    const int jn = (b + 1) * U;
                     uint32_t nn[U];
 #pragma unroll
                     for (int u = 0; u < U; u++) nn[u] = offs[(jn + u) * RPI + slot];
 #pragma unroll
                     for (int u = 0; u < U; u++) {
-                        const int j = b * U + u;
-                        if (j < nr) {
-                            VT av = a[u];
-                            // components that overlap the previous piece (ragged D) and lanes past the row end do not count
-#pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (!cvalid || k < shift) av[k] = 0.f;
-                            const VT prod = v[u] * av;
-                            float dot = lane_group_sum<LPR>((prod[0] + prod[1]) + (prod[2] + prod[3]));
-                            // parked in LDS (the round's list slot of the edge) and written out after the round: a
-                            // 16-byte store per load in the middle of the stream would sit in the ring's vmcnt queue
-                            if (c == 0) pend[j * RPI + slot] = dot;
-                        }
+                        dot_of(u, b * U + u);
                         a[u] = *a_ptr(jn + u);
                         v[u] = *row_ptr(nn[u]);
                     }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {      // the last batch only consumes
+                    const int j = (nb - 1) * U + u;
+                    if (j < nr) dot_of(u, j);
                 }
 #pragma unroll
                 for (int q = 0; q < (RL * RPI + kWave - 1) / kWave; q++) {
