@@ -27,7 +27,8 @@ class Tuning(ctypes.Structure):
                 ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
                 ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int),
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
-                ("pad_rows", ctypes.c_int), ("stream_kernel", ctypes.c_int), ("zero_fill", ctypes.c_int)]
+                ("pad_rows", ctypes.c_int), ("stream_kernel", ctypes.c_int), ("zero_fill", ctypes.c_int),
+                ("sweep", ctypes.c_int), ("sweep_slack", ctypes.c_int)]
 
 
 _lib = None
@@ -42,7 +43,8 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
-           "gnna_last_num_launches", "gnna_reorder_community_i32")
+           "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
+           "gnna_runtime_counters")
 
 
 def load() -> ctypes.CDLL:
@@ -104,6 +106,14 @@ def load() -> ctypes.CDLL:
     L.gnna_sddmm_f32.restype = ctypes.c_int
     L.gnna_sddmm_f32.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                                         ctypes.c_int, ctypes.c_void_p]
+    L.gnna_prepare_graph.restype = ctypes.c_int
+    L.gnna_prepare_graph.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_int64, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
+    L.gnna_release_graph.restype = ctypes.c_int
+    L.gnna_release_graph.argtypes = [ctypes.c_void_p]
+    L.gnna_runtime_counters.restype = None
+    L.gnna_runtime_counters.argtypes = [ctypes.POINTER(ctypes.c_int64)]
     L.gnna_profile_begin.restype = ctypes.c_int
     L.gnna_profile_begin.argtypes = [ctypes.c_int]
     L.gnna_profile_end.restype = ctypes.c_int
@@ -128,9 +138,9 @@ def _stream(device: torch.device) -> int:
 
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
-               pad_rows=-1, stream_kernel=-1, zero_fill=-1) -> None:
+               pad_rows=-1, stream_kernel=-1, zero_fill=-1, sweep=-1, sweep_slack=-1) -> None:
     t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
-               avg_degree, nonlocal_ids, gcn_prescale, pad_rows, stream_kernel, zero_fill)
+               avg_degree, nonlocal_ids, gcn_prescale, pad_rows, stream_kernel, zero_fill, sweep, sweep_slack)
     load().gnna_set_tuning(ctypes.byref(t))
 
 
@@ -138,16 +148,22 @@ def reset_tuning() -> None:
     load().gnna_set_tuning(None)
 
 
-_registered: dict = {}      # device address -> token of the tensor that registered hints / schedules for it
+_registered: dict = {}      # device address -> token of the storage that registered hints / schedules for it
 
 
 def _forget_when_freed(column_index) -> None:
-    """libgnna keys its per-graph table by the device address of `column_index`; PyTorch's caching allocator
-    hands that address to an unrelated tensor once this one is freed.  Drop the entry together with the
-    tensor (unless a newer tensor has registered the same address in the meantime)."""
+    """libgnna keys its per-graph tables by the device address of `column_index`; PyTorch's caching allocator
+    hands that address to an unrelated tensor once this one is freed.  Drop the entries together with the
+    memory.  The finalizer hangs on the tensor's STORAGE, not on the Python tensor object: hints registered
+    through a temporary alias (a view, a slice, `.detach()`) must live as long as the graph does, not as long as
+    the alias (unless a newer storage has registered the same address in the meantime)."""
     import weakref
     ptr = column_index.data_ptr()
-    token = object()
+    storage = column_index.untyped_storage()
+    token = _registered.get(ptr)
+    if token is not None and token[0]() is storage:
+        return                                           # this storage already carries the finalizer for `ptr`
+    token = (weakref.ref(storage),)
     _registered[ptr] = token
 
     def drop(ptr=ptr, token=token):
@@ -155,7 +171,8 @@ def _forget_when_freed(column_index) -> None:
             del _registered[ptr]
             if _lib is not None:
                 _lib.gnna_set_graph_hints(ptr, 0, 0)
-    weakref.finalize(column_index, drop)
+                _lib.gnna_release_graph(ptr)
+    weakref.finalize(storage, drop)
 
 
 def set_graph_hints(column_index, avg_degree: float, nonlocal_ids: bool) -> None:
@@ -339,10 +356,43 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
     return out
 
 
+def prepare_graph(column_index, part_pointers, part2Node, num_in_rows: int, num_out_rows: int, partSize: int,
+                  dims=()) -> dict:
+    """gnna_prepare_graph: counting pass, statistics, phase choice per width and scratch sizing up front (one stream
+    synchronisation here, none in any later aggregation on this graph); the plan stays until the column_index storage
+    is freed or `release_graph`.  -> {dim: phases the library will use}."""
+    dims = [int(d) for d in dims]
+    arr = (ctypes.c_int * max(1, len(dims)))(*dims)
+    out = (ctypes.c_int * max(1, len(dims)))()
+    with torch.cuda.device(column_index.device):
+        _check(load().gnna_prepare_graph(column_index.data_ptr(), part_pointers.data_ptr(), part2Node.data_ptr(),
+                                         part2Node.numel(), int(num_in_rows), int(num_out_rows), int(partSize),
+                                         arr, len(dims), out, _stream(column_index.device)))
+    _forget_when_freed(column_index)
+    return {d: int(out[i]) for i, d in enumerate(dims)}
+
+
+def release_graph(column_index) -> None:
+    """Drops the library's plans, hints and measured schedules for this graph (None: all graphs)."""
+    ptr = None if column_index is None else column_index.data_ptr()
+    _check(load().gnna_release_graph(ptr))
+    if column_index is None:
+        _registered.clear()
+    else:
+        _registered.pop(ptr, None)
+
+
+def runtime_counters() -> dict:
+    out = (ctypes.c_int64 * 8)()
+    load().gnna_runtime_counters(out)
+    names = ("plan_builds", "launch_syncs", "launch_frees", "launch_mallocs", "backoff_skips", "sweep_launches")
+    return {n: int(out[i]) for i, n in enumerate(names)}
+
+
 def set_graph_phases(column_index, dim: int, column_phases: int) -> None:
     """Measured schedule for `dim`-wide aggregations on this graph (0 removes it); see include/gnna.h."""
     _check(load().gnna_set_graph_phases(column_index.data_ptr(), int(dim), int(column_phases)))
-    if column_phases > 0 and column_index.data_ptr() not in _registered:
+    if column_phases > 0:
         _forget_when_freed(column_index)
 
 

@@ -26,7 +26,8 @@ EXT = os.path.join(PKG, "GNNAdvisor.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-LIB_SOURCES = [os.path.join(CSRC, f) for f in ("gnna_agg.hip", "gnna_stream.hip", "gnna_sddmm.hip", "gnna_gemm.hip", "gnna_runtime.hip", "gnna_host.cpp", "gnna_reorder.cpp")]
+LIB_SOURCES = [os.path.join(CSRC, f) for f in ("gnna_agg.hip", "gnna_stream.hip", "gnna_sweep.hip", "gnna_sddmm.hip", "gnna_gemm.hip",
+                                                "gnna_runtime.hip", "gnna_host.cpp", "gnna_reorder.cpp")]
 LIB_DEPS = LIB_SOURCES + [os.path.join(CSRC, "gnna_internal.h"), os.path.join(CSRC, "gnna_device.h"),
                            os.path.join(INCLUDE, "gnna.h")]
 EXT_SOURCES = [os.path.join(CSRC, "gnna_torch.cpp")]
@@ -41,13 +42,29 @@ def _stale(target: str, deps: list[str]) -> bool:
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if force or _stale(LIB, LIB_DEPS):
-        cmd = [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-               "-munsafe-fp-atomics", "-ffp-contract=off", "-fvisibility=hidden",
-               "-I" + INCLUDE, "-I" + CSRC, *LIB_SOURCES, "-o", LIB]
+    """One object per source (compiled in parallel, only the stale ones), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [d for d in LIB_DEPS if d not in LIB_SOURCES]
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
+             "-fvisibility=hidden", "-I" + INCLUDE, "-I" + CSRC]
+    jobs, objs = [], []
+    for src in LIB_SOURCES:
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [src] + headers):
+            jobs.append([HIPCC, *flags, "-c", src, "-o", obj])
+
+    def run(cmd):
         if verbose:
-            print(" ".join(cmd))
+            print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", LIB])
     return LIB
 
 

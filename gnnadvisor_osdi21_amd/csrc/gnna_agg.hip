@@ -538,7 +538,7 @@ int choose_row_stride(int dim)
 }  // namespace
 
 // Number of phases of the sliced schedule from the slice statistics of the partition (st.cells[l] =
-// non-empty (group, slice) cells when the 16 fine slices are merged into 16 >> l).
+// non-empty (group, slice) cells when the S = 32 fine slices are merged into S >> l).
 //  * not at all when the column ids of a row stay near the row (>= 60 % of the edges within a window of source
 //    rows that fits an XCD's L2: a locality-ordered graph gathers from a small moving window already) --
 //    measurable when rows and columns share one numbering; a caller's "scattered ids" hint settles it otherwise;
@@ -585,11 +585,14 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     // products-like (50 edges per row, X = 627 MB) 4 slices of 157 MB (12.5 per piece): 3.39 ms against 3.55 with 2
     // and 3.70 single pass.  A matrix no 16 slices can bring under the Infinity Cache (BASELINE config 5's shard:
     // 7.1 GB, 14.5 edges per row) stays single pass: 13.1 ms against 14.5 with two phases.
-    while (b > 1 && lvl < 4 && piece(lvl) < 16.0) { b >>= 1; lvl++; }
-    if (lvl >= 4) b = 1;
+    int levels = 0;                               // cells[l] <-> S >> l slices, l = 0 .. levels - 1 (down to 2 slices)
+    for (int t = S; t > 1; t >>= 1) levels++;
+    levels = std::min(levels, kSliceLevels);
+    while (b > 1 && lvl < levels && piece(lvl) < 16.0) { b >>= 1; lvl++; }
+    if (lvl >= levels) b = 1;
     const size_t mall = (size_t)160 << 20;
     if (x_bytes > mall) {
-        int bm = 2, lm = 3;                       // fewest slices that fit the Infinity Cache (cells[3] <-> 2 slices)
+        int bm = 2, lm = levels - 1;              // fewest slices that fit the Infinity Cache (cells[levels - 1] <-> 2 slices)
         while (bm < S && x_bytes / bm > mall) { bm <<= 1; lm--; }
         if (x_bytes / bm <= mall && lm >= 0 && piece(lm) >= 8.0) b = std::max(b, bm);
     }
@@ -600,7 +603,7 @@ int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, in
 {
     int b = 1;
     if (tune.column_phases >= 1) {
-        b = std::min(tune.column_phases, 16);
+        b = std::min(tune.column_phases, 16);   // (chunk-walk kernel: one launch per phase)
     } else if (tune.nonlocal_ids == 1 && tune.avg_degree > 0) {
         // measured optimum on the Reddit-like graph, D = 16 / 32 / 40 / 48 / 64 / 96 / 128:
         // 2 / 2 / 3 / 3-4 / 4 / 5 / 8 phases, i.e. one phase per ~14 MB of X, two from 12 MB on
@@ -815,21 +818,53 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     if (vec == 4 && num_windows == 1 && tune.stream_kernel != 2) {
         int B = 1;
         const uint8_t *cnt = nullptr;
-        const int S = 16;
-        const uint32_t slice_rows = (uint32_t)std::max<int64_t>(1, (num_in_rows + S - 1) / S);
+        int S = kMaxSlices;
+        SlicePlan plan;
         const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && x_bytes >= ((size_t)2 << 20);
-        if (tune.column_phases >= 2 && num_in_rows >= S) {
-            B = std::min(tune.column_phases, S);
-            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, false, &cnt, nullptr);
+        if (tune.column_phases >= 2 && num_in_rows >= kMaxSlices) {
+            B = std::min(tune.column_phases, kMaxSlices);
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, false, false, &plan);
             if (rc != GNNA_OK) return rc;
         } else if (tune.column_phases == 0 && can_slice && x_bytes >= ((size_t)6 << 20)) {
-            SlicePlanStats st;
-            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, true, &cnt, &st);
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, false, &plan);
             if (rc != GNNA_OK) return rc;
-            if (cnt && st.valid)
-                B = choose_slices(st, x_bytes, S, slice_rows, num_nodes, num_in_rows == num_nodes, tune.nonlocal_ids == 1);
+            if (plan.cnt && plan.stats.valid)
+                B = choose_slices(plan.stats, x_bytes, plan.S, plan.slice_rows, num_nodes, num_in_rows == num_nodes,
+                                  tune.nonlocal_ids == 1);
         }
+        cnt = plan.cnt;
+        if (cnt) S = plan.S;
         if (!cnt || B < 2) { B = 1; cnt = nullptr; }
+        // Destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
+        // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
+        if (cnt && tune.sweep == 1 && sweep_supports(mode, dim, x_bytes)) {
+            int Bs = B;
+            if (tune.column_phases < 2) {             // not forced: slices of about half an XCD's L2
+                Bs = 2;
+                while (Bs < S && x_bytes / Bs > ((size_t)2 << 20)) Bs <<= 1;
+            }
+            rc = run_prologue(0);
+            if (rc != GNNA_OK) return rc;
+            uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * (kXcds * 16);
+            hipError_t em = hipMemsetAsync(sync, 0, kXcds * 16 * sizeof(uint32_t), stream);
+            if (em != hipSuccess) return fail(GNNA_ERR_HIP, "sweep counters: %s", hipGetErrorString(em));
+            SweepLaunch w;
+            w.mode = mode; w.X = p.X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;
+            w.cnt = cnt; w.row_scale = p.row_scale; w.flag = flag; w.seq = seq; w.trust = p.trust; w.sync = sync;
+            w.P = num_parts; w.D = dim; w.ldx = ldx; w.U = tune.loads_in_flight; w.S = S; w.B = Bs;
+            const double rows_with_edges = plan.stats.valid ? std::min((double)num_nodes, plan.stats.groups) : (double)num_nodes;
+            const double rows_per_chunk = rows_with_edges / std::max<double>(1.0, (double)((num_parts + kWave - 1) / kWave)) + 1.0;
+            w.K = std::max(1, std::min(4, (int)((double)sweep_acc_rows(dim) / rows_per_chunk)));
+            if (tune.groups_per_chunk > 64) w.K = std::min(4, tune.groups_per_chunk / 64);   // experiments: G = 64 * K
+            w.slack = tune.sweep_slack; w.blocks_per_cu = tune.blocks_per_cu;
+            w.plain_ok = !accumulate_into_out; w.eps = p.eps;
+            t_last_phases = Bs;
+            t_last_launches = 1;
+            rc = launch_sweep(ds, w, stream);
+            if (rc != GNNA_OK) return rc;
+            profile_record(prof_call, 2, stream);
+            return GNNA_OK;
+        }
         t_last_phases = B;
         StreamLaunch a;
         a.mode = mode; a.X = p.X; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node; a.Y = out;
@@ -949,6 +984,67 @@ int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows,
     return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
                       part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0,
                       num_windows, window_begin, window_end);
+}
+
+int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers, const int32_t *part2Node,
+                       int64_t num_parts, int64_t num_in_rows, int64_t num_out_rows, int partSize,
+                       const int *dims, int num_dims, int *phases_out, void *stream_v)
+{
+    if (num_parts < 0 || num_in_rows < 0 || num_out_rows < 0 || partSize <= 0 || num_dims < 0 || (num_dims > 0 && !dims))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_prepare_graph: bad argument");
+    for (int i = 0; i < num_dims; i++)
+        if (phases_out) phases_out[i] = 1;
+    if (num_parts == 0) return GNNA_OK;
+    if (!column_index || !part_pointers || !part2Node) return fail(GNNA_ERR_INVALID_ARGUMENT, "null index pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    if (cap != hipStreamCaptureStatusNone)
+        return fail(GNNA_ERR_UNSUPPORTED, "gnna_prepare_graph synchronises and allocates: call it before the capture");
+    DeviceState *ds = nullptr;
+    int rc = get_device_state(&ds);
+    if (rc != GNNA_OK) return rc;
+    SlicePlan plan;
+    rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, true, &plan);
+    if (rc != GNNA_OK) return rc;
+    if (!plan.cnt || !plan.stats.valid) return fail(GNNA_ERR_HIP, "gnna_prepare_graph: the slice plan could not be built");
+    gnna_tuning tune;
+    gnna_get_tuning(&tune);
+    const bool hot = plan.stats.edges >= 32.0 * (double)num_in_rows;
+    size_t staged = 0;
+    for (int i = 0; i < num_dims; i++) {
+        const int dim = dims[i];
+        if (dim <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_prepare_graph: dims[%d] = %d", i, dim);
+        gnna_tuning t = tune;
+        apply_graph_hints(column_index, dim, &t);
+        const size_t raw = (size_t)num_in_rows * (size_t)dim * sizeof(float);
+        const bool hot_rows = hot && raw <= ((size_t)1 << 30);
+        int ldx = dim;
+        if (t.pad_rows == 1 || (t.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);
+        const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);
+        if (hot_rows || t.gcn_prescale == 1 || ldx != dim) staged = std::max(staged, x_bytes);   // (GCN pre-scaling stages too)
+        int B = 1;
+        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && x_bytes >= ((size_t)2 << 20);
+        if (dim >= 4 && t.stream_kernel != 2) {
+            if (t.column_phases >= 2 && num_in_rows >= kMaxSlices) B = std::min(t.column_phases, kMaxSlices);
+            else if (t.column_phases == 0 && can_slice && x_bytes >= ((size_t)6 << 20))
+                B = choose_slices(plan.stats, x_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,
+                                  t.nonlocal_ids == 1);
+        }
+        if (phases_out) phases_out[i] = std::max(1, B);
+    }
+    if (staged) {
+        void *ws = nullptr;
+        rc = get_workspace(ds, stream, 1, staged, &ws);
+        if (rc != GNNA_OK) return rc;
+    }
+    return GNNA_OK;
+}
+
+int gnna_release_graph(const int32_t *column_index)
+{
+    (void)release_slice_plans(column_index);
+    return gnna_set_graph_hints(column_index, 0, 0);
 }
 
 int gnna_last_num_phases(void) { return t_last_phases; }

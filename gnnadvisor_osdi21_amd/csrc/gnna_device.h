@@ -102,6 +102,55 @@ __device__ __forceinline__ void vset(typename VecOf<VEC>::T &v, int k, float x)
     if constexpr (VEC == 1) v = x; else v[k] = x;
 }
 
+// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (no LDS round trips).
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+
+// fold_row: folds the RPI slots of `acc`.  LPR <= 16: reduce-scatter with v_permlane32_swap /
+// v_permlane16_swap (+ DPP rotations); every lane ends with ONE float, component lane>>4 of piece lane%LPR
+// (returned in [0]).  Wider rows: butterfly per component, every slot ends with the row's 4-float piece.
+template <int LPR, int MODE>
+__device__ __forceinline__ typename VecOf<4>::T fold_row(const typename VecOf<4>::T acc, float scale)
+{
+    typedef typename VecOf<4>::T VT;
+    VT r = acc;
+    if constexpr (LPR <= 16) {
+        float px, qy;
+        {
+            auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[2]), false, false);
+            px = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+            t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[1]), __float_as_uint(acc[3]), false, false);
+            qy = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        }
+        float val;
+        {
+            auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(px), __float_as_uint(qy), false, false);
+            val = __uint_as_float(t[0]) + __uint_as_float(t[1]);
+        }
+        if constexpr (LPR <= 8) val += row_ror<8>(val);
+        if constexpr (LPR <= 4) val += row_ror<4>(val);
+        if constexpr (MODE == MODE_GIN) val *= scale;
+        r[0] = val;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float s = slot_reduce<LPR>(acc[k]);
+            if constexpr (MODE == MODE_GIN) s *= scale;
+            r[k] = s;
+        }
+    }
+    return r;
+}
+
 }  // namespace gnna
 
 #endif  // GNNA_DEVICE_H_

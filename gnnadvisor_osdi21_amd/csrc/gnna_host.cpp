@@ -26,7 +26,8 @@ thread_local char t_error[512] = "";
 const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*/4,
                                     /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0,
                                     /*column_phases=*/0, /*avg_degree=*/0, /*nonlocal_ids=*/0,
-                                    /*gcn_prescale=*/0, /*pad_rows=*/0, /*stream_kernel=*/0, /*zero_fill=*/0};
+                                    /*gcn_prescale=*/0, /*pad_rows=*/0, /*stream_kernel=*/0, /*zero_fill=*/0,
+                                    /*sweep=*/0, /*sweep_slack=*/0};
 gnna_tuning g_tuning = kDefaultTuning;
 std::mutex g_tuning_mutex;
 std::once_flag g_env_once;
@@ -69,6 +70,8 @@ void apply_env()
         else if (!std::strcmp(tok, "PAD")) g_tuning.pad_rows = v;
         else if (!std::strcmp(tok, "STREAM")) g_tuning.stream_kernel = v;
         else if (!std::strcmp(tok, "ZERO")) g_tuning.zero_fill = v;
+        else if (!std::strcmp(tok, "SWEEP")) g_tuning.sweep = v;
+        else if (!std::strcmp(tok, "SLACK")) g_tuning.sweep_slack = v;
     }
 }
 
@@ -147,6 +150,8 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->pad_rows >= 0) g_tuning.pad_rows = t->pad_rows;
     if (t->stream_kernel >= 0) g_tuning.stream_kernel = t->stream_kernel;
     if (t->zero_fill >= 0) g_tuning.zero_fill = t->zero_fill;
+    if (t->sweep >= 0) g_tuning.sweep = t->sweep;
+    if (t->sweep_slack >= 0) g_tuning.sweep_slack = t->sweep_slack;
 }
 
 int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids)
@@ -180,7 +185,7 @@ int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonloc
 
 int gnna_set_graph_phases(const int32_t *column_index, int dim, int column_phases)
 {
-    if (!column_index || dim <= 0 || column_phases < 0 || column_phases > 16)
+    if (!column_index || dim <= 0 || column_phases < 0 || column_phases > gnna::kMaxSlices)
         return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_set_graph_phases: bad argument (dim=%d phases=%d)", dim,
                           column_phases);
     std::lock_guard<std::mutex> lock(g_tuning_mutex);

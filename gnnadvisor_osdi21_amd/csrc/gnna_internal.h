@@ -42,6 +42,7 @@ struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
     int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
+    uint32_t *sweep_sync = nullptr;  // ring of kSweepSyncSlots counter blocks for the sweep kernel's soft barrier
     std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
     std::map<hipStream_t, CursorOwner> cursor_owner;
 };
@@ -61,23 +62,44 @@ int claim_cursors(DeviceState *ds, hipStream_t stream, const void *column_index,
 int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
 
 // ---- streaming kernel + sliced schedule (gnna_stream.hip) ----------------------------------------------
+constexpr int kMaxSlices = 32;    // fine source slices of a slice plan (one byte of cumulative count per group and boundary)
+constexpr int kSliceLevels = 5;   // cells[l]: non-empty (group, slice) cells when the fine slices are merged into kMaxSlices >> l
 struct SlicePlanStats {
     bool valid = false;
-    double cells[4] = {0, 0, 0, 0};  // non-empty (group, slice) cells at S, S/2, S/4, S/8 slices
+    double cells[kSliceLevels] = {0, 0, 0, 0, 0};
     double edges = 0, groups = 0;
     double span = 0;                 // sum over the edges of |column id - destination row|
     double near[24] = {0};           // near[k]: edges with |column id - destination row| < 256 * 2^(k / 2)
 };
-// Slice counts cnt[P][16] of the partition for S slices of slice_rows source rows (library cache; a miss
-// enqueues the counting kernel on `stream`, and with want_stats synchronises it once to read the
-// statistics).  *out stays null when the plan cannot be built right now (stream capture).
+struct SlicePlan {
+    const uint8_t *cnt = nullptr;    // [S - 1][P] cumulative slice counts (phase-major), null: no plan right now
+    int S = 0;                       // fine slices of the plan
+    uint32_t slice_rows = 0;         // source rows per fine slice
+    SlicePlanStats stats;
+};
+// Fine slicing of `num_in_rows` source rows: S = kMaxSlices slices of ceil(num_in_rows / S) rows.
+inline uint32_t slice_rows_for(int64_t num_in_rows)
+{
+    const int64_t r = (num_in_rows + kMaxSlices - 1) / kMaxSlices;
+    return (uint32_t)(r < 1 ? 1 : r);
+}
+// Slice plan of the partition for gathers from `num_in_rows` source rows (library cache keyed by the device
+// addresses; a miss enqueues the counting kernel on `stream`, and with want_stats synchronises it once to read
+// the statistics).  out->cnt stays null when the plan cannot be built right now (stream capture, or the
+// back-off for partitions that are never seen twice).  A plan made by gnna_prepare_graph is never evicted.
 int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_index, const int32_t *part_pointers,
-                   const int32_t *part2Node, int64_t num_parts, int S, uint32_t slice_rows, bool want_stats, const uint8_t **out,
-                   SlicePlanStats *stats_out);
+                   const int32_t *part2Node, int64_t num_parts, int64_t num_in_rows, bool want_stats, bool pin,
+                   SlicePlan *out);
 void drop_slice_plans();
+// Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
+int release_slice_plans(const void *column_index);
 // Number of phases of the sliced schedule from the statistics of the partition (gnna_agg.hip).
 int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
                   bool square, bool hinted_scattered);
+// Events on the launch path that the contract promises not to happen after gnna_prepare_graph (gnna_runtime_counters).
+enum { CTR_PLAN_BUILDS = 0, CTR_LAUNCH_SYNCS = 1, CTR_LAUNCH_FREES = 2, CTR_LAUNCH_MALLOCS = 3, CTR_BACKOFF_SKIPS = 4,
+       CTR_SWEEP_LAUNCHES = 5, CTR_COUNT = 8 };
+void count_event(int which);
 
 struct StreamLaunch {
     int mode;                 // MODE_SAG, MODE_GIN (also the pre-scaled GCN form: GIN + row_scale) or MODE_GCN (per-edge)
@@ -93,6 +115,27 @@ struct StreamLaunch {
     float eps;
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
+
+// ---- destination-blocked sweep kernel (gnna_sweep.hip) ------------------------------------------------------
+struct SweepLaunch {
+    int mode;                 // MODE_SAG or MODE_GIN (also the pre-scaled GCN form: GIN + row_scale)
+    const float *X; const int32_t *col; const int32_t *pp; const int32_t *p2n; float *Y;
+    const uint8_t *cnt;       // slice counts (required)
+    const float *row_scale;
+    const int32_t *flag; int32_t seq; int32_t trust;
+    uint32_t *sync;           // kXcds counters, 64 bytes apart, zero when the kernel starts
+    int64_t P;
+    int D, ldx, U, S, B;
+    int K = 0;                // chunks per set (0: as many as the accumulators and the wavefront count allow)
+    int slack = 0;            // soft-barrier slack in steps (0: built-in, >= 1000: none)
+    int blocks_per_cu = 0;    // 0: as many as are resident
+    bool plain_ok;
+    float eps;
+};
+bool sweep_supports(int mode, int dim, size_t x_bytes);
+int sweep_acc_rows(int dim);   // destination rows a wavefront's LDS accumulators hold at this width
+int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream);
+constexpr int kSweepSyncSlots = 64;    // ring of per-call counter blocks (kXcds x 64 bytes each)
 
 // ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------------
 // Returns the index of this call in the active profile (-1 when not profiling).

@@ -151,7 +151,9 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         // neighbourhood starts the walk): the front advances through a neighbourhood only when it is adjacent to
         // it in many places, so the odd long-range edge that survived step 1 does not open a second front far away.
         const int theta = avg_deg < 32 ? 1 : 3;
-        std::vector<int32_t> hits((size_t)n, 0);
+        // walk tag and hit counter of a node are separate words: packed into one int32 (tag * 65536 + count) the tag
+        // overflowed from 32768 walks on -- common once unsupported edges and hubs are dropped on a large graph
+        std::vector<int32_t> hit_tag((size_t)n, -1), hits((size_t)n, 0);
         std::vector<int32_t> depth((size_t)n, 0);
         auto bfs = [&](int32_t seed, int32_t tag, std::vector<int32_t> &out) {   // nodes of comp `tag` in discovery order
             out.clear();
@@ -167,8 +169,8 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                 for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
                     const int32_t u = bci[(size_t)k];
                     if (comp[(size_t)u] == tag) continue;
-                    if (hits[(size_t)u] < 0 || hits[(size_t)u] / 65536 != tag) hits[(size_t)u] = tag * 65536;   // counter of this walk
-                    if ((++hits[(size_t)u] & 65535) >= theta) {
+                    if (hit_tag[(size_t)u] != tag) { hit_tag[(size_t)u] = tag; hits[(size_t)u] = 0; }   // counter of this walk
+                    if (++hits[(size_t)u] >= theta) {
                         comp[(size_t)u] = tag;
                         depth[(size_t)u] = depth[(size_t)v] + 1;
                         out.push_back(u);

@@ -195,19 +195,21 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
         // edge belongs to exactly one slice, so the phases need neither atomics nor a zero-filled output
         int B = 1;
         const uint8_t *cnt = nullptr;
-        const int S = 16;
-        const uint32_t slice_rows = (uint32_t)std::max<int64_t>(1, (num_in_rows + S - 1) / S);
-        if (tune.column_phases >= 2 && num_in_rows >= S) {
-            B = std::min(tune.column_phases, S);
-            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, false, &cnt, nullptr);
+        int S = kMaxSlices;
+        SlicePlan plan;
+        if (tune.column_phases >= 2 && num_in_rows >= kMaxSlices) {
+            B = std::min(tune.column_phases, kMaxSlices);
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, false, false, &plan);
             if (rc != GNNA_OK) return rc;
         } else if (tune.column_phases == 0 && num_parts >= 1024 && num_in_rows >= 64 && b_bytes >= ((size_t)6 << 20)) {
-            SlicePlanStats st;
-            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, S, slice_rows, true, &cnt, &st);
+            rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, false, &plan);
             if (rc != GNNA_OK) return rc;
-            if (cnt && st.valid)
-                B = choose_slices(st, b_bytes, S, slice_rows, num_out_rows, num_in_rows == num_out_rows, tune.nonlocal_ids == 1);
+            if (plan.cnt && plan.stats.valid)
+                B = choose_slices(plan.stats, b_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,
+                                  tune.nonlocal_ids == 1);
         }
+        cnt = plan.cnt;
+        if (cnt) S = plan.S;
         if (!cnt || B < 2) { B = 1; cnt = nullptr; }
         StreamLaunch a;
         a.mode = MODE_SDDMM; a.X = src_feat; a.A = dst_feat; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node;

@@ -26,7 +26,7 @@
 //      slot 0's row and is masked at the add), so the compiler's in-order vmcnt bookkeeping stays
 //      exact and the ring really stays full.
 //
-// Sliced schedule: the source rows are cut into S <= 16 equal slices; `cnt[g][f]` (uint8) is the
+// Sliced schedule: the source rows are cut into S = 32 equal slices; `cnt[g][f]` (uint8) is the
 // number of column ids of group g that lie in slice f, computed once per graph by slice_count_kernel
 // and kept in a small library cache.  A slice phase takes, from every group, the id positions
 // [sum_{f'<lo} cnt, sum_{f'<hi} cnt) clamped to the group's length (the last phase takes the rest):
@@ -43,7 +43,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
+#include <vector>
 
 #include "gnna.h"
 #include "gnna_device.h"
@@ -52,7 +54,6 @@
 namespace gnna {
 namespace {
 
-constexpr int kMaxSlices = 16;   // bytes of slice counts per group
 constexpr int kIdSlots = 512;    // at most this many column ids parked in LDS per wavefront and round
 #ifndef GNNA_NARROW_SLOTS
 #define GNNA_NARROW_SLOTS 1024
@@ -97,7 +98,7 @@ struct StreamParams {
 // slice) cells for S, S/2, S/4, S/8 slices and the edges, which the launcher uses to pick the
 // number of phases.
 struct SliceStats {
-    unsigned long long cells[4];   // non-empty cells when the S slices are merged in pairs 0, 1, 2, 3 times
+    unsigned long long cells[kSliceLevels];   // non-empty cells when the S slices are merged in pairs 0 .. 4 times
     unsigned long long edges;
     unsigned long long groups;     // non-empty groups
     unsigned long long span;       // sum over the edges of |column id - destination row|
@@ -111,12 +112,12 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    unsigned long long cells[4] = {0, 0, 0, 0}, edges = 0, groups = 0, span = 0;
+    unsigned long long cells[kSliceLevels] = {0, 0, 0, 0, 0}, edges = 0, groups = 0, span = 0;
     unsigned long long near_l = 0;   // lane k < 24 accumulates near[k]
     for (int64_t g = wave; g < P; g += nwaves) {
         const int beg = pp[g], end = pp[g + 1];
         const int row = p2n[g];
-        int mine = 0;  // lane f < 16 accumulates the count of slice f
+        int mine = 0;  // lane f < S accumulates the count of slice f
         for (int t = beg; t < end; t += kWave) {
             const bool valid = t + lane < end;
             int f = -1, bucket = 99;
@@ -138,31 +139,30 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
                 const int c = __popcll(__ballot(bucket <= b));
                 if (lane == b) near_l += (unsigned long long)c;
             }
-#pragma unroll
-            for (int b = 0; b < kMaxSlices; b++) {
-                const int c = __popcll(__ballot(f == b));
-                if (lane == b) mine += c;
+            // sorted ids put a tile's edges into few slices: only the slices that occur are counted
+            unsigned long long left = __ballot(valid);
+            while (left) {
+                const int f0 = __builtin_amdgcn_readlane(f, __builtin_ctzll(left));
+                const unsigned long long same = __ballot(f == f0);
+                if (lane == f0) mine += __popcll(same);
+                left &= ~same;
             }
         }
         {
-            // cum[f][g] = ids of the group below slice f + 1 = inclusive prefix over lanes 0 .. f (a 16-lane DPP row)
-            int pre = lane < kMaxSlices ? mine : 0;
-            pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xF, 0xF, false);
-            pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xF, 0xF, false);
-            pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xF, 0xF, false);
-            pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xF, 0xF, false);
+            // cum[f][g] = ids of the group below slice f + 1 = inclusive prefix over lanes 0 .. f
+            const int pre = wave_inclusive_scan(lane < S ? mine : 0);
             if (lane < S - 1) cnt[(size_t)lane * (size_t)P + (size_t)g] = (uint8_t)min(pre, 255);
         }
         if (end > beg) {
-            // non-empty cells at 16, 8, 4, 2 slices (lanes 0..15 hold the fine counts)
-            int v = lane < kMaxSlices ? mine : 0;
+            // non-empty cells at S, S/2, ... 2 slices (lanes 0 .. S-1 hold the fine counts)
+            int v = lane < S ? mine : 0;
 #pragma unroll
-            for (int lvl = 0; lvl < 4; lvl++) {
-                const unsigned long long m = __ballot(v > 0 && lane < (kMaxSlices >> lvl));
+            for (int lvl = 0; lvl < kSliceLevels; lvl++) {
+                const unsigned long long m = __ballot(v > 0 && lane < (S >> lvl));
                 cells[lvl] += (unsigned long long)__popcll(m);
                 // merge pairs: lane i takes lanes 2i, 2i+1
                 const int a = __shfl(v, 2 * lane), b2 = __shfl(v, 2 * lane + 1);
-                v = lane < (kMaxSlices >> (lvl + 1)) ? a + b2 : 0;
+                v = lane < (S >> (lvl + 1)) ? a + b2 : 0;
             }
             edges += (unsigned long long)(end - beg);
             groups += 1;
@@ -173,7 +173,7 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
     if (stats && lane < 24 && near_l) atomicAdd(&stats->near[lane], near_l);
     if (stats && lane == 0) {
         if (span) atomicAdd(&stats->span, span);
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < kSliceLevels; i++)
             if (cells[i]) atomicAdd(&stats->cells[i], cells[i]);
         if (edges) atomicAdd(&stats->edges, edges);
         if (groups) atomicAdd(&stats->groups, groups);
@@ -181,42 +181,6 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
 }
 
 // ---- flush ----------------------------------------------------------------------------------------
-// fold_row: folds the RPI slots of `acc`.  LPR <= 16: reduce-scatter with v_permlane32_swap /
-// v_permlane16_swap (+ DPP rotations); every lane ends with ONE float, component lane>>4 of piece lane%LPR
-// (returned in [0]).  Wider rows: butterfly per component, every slot ends with the row's 4-float piece.
-template <int LPR, int MODE>
-__device__ __forceinline__ typename VecOf<4>::T fold_row(const typename VecOf<4>::T acc, float scale)
-{
-    typedef typename VecOf<4>::T VT;
-    VT r = acc;
-    if constexpr (LPR <= 16) {
-        float px, qy;
-        {
-            auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[2]), false, false);
-            px = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-            t = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[1]), __float_as_uint(acc[3]), false, false);
-            qy = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-        }
-        float val;
-        {
-            auto t = __builtin_amdgcn_permlane16_swap(__float_as_uint(px), __float_as_uint(qy), false, false);
-            val = __uint_as_float(t[0]) + __uint_as_float(t[1]);
-        }
-        if constexpr (LPR <= 8) val += row_ror<8>(val);
-        if constexpr (LPR <= 4) val += row_ror<4>(val);
-        if constexpr (MODE == MODE_GIN) val *= scale;
-        r[0] = val;
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            float s = slot_reduce<LPR>(acc[k]);
-            if constexpr (MODE == MODE_GIN) s *= scale;
-            r[k] = s;
-        }
-    }
-    return r;
-}
-
 // park_row: stores a folded row piece (the layout fold_row leaves) into the wavefront's LDS buffer in natural
 // float order: float i of the buffer is out[row, d0 + i].  A ragged last piece (shifted back to end at D)
 // overlaps its predecessor with identical values.
@@ -255,18 +219,6 @@ __device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *_
 }
 
 // ---- the streaming kernel ---------------------------------------------------------------------------
-
-// Inclusive prefix sum over the 64 lanes with DPP row shifts and row broadcasts (no LDS round trips).
-__device__ __forceinline__ int wave_inclusive_scan(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
-    return v;
-}
 
 #ifndef GNNA_STREAM_BLOCK
 #define GNNA_STREAM_BLOCK 256
@@ -485,7 +437,9 @@ stream_kernel(const StreamParams p)
                 // edge_out[e] = < A[row(e), :], X[col(e), :] >: every ring slot carries the destination row's piece of its
                 // load (consecutive loads of a piece re-read the same 4 * LPR floats: L1 hits), no accumulation, no flush --
                 // every edge is written once, in the one phase that owns it
-                const float *abase = p.A + dcol;
+                // (lanes past the row end read the sweep's first piece instead of running past A's last row: their
+                // value is zeroed in dot_of, the address must still be inside the tensor)
+                const float *abase = p.A + (cvalid ? dcol : (d0 + 4 <= D ? d0 : D - 4));
                 auto a_ptr = [&](int j) -> const MT * {
                     return reinterpret_cast<const MT *>(abase + (size_t)__builtin_amdgcn_readlane(row_j, j) * (size_t)D);
                 };
@@ -593,23 +547,33 @@ stream_kernel(const StreamParams p)
 struct Plan {
     const void *col = nullptr, *pp = nullptr, *p2n = nullptr;
     int64_t P = 0;
-    int S = 0;
     uint32_t slice_rows = 0;
     int device = -1;
-    uint8_t *cnt = nullptr;
-    size_t bytes = 0;
+    uint8_t *cnt = nullptr;          // (kMaxSlices - 1) * P bytes of cumulative counts, then this plan's SliceStats
+    size_t bytes = 0;                // capacity of `cnt` (counts + statistics tail)
     hipEvent_t ready = nullptr;
     hipStream_t made_on = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool multi_stream = false;       // used from more than one stream: a rebuild in place must wait for the device
     SliceStats stats{};
     bool have_stats = false;
+    bool pinned = false;             // made by gnna_prepare_graph: never evicted, only gnna_release_graph drops it
     uint64_t stamp = 0;
+    uint32_t uses = 0;
 };
-constexpr int kMaxPlans = 32;   // 15 bytes per neighbor-group each (Reddit-like: 28 MB): small next to 288 GB, and a
-                                // working set of graphs larger than the table would recount on every call
-Plan g_plans[kMaxPlans];
+constexpr int kMaxPlans = 32;   // unpinned plans kept (31 bytes per neighbor-group each; Reddit-like: 59 MB): small next to
+                                // 288 GB, and a working set of graphs larger than the table would recount on every call
+std::vector<Plan *> g_plans;    // pinned plans are unbounded
 std::mutex g_plan_mutex;
 uint64_t g_plan_clock = 0;
-SliceStats *g_stats_dev[64] = {nullptr};
+// back-off for partitions that are never seen twice (tensors re-allocated every step, sampled minibatches): after
+// kColdStreak plans in a row were evicted unused, automatic plans are not built for the next g_skip misses
+constexpr int kColdStreak = 8;
+int g_cold_evictions = 0;
+int g_skip_builds = 0;
+std::atomic<long long> g_counters[CTR_COUNT];
+
+size_t stats_offset(int64_t P) { return (((size_t)P * (size_t)(kMaxSlices - 1)) + 255) & ~(size_t)255; }
 
 typedef void (*StreamKernel)(const StreamParams);
 
@@ -638,64 +602,96 @@ StreamKernel pick_stream_lpr(int lpr, bool wide, int u)
 
 }  // namespace
 
-// Looks up / builds the slice counts of (column_index, part_pointers) for S slices of slice_rows source
-// rows.  A miss runs slice_count_kernel on `stream`; with want_stats the first use also synchronises
-// the stream once to read the statistics (never during stream capture: then *out stays null and the
-// caller takes the single-pass schedule).
+void count_event(int which) { g_counters[which].fetch_add(1, std::memory_order_relaxed); }
+
+// Looks up / builds the slice counts of (column_index, part_pointers) for gathers from num_in_rows source
+// rows.  A miss runs slice_count_kernel on `stream`; with want_stats the first use also synchronises the stream
+// once to read the statistics (never during stream capture: then out->cnt stays null and the caller takes the
+// single-pass schedule).  `pin` (gnna_prepare_graph) keeps the plan until gnna_release_graph.
 int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_index, const int32_t *part_pointers,
-                   const int32_t *part2Node, int64_t num_parts, int S, uint32_t slice_rows, bool want_stats, const uint8_t **out,
-                   SlicePlanStats *stats_out)
+                   const int32_t *part2Node, int64_t num_parts, int64_t num_in_rows, bool want_stats, bool pin,
+                   SlicePlan *out)
 {
-    *out = nullptr;
+    *out = SlicePlan();
+    const int S = kMaxSlices;
+    const uint32_t slice_rows = slice_rows_for(num_in_rows);
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    Plan *hit = nullptr, *victim = &g_plans[0];
-    for (auto &pl : g_plans) {
-        if (pl.cnt && pl.col == column_index && pl.pp == part_pointers && pl.p2n == part2Node && pl.P == num_parts && pl.S == S &&
-            pl.slice_rows == slice_rows && pl.device == dev) { hit = &pl; break; }
-        if (!pl.cnt) { if (victim->cnt) victim = &pl; }
-        else if (victim->cnt && pl.stamp < victim->stamp) victim = &pl;
+    Plan *hit = nullptr, *victim = nullptr;
+    int unpinned = 0;
+    for (Plan *pl : g_plans) {
+        if (pl->col == column_index && pl->pp == part_pointers && pl->p2n == part2Node && pl->P == num_parts &&
+            pl->slice_rows == slice_rows && pl->device == dev) { hit = pl; break; }
+        if (!pl->pinned) {
+            unpinned++;
+            if (pl->device == dev && (!victim || pl->stamp < victim->stamp)) victim = pl;
+        }
     }
-    if (hit && want_stats && !hit->have_stats) {   // built without statistics (forced phase count): count again
-        victim = hit;
-        hit = nullptr;
-    }
-    if (!hit) {
+    bool rebuild = false;
+    if (hit && want_stats && !hit->have_stats) rebuild = true;   // built without statistics (forced phase count): count again
+    if (!hit || rebuild) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
         if (cap != hipStreamCaptureStatusNone) return GNNA_OK;   // no allocation / sync while capturing
-        Plan &pl = *victim;
-        const size_t bytes = (size_t)num_parts * (size_t)(kMaxSlices - 1);
-        if (pl.bytes < bytes) {
-            if (pl.cnt) (void)hipFree(pl.cnt);
-            pl.cnt = nullptr; pl.bytes = 0;
-            hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl.cnt), bytes);
-            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(slice counts %zu B): %s", bytes, hipGetErrorString(e));
-            pl.bytes = bytes;
+        if (!hit && !pin && want_stats && g_skip_builds > 0) {   // partitions keep changing: do not count this one
+            g_skip_builds--;
+            count_event(CTR_BACKOFF_SKIPS);
+            return GNNA_OK;
         }
-        if (!pl.ready) (void)hipEventCreateWithFlags(&pl.ready, hipEventDisableTiming);
-        if (!g_stats_dev[dev]) {
-            hipError_t e = hipMalloc(reinterpret_cast<void **>(&g_stats_dev[dev]), sizeof(SliceStats));
-            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(slice stats): %s", hipGetErrorString(e));
+        Plan *pl = hit;
+        const size_t bytes = stats_offset(num_parts) + sizeof(SliceStats);
+        if (!pl) {
+            if (unpinned >= kMaxPlans && victim) {
+                pl = victim;                                     // least recently used plan of this device
+                if (pl->uses <= 1) {
+                    if (++g_cold_evictions >= kColdStreak) { g_skip_builds = 64; g_cold_evictions = 0; }
+                } else {
+                    g_cold_evictions = 0;
+                }
+            } else {
+                pl = new Plan();
+                g_plans.push_back(pl);
+            }
         }
-        pl.col = column_index; pl.pp = part_pointers; pl.p2n = part2Node; pl.P = num_parts; pl.S = S; pl.slice_rows = slice_rows;
-        pl.device = dev; pl.have_stats = false; pl.made_on = stream;
-        (void)hipMemsetAsync(g_stats_dev[dev], 0, sizeof(SliceStats), stream);
+        // another stream may still read the old counts (or the statistics tail) of a plan that is rebuilt in place
+        if (pl->cnt && (pl->multi_stream || (pl->last_stream != stream && pl->uses > 0))) {
+            (void)hipDeviceSynchronize();
+            count_event(CTR_LAUNCH_SYNCS);
+        }
+        if (pl->bytes < bytes) {
+            if (pl->cnt) { (void)hipFree(pl->cnt); count_event(CTR_LAUNCH_FREES); }
+            pl->cnt = nullptr; pl->bytes = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl->cnt), bytes);
+            count_event(CTR_LAUNCH_MALLOCS);
+            if (e != hipSuccess) {
+                pl->col = nullptr;
+                return fail(GNNA_ERR_HIP, "hipMalloc(slice counts %zu B): %s", bytes, hipGetErrorString(e));
+            }
+            pl->bytes = bytes;
+        }
+        if (!pl->ready) (void)hipEventCreateWithFlags(&pl->ready, hipEventDisableTiming);
+        pl->col = column_index; pl->pp = part_pointers; pl->p2n = part2Node; pl->P = num_parts; pl->slice_rows = slice_rows;
+        pl->device = dev; pl->have_stats = false; pl->made_on = stream; pl->last_stream = stream; pl->multi_stream = false;
+        pl->uses = 0;
+        SliceStats *stats_dev = reinterpret_cast<SliceStats *>(pl->cnt + stats_offset(num_parts));
+        (void)hipMemsetAsync(stats_dev, 0, sizeof(SliceStats), stream);
         int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((num_parts + kWavesPerBlock - 1) / kWavesPerBlock,
                                                                   (int64_t)ds->num_cus * 16));
         hipLaunchKernelGGL(slice_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, column_index,
-                           part_pointers, part2Node, num_parts, slice_rows, S, pl.cnt, g_stats_dev[dev]);
+                           part_pointers, part2Node, num_parts, slice_rows, S, pl->cnt, stats_dev);
+        count_event(CTR_PLAN_BUILDS);
         hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "slice count launch: %s", hipGetErrorString(e));
+        if (e != hipSuccess) { pl->col = nullptr; return fail(GNNA_ERR_HIP, "slice count launch: %s", hipGetErrorString(e)); }
         if (want_stats) {
-            e = hipMemcpyAsync(&pl.stats, g_stats_dev[dev], sizeof(SliceStats), hipMemcpyDeviceToHost, stream);
+            e = hipMemcpyAsync(&pl->stats, stats_dev, sizeof(SliceStats), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "slice statistics: %s", hipGetErrorString(e));
-            pl.have_stats = true;
+            if (!pin) count_event(CTR_LAUNCH_SYNCS);
+            if (e != hipSuccess) { pl->col = nullptr; return fail(GNNA_ERR_HIP, "slice statistics: %s", hipGetErrorString(e)); }
+            pl->have_stats = true;
         }
-        (void)hipEventRecord(pl.ready, stream);
-        hit = &pl;
+        (void)hipEventRecord(pl->ready, stream);
+        hit = pl;
     } else if (hit->made_on != stream) {
         // built on another stream: order after it (not from inside a capture: the counting pass was enqueued before the
         // capture began -- a capture needs its warm-up anyway -- and an outside event must not leak into the graph)
@@ -703,28 +699,41 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
         (void)hipStreamIsCapturing(stream, &cap);
         if (cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, hit->ready, 0);
     }
+    if (hit->uses > 0 && hit->last_stream != stream) hit->multi_stream = true;
+    hit->last_stream = stream;
+    hit->uses++;
+    if (hit->uses > 1) g_cold_evictions = 0;
+    if (pin) hit->pinned = true;
     hit->stamp = ++g_plan_clock;
-    *out = hit->cnt;
-    if (stats_out) {
-        stats_out->valid = hit->have_stats;
-        for (int i = 0; i < 4; i++) stats_out->cells[i] = (double)hit->stats.cells[i];
-        stats_out->edges = (double)hit->stats.edges;
-        stats_out->groups = (double)hit->stats.groups;
-        stats_out->span = (double)hit->stats.span;
-        for (int i = 0; i < 24; i++) stats_out->near[i] = (double)hit->stats.near[i];
-    }
+    out->cnt = hit->cnt;
+    out->S = S;
+    out->slice_rows = slice_rows;
+    out->stats.valid = hit->have_stats;
+    for (int i = 0; i < kSliceLevels; i++) out->stats.cells[i] = (double)hit->stats.cells[i];
+    out->stats.edges = (double)hit->stats.edges;
+    out->stats.groups = (double)hit->stats.groups;
+    out->stats.span = (double)hit->stats.span;
+    for (int i = 0; i < 24; i++) out->stats.near[i] = (double)hit->stats.near[i];
     return GNNA_OK;
 }
 
-void drop_slice_plans()
+int release_slice_plans(const void *column_index)
 {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
-    for (auto &pl : g_plans) {
-        if (pl.cnt) (void)hipFree(pl.cnt);
-        if (pl.ready) (void)hipEventDestroy(pl.ready);
-        pl = Plan();
+    int dropped = 0;
+    for (size_t i = 0; i < g_plans.size();) {
+        Plan *pl = g_plans[i];
+        if (column_index && pl->col != column_index) { i++; continue; }
+        if (pl->cnt) (void)hipFree(pl->cnt);             // (hipFree waits for the device: kernels still reading it finish first)
+        if (pl->ready) (void)hipEventDestroy(pl->ready);
+        delete pl;
+        g_plans.erase(g_plans.begin() + (long)i);
+        dropped++;
     }
+    return dropped;
 }
+
+void drop_slice_plans() { (void)release_slice_plans(nullptr); }
 
 int launch_stream(const StreamLaunch &a, hipStream_t stream)
 {
@@ -756,3 +765,12 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
 }
 
 }  // namespace gnna
+
+extern "C" {
+#pragma GCC visibility push(default)
+void gnna_runtime_counters(int64_t out[8])
+{
+    for (int i = 0; i < 8; i++) out[i] = i < gnna::CTR_COUNT ? (int64_t)gnna::g_counters[i].load() : 0;
+}
+#pragma GCC visibility pop
+}

@@ -1,0 +1,488 @@
+// gnna_sweep.hip -- the destination-blocked sweep form of the sliced neighbor-group aggregation.
+// CDNA4 / gfx950 only.
+//
+// Same computation as stream_kernel (gnna_stream.hip; reference GNNAdvisor_kernel.cu:186-259, 620-689):
+//   out[part2Node[g], :] += sum_{e in [partPtr[g], partPtr[g+1])} X[colidx[e], :]      (x eps / row factor)
+// and the same slice plan (cum[f][g], gnna_stream.hip).  What is different is WHO keeps a destination row's
+// partial sum between the source slices.
+//
+// Why: in the sliced schedule of stream_kernel a work item is (chunk, slice) and every (row, slice) piece ends in
+// a flush of the row with memory-side float atomics on a zero-filled output.  More slices mean fewer L2 misses
+// but more flushes -- on the Reddit-like headline (D = 64) 16 slices reach 83 % L2 hits and 4.9 GB of fabric
+// traffic, yet lose to 8 slices (73 %, 7.9 GB) because of the atomics, and WRITE_SIZE is 8 x the output.
+// Here a wavefront is persistent and owns a SET of K chunks (K * 64 neighbor-groups) for ALL slices:
+//
+//   * the partial rows of the set live in the wavefront's private LDS accumulators (ds_add_f32, no global
+//     atomics, no zero-filled output needed for them) while it walks the source slices 0 .. B-1;
+//   * every row is written ONCE, after the last slice: a plain coalesced store when the set owns the row, one
+//     atomic add when the row continues in a neighbouring set;
+//   * the wavefronts of an XCD (blockIdx % 8) walk the slices in step -- a soft barrier on a per-XCD counter
+//     with a bounded spin: a wavefront may run `slack` steps ahead of the slowest one -- so that the XCD's 4 MiB L2
+//     holds about one slice at a time and X is fetched from the fabric (sets per wavefront) x 8 times per
+//     aggregation instead of once per (XCD, phase, miss).  Only locality depends on the barrier, never the
+//     result: a wavefront that waits too long stops waiting for the rest of the launch;
+//   * a set with more destination rows than the accumulators hold (many low-degree rows) flushes the rows
+//     beyond the capacity the old way (atomics per slice), which stays correct for any partition.
+//
+// The per-(chunk, slice) step is the streaming kernel's: descriptors -> pieces -> load list -> U row loads
+// always in flight -> fold at the last load of a row piece.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <mutex>
+
+#include "gnna.h"
+#include "gnna_device.h"
+#include "gnna_internal.h"
+
+namespace gnna {
+namespace {
+
+constexpr int kSweepIdSlots = 512;   // column ids parked in LDS per wavefront and round of a step
+constexpr int kSweepBlock = 256;
+constexpr int kSweepWaves = kSweepBlock / kWave;
+constexpr int kSweepMaxK = 4;        // chunks (of 64 neighbor-groups) per set
+
+// LDS accumulator floats per wavefront.  Rows of <= 64 floats: 5.5 KiB (22 rows of 64 floats) -- with the
+// id list that is 31 KiB per 256-thread block, five blocks = 20 wavefronts per CU.  Rows of <= 128 floats: 12 KiB.
+template <int LPR> constexpr int acc_floats() { return LPR == 16 ? 1664 : (LPR < 16 ? 1408 : 3072); }
+
+// ds_add_f32 on a pointer that is known to point into LDS (an if-converted choice between an LDS and a global
+// destination would otherwise become ONE flat atomic, which counts on vmcnt as well and stalls the load ring)
+__device__ __forceinline__ void lds_add(float *p, float v)
+{
+    typedef __attribute__((address_space(3))) float lds_float;
+    (void)__hip_atomic_fetch_add((lds_float *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+struct SweepParams {
+    const float *X;
+    const int32_t *col;
+    const int32_t *pp;
+    const int32_t *p2n;
+    float *Y;
+    const uint8_t *cnt;        // [S-1][P] cumulative slice counts
+    const float *row_scale;    // MODE_GIN: optional per-destination-row factor on top of eps
+    const int32_t *flag;       // *flag == seq  <=>  partition is NOT canonical
+    uint32_t *sync;            // kXcds step counters of this call, 64 bytes apart, zero at launch
+    int64_t P;
+    int64_t num_chunks;        // ceil(P / 64)
+    int64_t num_sets;          // ceil(num_chunks / K)
+    int64_t sets_per_xcd;
+    int32_t seq;
+    int32_t trust;
+    int32_t D;
+    int32_t ldx;
+    int32_t S;
+    int32_t B;
+    int32_t K;
+    int32_t rounds;            // sets per wavefront
+    int32_t waves_per_xcd;
+    int32_t plain_ok;          // 1: rows owned by one set are written with plain stores (out is not accumulated into)
+    int32_t slack;             // a wavefront starts step t once every wavefront of its XCD has finished step t - slack
+                               // (1 = strict barrier); >= 1000: no synchronisation
+    float eps;
+};
+
+template <int LPR, int MODE, int U>
+__global__ void __launch_bounds__(kSweepBlock)
+sweep_kernel(const SweepParams p)
+{
+    typedef typename VecOf<4>::T VT;
+    typedef typename VecOf<4>::M MT;
+    constexpr int RPI = kWave / LPR;                                   // neighbor rows per wave-wide load
+    constexpr int RL = (kSweepIdSlots / RPI < kWave) ? kSweepIdSlots / RPI : kWave;   // loads per round
+    static_assert(RL % U == 0, "a round is a whole number of batches");
+    constexpr int ACC = acc_floats<LPR>();
+    __shared__ uint32_t s_off[kSweepWaves][RL * RPI];   // the round's list slots as byte offsets into X
+    __shared__ float s_acc[kSweepWaves][ACC];            // partial rows of the wavefront's set
+    __shared__ int s_row[kSweepWaves][kWave];            // destination row of accumulator slot q
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lslot = lane / LPR;
+    const int c = lane % LPR;
+    const int D = p.D;
+    const bool canonical = p.trust || (*p.flag != p.seq);
+    const char *xbase = reinterpret_cast<const char *>(p.X);
+    const uint32_t row_bytes32 = (uint32_t)p.ldx * 4u;
+    uint32_t *offs = s_off[wib];
+    float *accs = s_acc[wib];
+    int *srow = s_row[wib];
+    const int A = ACC / D < kWave ? ACC / D : kWave;                  // accumulator rows of this wavefront (>= 1)
+    const unsigned long long upto = (2ull << lane) - 1ull;             // lanes <= lane
+    const unsigned long long above = ~upto;                             // lanes > lane
+
+    // lane c owns the 4 floats starting at dcol; a ragged last piece is shifted back to end at D and its first
+    // `shift` components repeat the predecessor's (they are loaded but never added)
+    const int piece = c * 4;
+    const bool cvalid = piece < D;
+    int dcol = piece, shift = 0;
+    if (piece + 4 > D && cvalid) { dcol = D - 4; shift = piece - dcol; }
+    const uint32_t col_off = (uint32_t)(cvalid ? dcol : 0) * 4u;
+    // after fold_row a lane of a row of <= 64 floats holds component lane >> 4 of its piece
+    const int comp = lane >> 4;
+    const bool add_lane = LPR <= 16 ? ((lane & 15) < LPR && cvalid && comp >= shift) : (lslot == 0 && cvalid);
+
+    const int xcd = (int)(blockIdx.x & (kXcds - 1));
+    const int widx = (int)(blockIdx.x >> 3) * kSweepWaves + wib;
+    const int W = p.waves_per_xcd;
+    const int64_t set_lo = (int64_t)xcd * p.sets_per_xcd;
+    const int64_t set_hi = set_lo + p.sets_per_xcd < p.num_sets ? set_lo + p.sets_per_xcd : p.num_sets;
+    uint32_t *ctr = p.sync + xcd * 16;
+    bool in_step = p.slack < 1000 && W > 1;
+    const int K = p.K, B = p.B;
+    int tstep = 0;
+
+    for (int r = 0; r < p.rounds; r++) {
+        const int64_t set = set_lo + (int64_t)r * W + widx;
+        const bool have = set < set_hi;
+        // ---- round prologue: accumulator slot of every destination-row segment of the set ---------------
+        unsigned long long bases = 0;     // 16 bits per chunk: slot of the chunk's first segment
+        int nslots = 0, prev_last = -2, set_prev_row = -1, set_next_row = -1;
+        if (have) {
+            const int64_t g_first = set * K * kWave;
+            int64_t g_end = g_first + (int64_t)K * kWave;
+            g_end = g_end < p.P ? g_end : p.P;
+            if (g_first > 0) set_prev_row = p.p2n[g_first - 1];
+            if (g_end < p.P) set_next_row = p.p2n[g_end];
+            for (int k = 0; k < K; k++) {
+                const int64_t g0 = g_first + (int64_t)k * kWave;
+                if (g0 >= p.P) break;
+                const int ng = (int)(p.P - g0 < (int64_t)kWave ? p.P - g0 : (int64_t)kWave);
+                const bool gl = lane < ng;
+                const int my_row = gl ? p.p2n[g0 + lane] : -1;
+                const int up_row = __shfl_up(my_row, 1);
+                const bool seg_start = gl && (lane == 0 || my_row != up_row || !canonical);
+                const unsigned long long SS = __ballot(seg_start);
+                const int first_row = __builtin_amdgcn_readfirstlane(my_row);
+                const int last_row = __builtin_amdgcn_readlane(my_row, ng - 1);
+                const int merged = (canonical && k > 0 && first_row == prev_last) ? 1 : 0;
+                const int base = nslots - merged;
+                bases |= (unsigned long long)(unsigned)base << (16 * k);
+                const int idx = base + __popcll(SS & upto) - 1;
+                if (seg_start && idx < A) srow[idx] = my_row;   // (a merged first segment rewrites the same row)
+                nslots = base + __popcll(SS);
+                prev_last = last_row;
+            }
+            // zero the accumulators in use
+            const int used = (nslots < A ? nslots : A) * D;
+            for (int i = lane; i < used; i += kWave) accs[i] = 0.f;
+        }
+
+        for (int s = 0; s < B; s++, tstep++) {
+            // ---- soft barrier: every wavefront of the XCD has finished step tstep - slack --------------------
+            if (in_step && tstep >= p.slack) {
+                const uint32_t need = (uint32_t)W * (uint32_t)(tstep - p.slack + 1);
+                const unsigned long long t0 = wall_clock64();
+                while (true) {
+                    const uint32_t seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int32_t)(__builtin_amdgcn_readfirstlane(seen) - need) >= 0) break;
+                    if (wall_clock64() - t0 > 20000ull) { in_step = false; break; }   // 200 us: stop waiting for good
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            if (have) {
+                const int f_lo = s * p.S / B, f_hi = (s + 1) * p.S / B;
+                for (int k = 0; k < K; k++) {
+                    const int64_t g0 = (set * K + k) * (int64_t)kWave;
+                    if (g0 >= p.P) break;
+                    const int ng = (int)(p.P - g0 < (int64_t)kWave ? p.P - g0 : (int64_t)kWave);
+                    const int base = (int)((bases >> (16 * k)) & 0xffffu);
+
+                    // ---- 1. descriptors (all loads in flight together) -------------------------------------
+                    const bool gl = lane < ng;
+                    const int my_row = gl ? p.p2n[g0 + lane] : -1;
+                    const int pa = gl ? p.pp[g0 + lane] : 0;
+                    const int pb = gl ? p.pp[g0 + lane + 1] : 0;
+                    int cum_lo = 0, cum_hi = 0x7fffffff;
+                    if (gl) {
+                        if (f_lo > 0) cum_lo = __builtin_nontemporal_load(p.cnt + (size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane));
+                        if (f_hi < p.S) cum_hi = __builtin_nontemporal_load(p.cnt + (size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane));
+                    }
+                    const int len = pb > pa ? pb - pa : 0;
+                    const int beg = cum_lo < len ? cum_lo : len;
+                    int end = cum_hi < len ? cum_hi : len;
+                    end = end > beg ? end : beg;
+                    const int n_own = gl ? end - beg : 0;  // edges of this group in this phase
+                    if (__ballot(n_own > 0) == 0) continue;
+
+                    // destination-row segments; pieces of consecutive groups of one row that are adjacent in the
+                    // edge array are merged into one piece, headed by the first
+                    const int up_row = __shfl_up(my_row, 1);
+                    const bool seg_start = gl && (lane == 0 || my_row != up_row || !canonical);
+                    const unsigned long long SS = __ballot(seg_start);
+                    const int up_end = __shfl_up(pa + end, 1), up_n = __shfl_up(n_own, 1);
+                    const bool cont = n_own > 0 && !seg_start && up_n > 0 && up_end == pa + beg;
+                    const unsigned long long NE = __ballot(n_own > 0 && !cont);        // piece heads
+                    const int n_cum = wave_inclusive_scan(n_own);
+                    const unsigned long long heads_above = NE & above;
+                    const int next_head = heads_above ? __builtin_ctzll(heads_above) : 64;
+                    const int chain_cum = __shfl(n_cum, next_head - 1);
+                    const int n = (n_own > 0 && !cont) ? chain_cum - n_cum + n_own : 0;
+                    const int next_ne = next_head;
+                    const unsigned long long between = SS & above & (next_ne < 63 ? ((2ull << next_ne) - 1ull) : ~0ull);
+                    const bool last_in_seg = n > 0 && (next_ne == 64 || between != 0);
+                    const int aslot = base + __popcll(SS & upto) - 1;
+                    const int over = aslot >= A ? 1 : 0;                   // beyond the accumulators: flushed per slice
+
+                    // non-empty pieces compacted to lanes 0 .. R-1
+                    const int rank = __popcll(NE & (upto >> 1));
+                    const int R = __popcll(NE);
+                    const int dstl = (n > 0 ? rank : 63) << 2;
+                    const int c_pbeg = __builtin_amdgcn_ds_permute(dstl, pa + beg);
+                    const int t_n = __builtin_amdgcn_ds_permute(dstl, n);
+                    const int c_n = lane < R ? t_n : 0;
+                    const int c_meta = __builtin_amdgcn_ds_permute(dstl, ((over ? my_row : aslot) << 2) | (last_in_seg ? 2 : 0) | over);
+                    const int c_nl = (c_n + RPI - 1) / RPI;
+                    const int c_offI = wave_inclusive_scan(c_nl);
+                    const int c_offX = c_offI - c_nl;
+                    const int L = __builtin_amdgcn_readlane(c_offI, kWave - 1);
+
+                    VT acc = vzero<4>();
+                    for (int r0 = 0; r0 < L; r0 += RL) {
+                        // ---- 2. this round's loads: lane j describes load r0 + j ----------------------------
+                        const unsigned long long below = __ballot(lane < R && c_offI <= r0);
+                        unsigned long long inwin = __ballot(lane < R && c_offI > r0 && c_offI <= r0 + RL - 1);
+                        unsigned long long E = 0;
+                        while (inwin) {
+                            const int kk = __builtin_ctzll(inwin);
+                            inwin &= inwin - 1;
+                            E |= 1ull << (__builtin_amdgcn_readlane(c_offI, kk) - r0);
+                        }
+                        const int kp = __popcll(below) + __popcll(E & upto);
+                        const int k_offX = __shfl(c_offX, kp), k_pbeg = __shfl(c_pbeg, kp), k_n = __shfl(c_n, kp);
+                        const int k_meta = __shfl(c_meta, kp);
+                        const int J = r0 + lane;
+                        const bool active = J < L && lane < RL;
+                        const int i = J - k_offX;
+                        const int e_j = k_pbeg + i * RPI;
+                        int v_j = active ? k_n - i * RPI : 0;
+                        const bool fl_j = active && (k_meta & 2) && v_j <= RPI;   // last load of the last piece of its row
+                        v_j = v_j > RPI ? RPI : v_j;
+                        const unsigned long long FL = __ballot(fl_j);
+                        const unsigned long long TM = __ballot(active && v_j < RPI);   // loads with padded slots
+                        const int nr = (L - r0) < RL ? (L - r0) : RL;
+
+                        if (lane < RL) {
+                            uint32_t o[RPI];
+                            if (v_j == RPI) {
+                                if constexpr (RPI >= 4) {
+                                    typedef int i32x4 __attribute__((ext_vector_type(4)));
+                                    typedef i32x4 i32x4u __attribute__((aligned(4)));
+#pragma unroll
+                                    for (int s4 = 0; s4 < RPI; s4 += 4) {
+                                        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(p.col + e_j + s4));
+                                        o[s4] = (uint32_t)t[0]; o[s4 + 1] = (uint32_t)t[1]; o[s4 + 2] = (uint32_t)t[2]; o[s4 + 3] = (uint32_t)t[3];
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < RPI; q++) o[q] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + q);
+                                }
+                            } else {
+                                const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(p.col + e_j) : 0u;
+#pragma unroll
+                                for (int q = 0; q < RPI; q++) {
+                                    o[q] = first;
+                                    if (q > 0 && q < v_j) o[q] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + q);
+                                }
+                            }
+#pragma unroll
+                            for (int q = 0; q < RPI; q++) offs[lane * RPI + q] = o[q] * row_bytes32;
+                        }
+
+                        // ---- 3. stream: U unpredicated row loads always in flight -----------------------------
+                        auto row_ptr = [&](uint32_t o) -> const MT * {
+                            return reinterpret_cast<const MT *>(xbase + (o + col_off));
+                        };
+                        const int nb = (nr + U - 1) / U;
+                        VT v[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) v[u] = *row_ptr(offs[u * RPI + lslot]);
+                        auto consume = [&](int u, int j) {
+                            if ((TM >> j) & 1ull) {
+                                const int vj = __builtin_amdgcn_readlane(v_j, j);
+                                if (lslot >= vj) v[u] = vzero<4>();
+                            }
+                            acc += v[u];
+                            if ((FL >> j) & 1ull) {
+                                const int meta = __builtin_amdgcn_readlane(k_meta, j);
+                                const VT rr = fold_row<LPR, MODE_SAG>(acc, 1.f);
+                                if (!(meta & 1)) {
+                                    // the set's own accumulator row: LDS add, no memory traffic
+                                    float *dst = accs + (meta >> 2) * D + dcol;
+                                    if constexpr (LPR <= 16) {
+                                        if (add_lane) lds_add(dst + comp, rr[0]);
+                                    } else {
+                                        if (add_lane) {
+#pragma unroll
+                                            for (int q = 0; q < 4; q++)
+                                                if (q >= shift) lds_add(dst + q, rr[q]);
+                                        }
+                                    }
+                                } else {
+                                    // beyond the accumulators: add to the (zero-filled) output now, as stream_kernel does
+                                    const int64_t row = meta >> 2;
+                                    float scale = 1.f;
+                                    if constexpr (MODE == MODE_GIN) {
+                                        scale = p.eps;
+                                        if (p.row_scale) scale *= p.row_scale[row];
+                                    }
+                                    float *dst = p.Y + (size_t)row * (size_t)D + dcol;
+                                    if constexpr (LPR <= 16) {
+                                        if (add_lane) unsafeAtomicAdd(dst + comp, rr[0] * scale);
+                                    } else {
+                                        if (add_lane) {
+#pragma unroll
+                                            for (int q = 0; q < 4; q++)
+                                                if (q >= shift) unsafeAtomicAdd(dst + q, rr[q] * scale);
+                                        }
+                                    }
+                                }
+                                acc = vzero<4>();
+                            }
+                        };
+#pragma unroll 1
+                        for (int b = 0; b + 1 < nb; b++) {
+                            const int jn = (b + 1) * U;
+                            uint32_t nn[U];
+#pragma unroll
+                            for (int u = 0; u < U; u++) nn[u] = offs[(jn + u) * RPI + lslot];
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                consume(u, b * U + u);
+                                v[u] = *row_ptr(nn[u]);
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++) {      // the last batch only consumes
+                            const int j = (nb - 1) * U + u;
+                            if (j < nr) consume(u, j);
+                        }
+                    }
+                }
+            }
+            // ---- arrive ---------------------------------------------------------------------------------
+            if (p.slack < 1000 && lane == 0)
+                (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        // ---- every accumulator row is written once ----------------------------------------------------------
+        if (have) {
+            const int used = nslots < A ? nslots : A;
+            for (int q = 0; q < used; q++) {
+                const int row = __builtin_amdgcn_readfirstlane(srow[q]);
+                const bool shared = (q == 0 && row == set_prev_row) || (q == nslots - 1 && row == set_next_row);
+                const bool use_atomic = shared || !canonical || !p.plain_ok;
+                float scale = 1.f;
+                if constexpr (MODE == MODE_GIN) {
+                    scale = p.eps;
+                    if (p.row_scale) scale *= p.row_scale[row];
+                }
+                float *dst = p.Y + (size_t)row * (size_t)D;
+                const float *src = accs + q * D;
+                for (int i = lane; i < D; i += kWave) {
+                    const float val = src[i] * scale;
+                    if (!use_atomic) __builtin_nontemporal_store(val, dst + i);
+                    else unsafeAtomicAdd(dst + i, val);
+                }
+            }
+        }
+    }
+}
+
+typedef void (*SweepKernel)(const SweepParams);
+
+template <int LPR, int MODE>
+SweepKernel pick_sweep_u(int u)
+{
+    constexpr int RPI = kWave / LPR;
+    constexpr int RL = (kSweepIdSlots / RPI < kWave) ? kSweepIdSlots / RPI : kWave;
+    if constexpr (RL % 8 == 0) {
+        if (u >= 8) return sweep_kernel<LPR, MODE, 8>;
+    }
+    return sweep_kernel<LPR, MODE, 4>;
+}
+
+template <int MODE>
+SweepKernel pick_sweep(int lpr, int u)
+{
+    switch (lpr) {
+    case 4: return pick_sweep_u<4, MODE>(u);
+    case 8: return pick_sweep_u<8, MODE>(u);
+    case 16: return pick_sweep_u<16, MODE>(u);
+    default: return pick_sweep_u<32, MODE>(u);
+    }
+}
+
+}  // namespace
+
+int sweep_acc_rows(int dim)
+{
+    const int pieces = (dim + 3) / 4;
+    const int acc = pieces <= 8 ? acc_floats<8>() : (pieces <= 16 ? acc_floats<16>() : acc_floats<32>());
+    return std::max(1, std::min(kWave, acc / std::max(1, dim)));
+}
+
+bool sweep_supports(int mode, int dim, size_t x_bytes)
+{
+    return (mode == MODE_SAG || mode == MODE_GIN) && dim >= 4 && dim <= 128 && x_bytes <= 0xffffffffull;
+}
+
+int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
+{
+    SweepParams p;
+    p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
+    p.flag = a.flag; p.seq = a.seq; p.trust = a.trust; p.sync = a.sync;
+    p.P = a.P; p.D = a.D; p.ldx = a.ldx; p.S = a.S; p.B = a.B; p.plain_ok = a.plain_ok ? 1 : 0; p.eps = a.eps;
+    p.slack = a.slack > 0 ? a.slack : 2;
+    int lpr = 4;
+    const int pieces = (a.D + 3) / 4;
+    while (lpr < 32 && lpr < pieces) lpr <<= 1;
+    SweepKernel k = a.mode == MODE_GIN ? pick_sweep<MODE_GIN>(lpr, a.U) : pick_sweep<MODE_SAG>(lpr, a.U);
+    // persistent grid: as many blocks as are resident at once (LDS bound), the same number on every XCD
+    static std::mutex occ_mutex;
+    static std::map<const void *, int> occ_cache;      // (one device type per process)
+    int per_cu = 0;
+    hipError_t e = hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(occ_mutex);
+        auto it = occ_cache.find(reinterpret_cast<const void *>(k));
+        if (it != occ_cache.end()) {
+            per_cu = it->second;
+        } else {
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), kSweepBlock, 0);
+            if (e == hipSuccess && per_cu >= 1) occ_cache[reinterpret_cast<const void *>(k)] = per_cu;
+        }
+    }
+    if (e != hipSuccess || per_cu < 1) return fail(GNNA_ERR_HIP, "sweep kernel occupancy: %s", hipGetErrorString(e));
+    if (a.blocks_per_cu > 0) per_cu = std::min(per_cu, a.blocks_per_cu);
+    const int cus_per_xcd = std::max(1, ds->num_cus / kXcds);
+    const int blocks_per_xcd = cus_per_xcd * per_cu;
+    p.waves_per_xcd = blocks_per_xcd * kSweepWaves;
+    p.num_chunks = (a.P + kWave - 1) / kWave;
+    // K chunks per set, R sets per wavefront: the smallest R whose K fits, so that every wavefront is busy in
+    // every round (a last round that only some wavefronts take part in would idle the rest of the chip)
+    const int64_t waves = (int64_t)p.waves_per_xcd * kXcds;
+    int R = 1;
+    int64_t K = 1;
+    for (;; R++) {
+        K = (p.num_chunks + waves * R - 1) / (waves * R);
+        if (K <= (a.K > 0 ? std::min(a.K, kSweepMaxK) : kSweepMaxK)) break;
+    }
+    K = std::max<int64_t>(K, 1);
+    p.K = (int)K;
+    p.num_sets = (p.num_chunks + K - 1) / K;
+    p.sets_per_xcd = (p.num_sets + kXcds - 1) / kXcds;
+    p.rounds = (int)((p.sets_per_xcd + p.waves_per_xcd - 1) / p.waves_per_xcd);
+    const unsigned grid = (unsigned)(blocks_per_xcd * kXcds);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kSweepBlock), 0, stream, p);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
+    count_event(CTR_SWEEP_LAUNCHES);
+    return GNNA_OK;
+}
+
+}  // namespace gnna

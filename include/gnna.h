@@ -32,7 +32,9 @@
  *     seen yet (and that is large enough to be worth slicing) runs a counting pass over the
  *     column ids and synchronises `stream` once to read its statistics; never while the stream
  *     is being captured.  Library scratch is allocated on first use and never grown during capture
- *     (GNNA_ERR_UNSUPPORTED instead): warm a path up once before capturing it.
+ *     (GNNA_ERR_UNSUPPORTED instead): warm a path up once before capturing it -- or call
+ *     gnna_prepare_graph() once per graph: after it no aggregation on that graph synchronises,
+ *     allocates or frees, and a captured call takes the same schedule as an eager one.
  *   - return value: GNNA_OK or a negative gnna_status; gnna_last_error() gives the
  *     message for the calling thread.  (The reference printf()s and exit(-1)s on launch
  *     failure, .cu:177-181; this library reports instead.)
@@ -50,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 100 /* 0.1.0 */
+#define GNNA_VERSION 300 /* 0.3.0: gnna_tuning grew (sweep, sweep_slack), graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -198,7 +200,7 @@ typedef struct gnna_tuning {
                              0: one wavefront per work item (hardware scheduled)          */
     int xcd_remap;        /* 1: consecutive work items stay on one XCD's L2; 0: off       */
     int trust_canonical;  /* 1: skip the partition validation pass (build_part output)    */
-    int column_phases;    /* 1: single pass; 2..16: gather X in that many source-id ranges (cache-resident
+    int column_phases;    /* 1: single pass; 2..32: gather X in that many source-id ranges (cache-resident
                              slices; the streaming kernel runs them as one launch, the chunk-walk kernel one
                              launch each); 0: automatic -- streaming kernel: from the library's own statistics of
                              the partition; chunk-walk kernel: from the size of X and the two hints below */
@@ -221,6 +223,13 @@ typedef struct gnna_tuning {
                              `out`: 1 = only the rows that pass does not store (rows without edges, rows shared by
                              two work items), 2 = the whole output, 0 = automatic (1 once `out` is >= 32 MiB).
                              Every other schedule adds into `out` and always clears all of it */
+    int sweep;            /* destination-blocked sweep kernel (gnna_sweep.hip): persistent wavefronts keep the partial
+                             rows of their groups in LDS while every XCD walks the source slices in step, and write
+                             each row once.  1 = wherever it applies (sliced schedule, unweighted or pre-scaled gather,
+                             rows of >= 4 floats), 2 = never, 0 = automatic */
+    int sweep_slack;      /* sweep kernel: how many slice steps a wavefront may run ahead of the slowest wavefront of
+                             its XCD (soft barrier on a per-XCD counter, bounded spin: only locality depends on it).
+                             0 = built-in, n > 0 = n steps, >= 1000 = no synchronisation at all */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
@@ -234,11 +243,35 @@ GNNA_API void gnna_get_tuning(gnna_tuning *t);
 GNNA_API int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids);
 
 /* Measured schedule: aggregations of `dim`-wide features on the graph whose column_index array
- * starts at this device address use `column_phases` (1..16) column phases instead of the rule
+ * starts at this device address use `column_phases` (1..32) column phases instead of the rule
  * based on the hints; 0 removes the entry.  Up to 8 widths per graph.  An explicit process-wide
  * gnna_tuning.column_phases >= 1 still wins.  (decider.inputProperty.calibrate() measures and
  * registers these.) */
 GNNA_API int gnna_set_graph_phases(const int32_t *column_index, int dim, int column_phases);
+
+/* ---- graph lifecycle (optional) ----------------------------------------------------------
+ * gnna_prepare_graph does, up front and on `stream`, everything an aggregation call would otherwise do at first
+ * sight of a partition: the counting pass over the column ids, the read-back of its statistics (ONE
+ * synchronisation of `stream`, here instead of inside the first aggregation), the choice of the phase count for
+ * every feature width in dims[0 .. num_dims) (written to phases_out when not NULL) and the sizing of the stream's
+ * scratch (row staging for widths that want it).  The plan is pinned: it is not subject to the library's
+ * least-recently-used replacement and lives until gnna_release_graph.  After a successful prepare, aggregation
+ * calls on (column_index, part_pointers, part2Node) gathering from `num_in_rows` source rows never synchronise,
+ * allocate or free, and a call inside a stream capture takes the sliced schedule like an eager call.
+ * num_out_rows: destination rows (rows of `out`); partSize as passed to the aggregation calls.
+ * All pointers are DEVICE pointers and must stay valid (and unchanged in content) until the release.
+ * gnna_release_graph forgets every plan, hint and measured schedule keyed by this column_index address
+ * (NULL: all graphs); it waits for the device before freeing. */
+GNNA_API int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers, const int32_t *part2Node,
+                                int64_t num_parts, int64_t num_in_rows, int64_t num_out_rows, int partSize,
+                                const int *dims, int num_dims, int *phases_out, void *stream);
+GNNA_API int gnna_release_graph(const int32_t *column_index);
+
+/* Events of the library's launch path since load (for tests and monitoring):
+ *   [0] counting passes run, [1] stream / device synchronisations inside aggregation calls, [2] hipFree and
+ *   [3] hipMalloc inside aggregation calls, [4] counting passes skipped by the back-off for partitions that are
+ *   never seen twice, [5] launches of the sweep kernel; [6..7] reserved (0). */
+GNNA_API void gnna_runtime_counters(int64_t out[8]);
 
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
 GNNA_API int gnna_last_num_phases(void);

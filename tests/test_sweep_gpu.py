@@ -1,0 +1,174 @@
+"""GPU parity of the destination-blocked sweep kernel (csrc/gnna_sweep.hip) -- the sliced schedule with the
+partial rows kept in LDS across the source slices -- against the CPU oracle, through the C ABI.
+
+Same bars as test_parity_gpu.py: X = ones exact (reference unitest.py:27,54-63), random inputs within
+1e-4 * max(1, scale) of the fp64 CSR formula.  Every case also checks that the sweep kernel really ran
+(gnna_runtime_counters), so a silent fall-back to the streaming kernel cannot pass.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib, graph
+from util import assert_close_f64, dev, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+class sweep_forced:
+    """Process-wide knobs for one case: sweep kernel on, `phases` forced, optional K (chunks per set) and slack."""
+
+    def __init__(self, phases, K=0, slack=0, **kw):
+        self.kw = dict(column_phases=phases, sweep=1, sweep_slack=slack, **kw)
+        if K:
+            self.kw["groups_per_chunk"] = 64 * K
+
+    def __enter__(self):
+        _lib.reset_tuning()
+        _lib.set_tuning(**self.kw)
+        self.before = _lib.runtime_counters()["sweep_launches"]
+        return self
+
+    def launches(self):
+        return _lib.runtime_counters()["sweep_launches"] - self.before
+
+    def __exit__(self, *exc):
+        _lib.reset_tuning()
+
+
+def check_modes(g, X, pp, p2n, ps, eps=0.5, what=""):
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    ys = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    yg = _lib.agg_gcn(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    yi = _lib.agg_gin(Xd, rp, ci, eps, ppd, p2nd, ps, 32, 4)
+    torch.cuda.synchronize()
+    Xn, cin, rpn, degn = X.numpy(), g.column_index.numpy(), g.row_pointers.numpy(), g.degrees.numpy()
+    assert_close_f64(ys.cpu().numpy(), oracle.csr_f64(0, Xn, rpn, cin), what=what + " sag vs fp64")
+    gscale = oracle.csr_f64(1, np.abs(Xn), rpn, cin, degn)
+    assert_close_f64(yg.cpu().numpy(), oracle.csr_f64(1, Xn, rpn, cin, degn), what=what + " gcn vs fp64", scale=gscale)
+    assert_close_f64(yi.cpu().numpy(), oracle.csr_f64(2, Xn, rpn, cin, None, eps), what=what + " gin vs fp64")
+    assert_close_f64(ys.cpu().numpy(), oracle.sag(Xn, cin, pp.numpy(), p2n.numpy()), what=what + " sag vs oracle")
+
+
+@pytest.mark.parametrize("dim", [4, 6, 7, 16, 22, 32, 41, 47, 64, 100, 128])
+@pytest.mark.parametrize("phases", [2, 5, 32])
+def test_sweep_matches_oracle_over_widths_and_phase_counts(dim, phases):
+    g, X, pp, p2n = make_case(3000, 200000, dim, 16, seed=dim * 7 + phases, kind="powerlaw")
+    with sweep_forced(phases, gcn_prescale=1) as s:
+        check_modes(g, X, pp, p2n, 16, what=f"sweep dim={dim} phases={phases}")
+        assert s.launches() == 3, "the sweep kernel did not run"
+        assert _lib.last_num_phases() == phases
+
+
+@pytest.mark.parametrize("ps", [1, 3, 8, 32, 64, 100])
+@pytest.mark.parametrize("K", [1, 2, 4])
+def test_sweep_part_sizes_and_set_sizes(ps, K):
+    g, X, pp, p2n = make_case(2500, 150000, 64, ps, seed=ps + K, kind="powerlaw")
+    with sweep_forced(8, K=K, gcn_prescale=1) as s:
+        check_modes(g, X, pp, p2n, ps, what=f"sweep ps={ps} K={K}")
+        assert s.launches() == 3
+
+
+def test_sweep_ones_is_exact():
+    for dim, n, e in ((64, 5000, 600000), (16, 4000, 300000), (128, 2000, 200000)):
+        g, X, pp, p2n = make_case(n, e, dim, 32, seed=dim, kind="powerlaw", x="ones")
+        Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+        for phases in (3, 16, 32):
+            with sweep_forced(phases) as s:
+                y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4).cpu().numpy()
+                assert s.launches() == 1
+            want = np.repeat((g.row_pointers[1:] - g.row_pointers[:-1]).numpy().astype(np.float32)[:, None], dim, 1)
+            assert np.array_equal(y, want), (dim, phases)
+
+
+def test_sweep_rows_beyond_the_accumulators_take_the_atomic_path():
+    """Low-degree rows: 64 groups of a chunk are ~50 different rows, far more than a wavefront's LDS holds."""
+    for dim in (64, 128, 16):
+        g, X, pp, p2n = make_case(20000, 70000, dim, 4, seed=dim + 1)
+        for K in (1, 4):
+            with sweep_forced(4, K=K, gcn_prescale=1) as s:
+                check_modes(g, X, pp, p2n, 4, what=f"sweep overflow dim={dim} K={K}")
+                assert s.launches() == 3
+
+
+def test_sweep_hub_row_spanning_many_sets_and_rows_without_edges():
+    n = 40000
+    src = torch.cat([torch.zeros(n - 1, dtype=torch.int64), torch.arange(1, n)])
+    dst = torch.cat([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.int64)])
+    keep = (torch.arange(2 * (n - 1)) % 7) != 3          # some rows lose their only edge
+    gg = graph.graph_from_edges(src[keep], dst[keep], n)
+    pp, p2n = _lib.build_part(4, gg.row_pointers)
+    X = torch.randn(n, 64, generator=torch.Generator().manual_seed(4))
+    for slack in (1, 2, 1000):
+        with sweep_forced(6, slack=slack, gcn_prescale=1) as s:
+            check_modes(gg, X, pp, p2n, 4, what=f"sweep hub slack={slack}")
+            assert s.launches() == 3
+
+
+def test_sweep_non_canonical_partition_is_still_correct():
+    g, X, pp, p2n = make_case(1500, 90000, 64, 8, seed=11, kind="powerlaw")
+    P = p2n.numel()
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(5))
+    # shuffled groups: each keeps its edge range, the order (and therefore part2Node) is no longer monotone
+    beg, end = pp[:-1][perm], pp[1:][perm]
+    lens = (end - beg).to(torch.int64)
+    ci_new = torch.cat([g.column_index[int(b):int(e)] for b, e in zip(beg.tolist(), end.tolist())])
+    pp_new = torch.zeros(P + 1, dtype=torch.int32)
+    pp_new[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    p2n_new = p2n[perm].contiguous()
+    Xd, cid, ppd, p2nd = dev(X, ci_new.contiguous(), pp_new, p2n_new)
+    with sweep_forced(4) as s:
+        y = _lib.sag(Xd, None, cid, None, ppd, p2nd, 8, 32, 4).cpu().numpy()
+        assert s.launches() == 1
+    assert_close_f64(y, oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                     what="sweep on shuffled groups")
+
+
+def test_sweep_rectangular_and_accumulate():
+    """Destination shard: out rows != source rows, and a second call that adds into the first one's result."""
+    n_out, n_in, dim, ps = 1200, 9000, 64, 16
+    rp, ci = graph.powerlaw_shard(n_out, n_in, 150000, 4000, seed=3)
+    pp, p2n = _lib.build_part(ps, rp)
+    X = torch.randn(n_in, dim, generator=torch.Generator().manual_seed(8))
+    Xd, cid, ppd, p2nd = dev(X, ci, pp, p2n)
+    ref = oracle.csr_f64(0, X.numpy(), rp.numpy(), ci.numpy())
+    with sweep_forced(8) as s:
+        y = _lib.agg_rect(0, Xd, cid, ppd, p2nd, n_out, ps)
+        y2 = _lib.agg_rect(0, Xd, cid, ppd, p2nd, n_out, ps, out=y.clone(), accumulate=True)
+        assert s.launches() == 2
+    assert_close_f64(y.cpu().numpy(), ref, what="sweep rect")
+    assert_close_f64(y2.cpu().numpy(), 2 * ref, what="sweep rect accumulate")
+
+
+def test_sweep_in_a_captured_graph_after_prepare():
+    """gnna_prepare_graph makes the plan up front: the call inside a stream capture takes the sliced (here: sweep)
+    schedule, and replays give the same result."""
+    g, X, pp, p2n = make_case(6000, 700000, 64, 32, seed=21, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    out = torch.empty_like(Xd)
+    _lib.reset_tuning()
+    _lib.set_tuning(sweep=1, column_phases=8)
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 32, [64])
+            _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4, out=out)      # warm-up (scratch)
+            side.synchronize()
+            before = _lib.runtime_counters()
+            graph_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_, stream=side):
+                _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4, out=out)
+                assert _lib.last_num_phases() == 8
+        after = _lib.runtime_counters()
+        assert after["sweep_launches"] == before["sweep_launches"] + 1
+        for k in ("plan_builds", "launch_syncs", "launch_frees", "launch_mallocs"):
+            assert after[k] == before[k], k
+        out.fill_(float("nan"))
+        graph_.replay()
+        torch.cuda.synchronize()
+        assert_close_f64(out.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                         what="sweep replay")
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
