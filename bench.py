@@ -224,6 +224,172 @@ class Workload:
                 "verified": bool(exact and ok)}
 
 
+class RankOf8Workload:
+    """BASELINE config 5 in its TRUE per-rank shape, on one GPU: rank `rank` of `world` = 8 of a papers100M-like graph.
+    The rank's destination shard (13.9 M rows, ~2.0e8 edges) gathers D = 128 features from ALL 111 M source nodes:
+    either from the all-gather buffer (every rank's block: 56.9 GB resident, 64-bit row offsets) or, with the halo
+    exchange, from the compact buffer of the remote rows this shard references (a few GB) plus the rank's own
+    block.  One process plays the rank (`ShardedAggregator(emulate=(rank, world))`): shard, local / remote split,
+    halo lists and piece CSRs are built exactly as that rank builds them; the receive buffer is filled from the
+    global features instead of by RCCL, so a step times the KERNELS a rank runs per aggregation (the exchange itself
+    is the N-GPU run's to measure)."""
+
+    def __init__(self, dev, dim=128, form="allgather-one-call", world=8, rank=0, scale=1.0, manual=False,
+                 config="papers100M-like", keep_global=True):
+        import torch
+        from gnnadvisor_osdi21_amd import _lib, graph
+        from gnnadvisor_osdi21_amd.dist import ShardedAggregator
+        self._lib, self.dev, self.dim, self.form, self.world, self.rank, self.scale = _lib, dev, dim, form, world, rank, scale
+        self.config = f"rank-of-{world}/{form}"
+        cfg = graph.CONFIGS[config]
+        self.n_local = n_local = max(64, int(cfg["num_nodes"] * scale) // world)
+        self.n_global = n_global = n_local * world
+        e_target = int(cfg["num_edges"] * scale * cfg.get("oversample", 1.0)) // world
+        rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
+                                      seed=cfg["seed"] * 1000 + rank, device=dev, block_start=rank * n_local)
+        self.rp, self.ci_global = rp, ci
+        bounds = [i * n_local for i in range(world + 1)]
+        avg = ci.numel() / n_local
+        self.ps = 32 if manual else int(min(64, max(16, 1 << max(0, round(__import__("math").log2(max(1.0, avg)))))))
+        kw = dict(device=dev, emulate=(rank, world))
+        if form == "allgather-one-call":      # the whole shard in one rectangular call over the all-gather buffer
+            self.agg = ShardedAggregator(rp, ci, bounds, self.ps, overlap=False, exchange="allgather", **kw)
+        elif form == "allgather-pieces":      # local part + K piece CSRs over the sub-block-major all-gather buffer
+            self.agg = ShardedAggregator(rp, ci, bounds, self.ps, force_overlap=True, exchange="allgather", **kw)
+        elif form == "halo":                  # what `--exchange auto` takes: local part + K pieces over the compact buffer
+            self.agg = ShardedAggregator(rp, ci, bounds, self.ps, force_overlap=True, exchange="auto", **kw)
+        else:
+            raise ValueError(form)
+        gen = torch.Generator(device=dev).manual_seed(4321)
+        self.X_global = torch.randn(n_global, dim, device=dev, generator=gen)
+        self.X_local = self.X_global[rank * n_local:(rank + 1) * n_local]
+        self.buf = self.agg.emulated_receive(self.X_global)
+        self.out = torch.empty(n_local, dim, device=dev)
+        self.P = int(self.agg.part2Node.numel())
+        self.unique_sources = int(torch.unique(ci).numel())
+
+        class _G:
+            pass
+        self.g = _G()
+        self.g.nnz, self.g.num_nodes = int(ci.numel()), n_local
+        self.calibrated = None
+        self.phases, self.launches = 1, 1
+        if not keep_global and self.buf is not self.X_global:
+            self.X_global = None              # (the PMC child does not verify)
+
+    # -- one aggregation's kernels on the resident buffers
+    def step(self, X=None, out=None):
+        calls = []
+        real = self.agg.aggregate_fn
+
+        def counting(*a, **k):
+            r = real(*a, **k)
+            calls.append((self._lib.last_num_launches(), self._lib.last_num_phases()))
+            return r
+        self.agg.aggregate_fn = counting
+        try:
+            y = self.agg.aggregate_only(self.X_local if X is None else X, out=self.out if out is None else out)
+        finally:
+            self.agg.aggregate_fn = real
+        self.launches = sum(c[0] for c in calls)
+        self.phases = max(c[1] for c in calls)
+        self.calls = len(calls)
+        return y
+
+    def time(self, steps, warmup):
+        import torch
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        self._lib.profile_begin(steps * 16)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = self._lib.profile_end()
+        per_step = prof["calls"] / max(1, steps)
+        return elapsed, {"main_ms": prof["main_ms"] * per_step, "prologue_ms": prof["prologue_ms"] * per_step,
+                         "calls": prof["calls"]}
+
+    def verify(self, samples=200):
+        """X = ones on every rank -> exact row nnz; `samples` rows of the timed output against an fp64 gather-sum over
+        the GLOBAL features and the shard's GLOBAL column ids (so the remap into the buffer layout is checked too);
+        then the degree-weighted (GCN) form the same way."""
+        import torch
+        n, D, dev = self.n_local, self.dim, self.dev
+        rp, ci = self.rp, self.ci_global
+        deg = (rp[1:] - rp[:-1]).to(torch.float32)
+        # (1) ones: the receive buffer becomes all ones as well
+        keep = self.agg._halo_buf if self.agg.exchange == "halo" else self.agg._gather_buf
+        ones_buf = torch.ones_like(keep) if keep is not self.X_global else None
+        if ones_buf is None:
+            ones_buf = torch.ones(self.n_global, D, device=dev)
+        if self.agg.exchange == "halo":
+            self.agg._halo_buf = ones_buf
+        else:
+            self.agg._gather_buf = ones_buf
+        y1 = torch.empty(n, D, device=dev)
+        self.step(torch.ones(n, D, device=dev), y1)
+        exact = bool((y1 == deg[:, None]).all())
+        del y1, ones_buf
+        if self.agg.exchange == "halo":
+            self.agg._halo_buf = keep
+        else:
+            self.agg._gather_buf = keep
+        # (2) sampled rows of the timed configuration
+        self.step()
+        gen = torch.Generator(device="cpu").manual_seed(77)
+        rows = torch.randint(0, n, (samples,), generator=gen).tolist()
+        rows[0] = int(torch.argmax(deg))
+        worst, ok = 0.0, True
+        for i in rows:
+            b, e = int(rp[i]), int(rp[i + 1])
+            xs = self.X_global[ci[b:e].long()].double()
+            ref, scale = xs.sum(0), torch.clamp(xs.abs().sum(0), min=1.0)
+            err = (self.out[i].double() - ref).abs()
+            worst = max(worst, float((err / scale).max()))
+            ok = ok and bool((err <= 1e-4 * scale).all())
+        # (3) the degree-weighted form on the same buffers: deg_i * sum_j deg_j x_j
+        gen_d = torch.Generator(device=dev).manual_seed(5)
+        deg_global = torch.rand(self.n_global, device=dev, generator=gen_d) + 0.5
+        self.agg.emulated_receive_degrees(deg_global)
+        deg_local = deg_global[self.rank * n:(self.rank + 1) * n].contiguous()
+        yg = self.agg.aggregate_only(self.X_local, mode=1, degrees_local=deg_local)
+        worst_g, ok_g = 0.0, True
+        for i in rows[:64]:
+            b, e = int(rp[i]), int(rp[i + 1])
+            ids = ci[b:e].long()
+            xs = self.X_global[ids].double() * deg_global[ids].double()[:, None] * float(deg_local[i])
+            ref, scale = xs.sum(0), torch.clamp(xs.abs().sum(0), min=1.0)
+            err = (yg[i].double() - ref).abs()
+            worst_g = max(worst_g, float((err / scale).max()))
+            ok_g = ok_g and bool((err <= 1e-4 * scale).all())
+        del yg, deg_global
+        self.agg._deg_all = None
+        return {"ones_exact": exact, "sampled_rows": samples, "sampled_rows_ok": ok, "max_err_over_sum_abs": worst,
+                "gcn_weighted_rows_ok": ok_g, "gcn_max_err_over_sum_abs": worst_g, "bound": 1e-4,
+                "verified": bool(exact and ok and ok_g)}
+
+    def describe(self):
+        a = self.agg
+        D = self.dim
+        gb = lambda rows: rows * D * 4 / 1e9
+        d = {"rows_per_rank": self.n_local, "source_rows_all_ranks": self.n_global, "nnz": self.g.nnz,
+             "unique_source_rows_referenced": self.unique_sources, "partSize": self.ps, "num_parts": self.P,
+             "exchange": a.exchange, "pieces": a.chunks, "library_calls_per_step": getattr(self, "calls", None),
+             "source_buffer_rows": int(self.buf.shape[0]), "source_buffer_GB": gb(int(self.buf.shape[0])),
+             "allgather_buffer_GB": gb(self.n_global), "own_block_GB": gb(self.n_local),
+             "wide_offsets": bool(self.buf.shape[0] * D * 4 > 0xffffffff)}
+        if a.exchange == "halo":
+            d["halo_rows_per_peer"] = list(a.halo_rows_per_peer)
+            d["halo_rows"] = a.halo_rows
+            d["halo_share_of_remote_rows"] = a.halo_rows / max(1, (self.world - 1) * self.n_local)
+            d["bytes_received_per_step"] = a.bytes_received_per_step(D)
+        d["allgather_bytes_received_per_step"] = a.allgather_bytes_per_step(D)
+        return d
+
+
 # ---------------------------------------------------------------------------------------------- PMC child
 
 def pmc_child(args):
@@ -238,15 +404,21 @@ def pmc_child(args):
     manifest = {"workloads": [], "calib_bytes": CALIB_BYTES, "calib_copies": 3}
     for spec in args.pmc_workloads.split(","):
         cfg, dim, ps, phases, scale = spec.split(":")
-        w = Workload(cfg, int(dim), dev, scale=float(scale), locality=args.locality, manual=args.manual,
-                     part_size=int(ps), calibrate=False, force_phases=0 if args.manual else int(phases))
+        if cfg.startswith("rank-of-"):
+            world, form = cfg[len("rank-of-"):].split("/")
+            w = RankOf8Workload(dev, int(dim), form=form, world=int(world), scale=float(scale), manual=args.manual,
+                                keep_global=False)
+        else:
+            w = Workload(cfg, int(dim), dev, scale=float(scale), locality=args.locality, manual=args.manual,
+                         part_size=int(ps), calibrate=False, force_phases=0 if args.manual else int(phases))
         warm, steps = 1, 3
         for _ in range(warm + steps):
             w.step()
         torch.cuda.synchronize()
+        if not cfg.startswith("rank-of-"):
+            w.launches, w.phases = _lib.last_num_launches(), _lib.last_num_phases()
         manifest["workloads"].append({"config": cfg, "dim": int(dim), "warmup": warm, "steps": steps,
-                                      "launches_per_step": _lib.last_num_launches(),
-                                      "phases": _lib.last_num_phases()})
+                                      "launches_per_step": w.launches, "phases": w.phases})
         del w
         torch.cuda.empty_cache()
     x = torch.randn(CALIB_BYTES // 4, device=dev)
@@ -267,7 +439,7 @@ def run_pmc_pass(counters, specs, args, workdir):
              "--pmc-workloads", ",".join(specs), "--scale", str(args.scale), "--locality", str(args.locality)]
     if args.manual:
         child.append("--manual")
-    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "agg_kernel|stream_kernel|copyBuffer", "-T",
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "agg_kernel|stream_kernel|sweep_kernel|copyBuffer", "-T",
            "-d", outdir, "-o", "pmc", "-f", "csv", "--", *child]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -284,7 +456,7 @@ def run_pmc_pass(counters, specs, args, workdir):
 def split_counters(manifest, rows, counter):
     """-> ([per-step sum of `counter` over the aggregation launches, per workload], copy-kernel values)"""
     agg = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter
-           and ("agg_kernel" in r["Kernel_Name"] or "stream_kernel" in r["Kernel_Name"])]
+           and any(k in r["Kernel_Name"] for k in ("agg_kernel", "stream_kernel", "sweep_kernel"))]
     cp = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and "copyBuffer" in r["Kernel_Name"]]
     cp = cp[-manifest["calib_copies"]:]      # the calibration copies are the child's last dispatches (earlier
     #                                          copyBuffer dispatches are small host-to-device transfers)
@@ -342,15 +514,25 @@ def measure_traffic(workloads, args):
     return res
 
 
+def kernel_label(w):
+    calls = getattr(w, "calls", 1) or 1
+    if getattr(w, "swept", False):
+        return "sweep_kernel (dst-blocked slice sweep, LDS accumulators, one launch)"
+    if calls > 1:
+        return f"stream_kernel x {calls} library calls per step (local part + remote pieces)"
+    if w.launches == 1:
+        return "stream_kernel (sliced schedule, one launch)" if w.phases > 1 else "stream_kernel"
+    return "agg_kernel (one launch per column phase)"
+
+
 def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
     g = w.g
     alg = gather_model_bytes(g.nnz, g.num_nodes, w.P, w.dim)
-    comp = compulsory_bytes(g.nnz, g.num_nodes, g.num_nodes, w.dim)
+    comp = compulsory_bytes(g.nnz, g.num_nodes, getattr(w, "unique_sources", g.num_nodes), w.dim)
     t = kern_ms * 1e-3
     fabric = traffic.get("bytes_per_step") if traffic else None
     rec = {"bound": bound, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "kernel": "stream_kernel (sliced schedule, one launch)" if w.launches == 1 and w.phases > 1 else
-                     ("stream_kernel" if w.launches == 1 else "agg_kernel (one launch per column phase)"),
+           "kernel": kernel_label(w),
            "kernel_ms": kern_ms, "kernel_launches_per_step": w.launches, "column_phases": w.phases,
            "kernel_ms_per_launch": kern_ms / max(1, w.launches), "prologue_ms": prologue_ms,
            "kernel_edges_per_s": g.nnz / t if t > 0 else 0.0,

@@ -852,11 +852,9 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             w.mode = mode; w.X = p.X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;
             w.cnt = cnt; w.row_scale = p.row_scale; w.flag = flag; w.seq = seq; w.trust = p.trust; w.sync = sync;
             w.P = num_parts; w.D = dim; w.ldx = ldx; w.U = tune.loads_in_flight; w.S = S; w.B = Bs;
-            const double rows_with_edges = plan.stats.valid ? std::min((double)num_nodes, plan.stats.groups) : (double)num_nodes;
-            const double rows_per_chunk = rows_with_edges / std::max<double>(1.0, (double)((num_parts + kWave - 1) / kWave)) + 1.0;
-            w.K = std::max(1, std::min(4, (int)((double)sweep_acc_rows(dim) / rows_per_chunk)));
-            if (tune.groups_per_chunk > 64) w.K = std::min(4, tune.groups_per_chunk / 64);   // experiments: G = 64 * K
-            w.slack = tune.sweep_slack; w.blocks_per_cu = tune.blocks_per_cu;
+            w.rows_with_edges = plan.stats.valid ? (int64_t)std::min((double)num_nodes, plan.stats.groups) : num_nodes;
+            if (tune.groups_per_chunk > 64) w.rounds = tune.groups_per_chunk / 64;   // experiments: G = 64 * (sets per workgroup)
+            w.slack = tune.sweep_slack;
             w.plain_ok = !accumulate_into_out; w.eps = p.eps;
             t_last_phases = Bs;
             t_last_launches = 1;

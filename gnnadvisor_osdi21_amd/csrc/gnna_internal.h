@@ -126,9 +126,9 @@ struct SweepLaunch {
     uint32_t *sync;           // kXcds counters, 64 bytes apart, zero when the kernel starts
     int64_t P;
     int D, ldx, U, S, B;
-    int K = 0;                // chunks per set (0: as many as the accumulators and the wavefront count allow)
+    int rounds = 0;           // sets per workgroup (0: from rows_with_edges and the accumulator capacity)
+    int64_t rows_with_edges = 0;
     int slack = 0;            // soft-barrier slack in steps (0: built-in, >= 1000: none)
-    int blocks_per_cu = 0;    // 0: as many as are resident
     bool plain_ok;
     float eps;
 };

@@ -10,28 +10,36 @@
 // a flush of the row with memory-side float atomics on a zero-filled output.  More slices mean fewer L2 misses
 // but more flushes -- on the Reddit-like headline (D = 64) 16 slices reach 83 % L2 hits and 4.9 GB of fabric
 // traffic, yet lose to 8 slices (73 %, 7.9 GB) because of the atomics, and WRITE_SIZE is 8 x the output.
-// Here a wavefront is persistent and owns a SET of K chunks (K * 64 neighbor-groups) for ALL slices:
 //
-//   * the partial rows of the set live in the wavefront's private LDS accumulators (ds_add_f32, no global
-//     atomics, no zero-filled output needed for them) while it walks the source slices 0 .. B-1;
+// Here ONE persistent 16-wavefront workgroup per CU owns a SET of consecutive neighbor-groups -- an equal share
+// of the EDGES, found by a search in part_pointers -- for ALL source slices:
+//
+//   * the partial rows of the set (up to 512 rows of 64 floats) live in the CU's LDS (ds_add_f32; no global
+//     atomics, nothing read back) while the workgroup walks the source slices 0 .. B-1;
+//   * inside the workgroup the (chunk of 64 groups, slice) items of a set are a pool that the wavefronts drain
+//     dynamically (an LDS counter), in slice order: a wavefront that drew a short item simply draws the next;
 //   * every row is written ONCE, after the last slice: a plain coalesced store when the set owns the row, one
 //     atomic add when the row continues in a neighbouring set;
-//   * the wavefronts of an XCD (blockIdx % 8) walk the slices in step -- a soft barrier on a per-XCD counter
-//     with a bounded spin: a wavefront may run `slack` steps ahead of the slowest one -- so that the XCD's 4 MiB L2
-//     holds about one slice at a time and X is fetched from the fabric (sets per wavefront) x 8 times per
-//     aggregation instead of once per (XCD, phase, miss).  Only locality depends on the barrier, never the
-//     result: a wavefront that waits too long stops waiting for the rest of the launch;
-//   * a set with more destination rows than the accumulators hold (many low-degree rows) flushes the rows
-//     beyond the capacity the old way (atomics per slice), which stays correct for any partition.
+//   * the workgroups of an XCD (blockIdx % 8) walk the slices in step: a workgroup starts items of slice step t
+//     only when every workgroup of its XCD has finished step t - slack (a per-XCD counter in memory, polled
+//     with a bounded spin), so that the XCD's 4 MiB L2 holds about `slack` slices at a time and X is fetched
+//     from the fabric (sets per workgroup) x 8 times per aggregation.  Only locality depends on that barrier,
+//     never the result: a workgroup that waits too long stops waiting for the rest of the launch;
+//   * rows beyond the accumulators' capacity (a set of many low-degree rows), and every row of a partition that
+//     is not canonical, are flushed the old way (atomics per slice), which is correct for any partition.
 //
-// The per-(chunk, slice) step is the streaming kernel's: descriptors -> pieces -> load list -> U row loads
+// The per-(chunk, slice) item is the streaming kernel's: descriptors -> pieces -> load list -> U row loads
 // always in flight -> fold at the last load of a row piece.
+//
+// (A first version of this file gave every WAVEFRONT its own set and 5.5 KiB of accumulators, 20 wavefronts per
+// CU, barrier per wavefront: 2.25-2.5 ms on the Reddit-like headline without the barrier, 5-17 ms with it,
+// against 1.59 ms for stream_kernel -- too few loads in flight, static sets, and a barrier whose unit is one
+// latency chain.  DESIGN.md 3.1b.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
-#include <map>
-#include <mutex>
 
 #include "gnna.h"
 #include "gnna_device.h"
@@ -40,14 +48,12 @@
 namespace gnna {
 namespace {
 
-constexpr int kSweepIdSlots = 512;   // column ids parked in LDS per wavefront and round of a step
-constexpr int kSweepBlock = 256;
+constexpr int kSweepIdSlots = 512;   // column ids parked in LDS per wavefront and round of an item
+constexpr int kSweepBlock = 1024;
 constexpr int kSweepWaves = kSweepBlock / kWave;
-constexpr int kSweepMaxK = 4;        // chunks (of 64 neighbor-groups) per set
 
-// LDS accumulator floats per wavefront.  Rows of <= 64 floats: 5.5 KiB (22 rows of 64 floats) -- with the
-// id list that is 31 KiB per 256-thread block, five blocks = 20 wavefronts per CU.  Rows of <= 128 floats: 12 KiB.
-template <int LPR> constexpr int acc_floats() { return LPR == 16 ? 1664 : (LPR < 16 ? 1408 : 3072); }
+// LDS accumulator floats per workgroup: what 160 KiB leave next to the wavefronts' id lists.
+template <int LPR> constexpr int acc_floats() { return LPR >= 16 ? 32768 : 28672; }   // 128 KiB / 112 KiB
 
 // ds_add_f32 on a pointer that is known to point into LDS (an if-converted choice between an LDS and a global
 // destination would otherwise become ONE flat atomic, which counts on vmcnt as well and stalls the load ring)
@@ -68,23 +74,37 @@ struct SweepParams {
     const int32_t *flag;       // *flag == seq  <=>  partition is NOT canonical
     uint32_t *sync;            // kXcds step counters of this call, 64 bytes apart, zero at launch
     int64_t P;
-    int64_t num_chunks;        // ceil(P / 64)
-    int64_t num_sets;          // ceil(num_chunks / K)
-    int64_t sets_per_xcd;
     int32_t seq;
     int32_t trust;
     int32_t D;
     int32_t ldx;
     int32_t S;
     int32_t B;
-    int32_t K;
-    int32_t rounds;            // sets per wavefront
-    int32_t waves_per_xcd;
+    int32_t rounds;            // sets per workgroup
     int32_t plain_ok;          // 1: rows owned by one set are written with plain stores (out is not accumulated into)
-    int32_t slack;             // a wavefront starts step t once every wavefront of its XCD has finished step t - slack
+    int32_t slack;             // a workgroup starts step t once every workgroup of its XCD has finished step t - slack
                                // (1 = strict barrier); >= 1000: no synchronisation
     float eps;
 };
+
+// First index g in [0, P] with pp[g] >= target (pp non-decreasing, pp[P] >= target), searched 64 ways per round
+// trip by one wavefront.
+__device__ __forceinline__ int64_t lower_bound64(const int32_t *__restrict__ pp, int64_t P, int64_t target, int lane)
+{
+    int64_t lo = 0, hi = P;
+    while (hi > lo) {
+        const int64_t span = hi - lo;
+        const int64_t idx = lo + (span * lane) / kWave;                  // lo <= idx < hi
+        const bool below = (int64_t)pp[idx] < target;
+        const int c = __popcll(__ballot(below));                        // a prefix of the lanes
+        if (c == 0) { hi = lo; break; }
+        const int64_t new_lo = lo + (span * (c - 1)) / kWave + 1;
+        const int64_t new_hi = c < kWave ? lo + (span * c) / kWave : hi;
+        lo = new_lo;
+        hi = new_hi > new_lo ? new_hi : new_lo;
+    }
+    return lo;
+}
 
 template <int LPR, int MODE, int U>
 __global__ void __launch_bounds__(kSweepBlock)
@@ -96,9 +116,10 @@ sweep_kernel(const SweepParams p)
     constexpr int RL = (kSweepIdSlots / RPI < kWave) ? kSweepIdSlots / RPI : kWave;   // loads per round
     static_assert(RL % U == 0, "a round is a whole number of batches");
     constexpr int ACC = acc_floats<LPR>();
-    __shared__ uint32_t s_off[kSweepWaves][RL * RPI];   // the round's list slots as byte offsets into X
-    __shared__ float s_acc[kSweepWaves][ACC];            // partial rows of the wavefront's set
-    __shared__ int s_row[kSweepWaves][kWave];            // destination row of accumulator slot q
+    __shared__ float s_acc[ACC];                          // partial rows of the workgroup's set
+    __shared__ uint32_t s_off[kSweepWaves][RL * RPI];     // per wavefront: the round's list slots as byte offsets into X
+    __shared__ int64_t s_g[2];                            // the set's group range
+    __shared__ int s_ctl[8];                              // 0 next item, 1 items done, 2 last seen XCD counter, 3 gave up
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -109,9 +130,7 @@ sweep_kernel(const SweepParams p)
     const char *xbase = reinterpret_cast<const char *>(p.X);
     const uint32_t row_bytes32 = (uint32_t)p.ldx * 4u;
     uint32_t *offs = s_off[wib];
-    float *accs = s_acc[wib];
-    int *srow = s_row[wib];
-    const int A = ACC / D < kWave ? ACC / D : kWave;                  // accumulator rows of this wavefront (>= 1)
+    const int CAP = ACC / D;                                            // accumulator rows (>= 1: the launcher checks D)
     const unsigned long long upto = (2ull << lane) - 1ull;             // lanes <= lane
     const unsigned long long above = ~upto;                             // lanes > lane
 
@@ -127,88 +146,98 @@ sweep_kernel(const SweepParams p)
     const bool add_lane = LPR <= 16 ? ((lane & 15) < LPR && cvalid && comp >= shift) : (lslot == 0 && cvalid);
 
     const int xcd = (int)(blockIdx.x & (kXcds - 1));
-    const int widx = (int)(blockIdx.x >> 3) * kSweepWaves + wib;
-    const int W = p.waves_per_xcd;
-    const int64_t set_lo = (int64_t)xcd * p.sets_per_xcd;
-    const int64_t set_hi = set_lo + p.sets_per_xcd < p.num_sets ? set_lo + p.sets_per_xcd : p.num_sets;
+    const int nbx = (int)(gridDim.x >> 3);                             // workgroups per XCD
+    const int bx = (int)(blockIdx.x >> 3);
     uint32_t *ctr = p.sync + xcd * 16;
-    bool in_step = p.slack < 1000 && W > 1;
-    const int K = p.K, B = p.B;
-    int tstep = 0;
+    const bool syncing = p.slack < 1000 && nbx > 1;
+    const int B = p.B, R = p.rounds;
+    const int64_t nnz = (int64_t)p.pp[p.P];
+    const int64_t num_sets = (int64_t)gridDim.x * R;
 
-    for (int r = 0; r < p.rounds; r++) {
-        const int64_t set = set_lo + (int64_t)r * W + widx;
-        const bool have = set < set_hi;
-        // ---- round prologue: accumulator slot of every destination-row segment of the set ---------------
-        unsigned long long bases = 0;     // 16 bits per chunk: slot of the chunk's first segment
-        int nslots = 0, prev_last = -2, set_prev_row = -1, set_next_row = -1;
-        if (have) {
-            const int64_t g_first = set * K * kWave;
-            int64_t g_end = g_first + (int64_t)K * kWave;
-            g_end = g_end < p.P ? g_end : p.P;
-            if (g_first > 0) set_prev_row = p.p2n[g_first - 1];
-            if (g_end < p.P) set_next_row = p.p2n[g_end];
-            for (int k = 0; k < K; k++) {
-                const int64_t g0 = g_first + (int64_t)k * kWave;
-                if (g0 >= p.P) break;
-                const int ng = (int)(p.P - g0 < (int64_t)kWave ? p.P - g0 : (int64_t)kWave);
-                const bool gl = lane < ng;
-                const int my_row = gl ? p.p2n[g0 + lane] : -1;
-                const int up_row = __shfl_up(my_row, 1);
-                const bool seg_start = gl && (lane == 0 || my_row != up_row || !canonical);
-                const unsigned long long SS = __ballot(seg_start);
-                const int first_row = __builtin_amdgcn_readfirstlane(my_row);
-                const int last_row = __builtin_amdgcn_readlane(my_row, ng - 1);
-                const int merged = (canonical && k > 0 && first_row == prev_last) ? 1 : 0;
-                const int base = nslots - merged;
-                bases |= (unsigned long long)(unsigned)base << (16 * k);
-                const int idx = base + __popcll(SS & upto) - 1;
-                if (seg_start && idx < A) srow[idx] = my_row;   // (a merged first segment rewrites the same row)
-                nslots = base + __popcll(SS);
-                prev_last = last_row;
-            }
-            // zero the accumulators in use
-            const int used = (nslots < A ? nslots : A) * D;
-            for (int i = lane; i < used; i += kWave) accs[i] = 0.f;
+    if (threadIdx.x == 0) { s_ctl[2] = 0; s_ctl[3] = 0; }
+
+    for (int r = 0; r < R; r++) {
+        // ---- the set: an equal share of the edges, XCD-major, then workgroup, then round -------------------
+        const int64_t set = ((int64_t)xcd * nbx + bx) * R + r;
+        if (wib < 2) {
+            const int64_t i = set + wib;
+            // (nnz < 2^31 and sets < 2^31: the product fits 64 bits)
+            const int64_t target = i >= num_sets ? nnz : (nnz * i) / num_sets;
+            const int64_t g = i <= 0 ? 0 : (i >= num_sets ? p.P : lower_bound64(p.pp, p.P, target, lane));
+            if (lane == 0) s_g[wib] = g;
         }
+        if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
+        __syncthreads();
+        const int64_t g_lo = s_g[0], g_hi = s_g[1];
+        const int nchunks = (int)((g_hi - g_lo + kWave - 1) / kWave);
+        int row_first = 0, row_last = -1, set_prev_row = -1, set_next_row = -1;
+        if (g_hi > g_lo) {
+            row_first = p.p2n[g_lo];
+            row_last = p.p2n[g_hi - 1];
+            if (g_lo > 0) set_prev_row = p.p2n[g_lo - 1];
+            if (g_hi < p.P) set_next_row = p.p2n[g_hi];
+        }
+        int nrows = 0;                                                   // rows of the set kept in LDS
+        if (canonical && row_last >= row_first) nrows = row_last - row_first + 1 < CAP ? row_last - row_first + 1 : CAP;
+        for (int i = threadIdx.x; i < nrows * D; i += kSweepBlock) s_acc[i] = 0.f;
+        __syncthreads();
 
-        for (int s = 0; s < B; s++, tstep++) {
-            // ---- soft barrier: every wavefront of the XCD has finished step tstep - slack --------------------
-            if (in_step && tstep >= p.slack) {
-                const uint32_t need = (uint32_t)W * (uint32_t)(tstep - p.slack + 1);
-                const unsigned long long t0 = wall_clock64();
-                while (true) {
-                    const uint32_t seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((int32_t)(__builtin_amdgcn_readfirstlane(seen) - need) >= 0) break;
-                    if (wall_clock64() - t0 > 20000ull) { in_step = false; break; }   // 200 us: stop waiting for good
-                    __builtin_amdgcn_s_sleep(8);
+        const int total_items = nchunks * B;
+        if (nchunks == 0 && syncing && threadIdx.x == 0)                 // nothing to do: still counts as arrived
+            (void)__hip_atomic_fetch_add(ctr, (uint32_t)B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (true) {
+            int item = 0;
+            if (lane == 0) item = __hip_atomic_fetch_add(&s_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            item = __builtin_amdgcn_readfirstlane(item);
+            if (item >= total_items) break;
+            const int t = item / nchunks;                                // slice step of the item (items are drawn in step order)
+            const int chunk = item - t * nchunks;
+            const int T = r * B + t;
+
+            // ---- soft barrier: every workgroup of the XCD has finished step T - slack -------------------------
+            if (syncing && T >= p.slack) {
+                const uint32_t need = (uint32_t)nbx * (uint32_t)(T - p.slack + 1);
+                const int seen = __hip_atomic_load(&s_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int gave_up = __hip_atomic_load(&s_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((int32_t)((uint32_t)__builtin_amdgcn_readfirstlane(seen) - need) < 0 && !__builtin_amdgcn_readfirstlane(gave_up)) {
+                    const unsigned long long t0 = wall_clock64();
+                    while (true) {
+                        const uint32_t now = __builtin_amdgcn_readfirstlane(
+                            __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        if ((int32_t)(now - need) >= 0) {
+                            if (lane == 0) __hip_atomic_store(&s_ctl[2], (int)now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            break;
+                        }
+                        if (wall_clock64() - t0 > 20000ull) {           // 200 us: this workgroup stops waiting for good
+                            if (lane == 0) __hip_atomic_store(&s_ctl[3], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
                 }
             }
-            if (have) {
-                const int f_lo = s * p.S / B, f_hi = (s + 1) * p.S / B;
-                for (int k = 0; k < K; k++) {
-                    const int64_t g0 = (set * K + k) * (int64_t)kWave;
-                    if (g0 >= p.P) break;
-                    const int ng = (int)(p.P - g0 < (int64_t)kWave ? p.P - g0 : (int64_t)kWave);
-                    const int base = (int)((bases >> (16 * k)) & 0xffffu);
 
-                    // ---- 1. descriptors (all loads in flight together) -------------------------------------
-                    const bool gl = lane < ng;
-                    const int my_row = gl ? p.p2n[g0 + lane] : -1;
-                    const int pa = gl ? p.pp[g0 + lane] : 0;
-                    const int pb = gl ? p.pp[g0 + lane + 1] : 0;
-                    int cum_lo = 0, cum_hi = 0x7fffffff;
-                    if (gl) {
-                        if (f_lo > 0) cum_lo = __builtin_nontemporal_load(p.cnt + (size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane));
-                        if (f_hi < p.S) cum_hi = __builtin_nontemporal_load(p.cnt + (size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane));
-                    }
-                    const int len = pb > pa ? pb - pa : 0;
-                    const int beg = cum_lo < len ? cum_lo : len;
-                    int end = cum_hi < len ? cum_hi : len;
-                    end = end > beg ? end : beg;
-                    const int n_own = gl ? end - beg : 0;  // edges of this group in this phase
-                    if (__ballot(n_own > 0) == 0) continue;
+            {
+                const int f_lo = t * p.S / B, f_hi = (t + 1) * p.S / B;
+                const int64_t g0 = g_lo + (int64_t)chunk * kWave;
+                const int ng = (int)(g_hi - g0 < (int64_t)kWave ? g_hi - g0 : (int64_t)kWave);
 
+                // ---- 1. descriptors (all loads in flight together) -------------------------------------
+                const bool gl = lane < ng;
+                const int my_row = gl ? p.p2n[g0 + lane] : -1;
+                const int pa = gl ? p.pp[g0 + lane] : 0;
+                const int pb = gl ? p.pp[g0 + lane + 1] : 0;
+                int cum_lo = 0, cum_hi = 0x7fffffff;
+                if (gl) {
+                    if (f_lo > 0) cum_lo = __builtin_nontemporal_load(p.cnt + (size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane));
+                    if (f_hi < p.S) cum_hi = __builtin_nontemporal_load(p.cnt + (size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane));
+                }
+                const int len = pb > pa ? pb - pa : 0;
+                const int beg = cum_lo < len ? cum_lo : len;
+                int end = cum_hi < len ? cum_hi : len;
+                end = end > beg ? end : beg;
+                const int n_own = gl ? end - beg : 0;  // edges of this group in this phase
+                if (__ballot(n_own > 0) != 0) {
                     // destination-row segments; pieces of consecutive groups of one row that are adjacent in the
                     // edge array are merged into one piece, headed by the first
                     const int up_row = __shfl_up(my_row, 1);
@@ -222,19 +251,18 @@ sweep_kernel(const SweepParams p)
                     const int next_head = heads_above ? __builtin_ctzll(heads_above) : 64;
                     const int chain_cum = __shfl(n_cum, next_head - 1);
                     const int n = (n_own > 0 && !cont) ? chain_cum - n_cum + n_own : 0;
-                    const int next_ne = next_head;
-                    const unsigned long long between = SS & above & (next_ne < 63 ? ((2ull << next_ne) - 1ull) : ~0ull);
-                    const bool last_in_seg = n > 0 && (next_ne == 64 || between != 0);
-                    const int aslot = base + __popcll(SS & upto) - 1;
-                    const int over = aslot >= A ? 1 : 0;                   // beyond the accumulators: flushed per slice
+                    const unsigned long long between = SS & above & (next_head < 63 ? ((2ull << next_head) - 1ull) : ~0ull);
+                    const bool last_in_seg = n > 0 && (next_head == 64 || between != 0);
+                    const int aslot = my_row - row_first;
+                    const int over = (aslot < 0 || aslot >= nrows) ? 1 : 0;   // not in the accumulators: flushed per slice
 
-                    // non-empty pieces compacted to lanes 0 .. R-1
+                    // non-empty pieces compacted to lanes 0 .. Rn-1
                     const int rank = __popcll(NE & (upto >> 1));
-                    const int R = __popcll(NE);
+                    const int Rn = __popcll(NE);
                     const int dstl = (n > 0 ? rank : 63) << 2;
                     const int c_pbeg = __builtin_amdgcn_ds_permute(dstl, pa + beg);
                     const int t_n = __builtin_amdgcn_ds_permute(dstl, n);
-                    const int c_n = lane < R ? t_n : 0;
+                    const int c_n = lane < Rn ? t_n : 0;
                     const int c_meta = __builtin_amdgcn_ds_permute(dstl, ((over ? my_row : aslot) << 2) | (last_in_seg ? 2 : 0) | over);
                     const int c_nl = (c_n + RPI - 1) / RPI;
                     const int c_offI = wave_inclusive_scan(c_nl);
@@ -244,8 +272,8 @@ sweep_kernel(const SweepParams p)
                     VT acc = vzero<4>();
                     for (int r0 = 0; r0 < L; r0 += RL) {
                         // ---- 2. this round's loads: lane j describes load r0 + j ----------------------------
-                        const unsigned long long below = __ballot(lane < R && c_offI <= r0);
-                        unsigned long long inwin = __ballot(lane < R && c_offI > r0 && c_offI <= r0 + RL - 1);
+                        const unsigned long long below = __ballot(lane < Rn && c_offI <= r0);
+                        unsigned long long inwin = __ballot(lane < Rn && c_offI > r0 && c_offI <= r0 + RL - 1);
                         unsigned long long E = 0;
                         while (inwin) {
                             const int kk = __builtin_ctzll(inwin);
@@ -274,8 +302,8 @@ sweep_kernel(const SweepParams p)
                                     typedef i32x4 i32x4u __attribute__((aligned(4)));
 #pragma unroll
                                     for (int s4 = 0; s4 < RPI; s4 += 4) {
-                                        const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(p.col + e_j + s4));
-                                        o[s4] = (uint32_t)t[0]; o[s4 + 1] = (uint32_t)t[1]; o[s4 + 2] = (uint32_t)t[2]; o[s4 + 3] = (uint32_t)t[3];
+                                        const i32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(p.col + e_j + s4));
+                                        o[s4] = (uint32_t)tt[0]; o[s4 + 1] = (uint32_t)tt[1]; o[s4 + 2] = (uint32_t)tt[2]; o[s4 + 3] = (uint32_t)tt[3];
                                     }
                                 } else {
 #pragma unroll
@@ -312,7 +340,7 @@ sweep_kernel(const SweepParams p)
                                 const VT rr = fold_row<LPR, MODE_SAG>(acc, 1.f);
                                 if (!(meta & 1)) {
                                     // the set's own accumulator row: LDS add, no memory traffic
-                                    float *dst = accs + (meta >> 2) * D + dcol;
+                                    float *dst = s_acc + (meta >> 2) * D + dcol;
                                     if constexpr (LPR <= 16) {
                                         if (add_lane) lds_add(dst + comp, rr[0]);
                                     } else {
@@ -323,7 +351,7 @@ sweep_kernel(const SweepParams p)
                                         }
                                     }
                                 } else {
-                                    // beyond the accumulators: add to the (zero-filled) output now, as stream_kernel does
+                                    // not in the accumulators: add to the (zero-filled) output now, as stream_kernel does
                                     const int64_t row = meta >> 2;
                                     float scale = 1.f;
                                     if constexpr (MODE == MODE_GIN) {
@@ -364,32 +392,34 @@ sweep_kernel(const SweepParams p)
                     }
                 }
             }
-            // ---- arrive ---------------------------------------------------------------------------------
-            if (p.slack < 1000 && lane == 0)
-                (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-
-        // ---- every accumulator row is written once ----------------------------------------------------------
-        if (have) {
-            const int used = nslots < A ? nslots : A;
-            for (int q = 0; q < used; q++) {
-                const int row = __builtin_amdgcn_readfirstlane(srow[q]);
-                const bool shared = (q == 0 && row == set_prev_row) || (q == nslots - 1 && row == set_next_row);
-                const bool use_atomic = shared || !canonical || !p.plain_ok;
-                float scale = 1.f;
-                if constexpr (MODE == MODE_GIN) {
-                    scale = p.eps;
-                    if (p.row_scale) scale *= p.row_scale[row];
-                }
-                float *dst = p.Y + (size_t)row * (size_t)D;
-                const float *src = accs + q * D;
-                for (int i = lane; i < D; i += kWave) {
-                    const float val = src[i] * scale;
-                    if (!use_atomic) __builtin_nontemporal_store(val, dst + i);
-                    else unsafeAtomicAdd(dst + i, val);
-                }
+            // ---- the item is done; the wavefront that completes a slice step of the workgroup arrives ---------
+            if (syncing && lane == 0) {
+                const int done = __hip_atomic_fetch_add(&s_ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
+                if (done % nchunks == 0)
+                    (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        __syncthreads();
+
+        // ---- every accumulator row is written once ----------------------------------------------------------
+        for (int q = wib; q < nrows; q += kSweepWaves) {
+            const int row = row_first + q;
+            const bool shared = row == set_prev_row || row == set_next_row;
+            const bool use_atomic = shared || !p.plain_ok;
+            float scale = 1.f;
+            if constexpr (MODE == MODE_GIN) {
+                scale = p.eps;
+                if (p.row_scale) scale *= p.row_scale[row];
+            }
+            float *dst = p.Y + (size_t)row * (size_t)D;
+            const float *src = s_acc + q * D;
+            for (int i = lane; i < D; i += kWave) {
+                const float val = src[i] * scale;
+                if (!use_atomic) __builtin_nontemporal_store(val, dst + i);
+                else unsafeAtomicAdd(dst + i, val);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -422,8 +452,8 @@ SweepKernel pick_sweep(int lpr, int u)
 int sweep_acc_rows(int dim)
 {
     const int pieces = (dim + 3) / 4;
-    const int acc = pieces <= 8 ? acc_floats<8>() : (pieces <= 16 ? acc_floats<16>() : acc_floats<32>());
-    return std::max(1, std::min(kWave, acc / std::max(1, dim)));
+    const int acc = pieces <= 8 ? acc_floats<8>() : acc_floats<16>();
+    return std::max(1, acc / std::max(1, dim));
 }
 
 bool sweep_supports(int mode, int dim, size_t x_bytes)
@@ -442,44 +472,19 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     const int pieces = (a.D + 3) / 4;
     while (lpr < 32 && lpr < pieces) lpr <<= 1;
     SweepKernel k = a.mode == MODE_GIN ? pick_sweep<MODE_GIN>(lpr, a.U) : pick_sweep<MODE_SAG>(lpr, a.U);
-    // persistent grid: as many blocks as are resident at once (LDS bound), the same number on every XCD
-    static std::mutex occ_mutex;
-    static std::map<const void *, int> occ_cache;      // (one device type per process)
-    int per_cu = 0;
-    hipError_t e = hipSuccess;
-    {
-        std::lock_guard<std::mutex> lock(occ_mutex);
-        auto it = occ_cache.find(reinterpret_cast<const void *>(k));
-        if (it != occ_cache.end()) {
-            per_cu = it->second;
-        } else {
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k), kSweepBlock, 0);
-            if (e == hipSuccess && per_cu >= 1) occ_cache[reinterpret_cast<const void *>(k)] = per_cu;
-        }
-    }
-    if (e != hipSuccess || per_cu < 1) return fail(GNNA_ERR_HIP, "sweep kernel occupancy: %s", hipGetErrorString(e));
-    if (a.blocks_per_cu > 0) per_cu = std::min(per_cu, a.blocks_per_cu);
+    // persistent grid: one workgroup per CU (all of the CU's LDS), the same number on every XCD
     const int cus_per_xcd = std::max(1, ds->num_cus / kXcds);
-    const int blocks_per_xcd = cus_per_xcd * per_cu;
-    p.waves_per_xcd = blocks_per_xcd * kSweepWaves;
-    p.num_chunks = (a.P + kWave - 1) / kWave;
-    // K chunks per set, R sets per wavefront: the smallest R whose K fits, so that every wavefront is busy in
-    // every round (a last round that only some wavefronts take part in would idle the rest of the chip)
-    const int64_t waves = (int64_t)p.waves_per_xcd * kXcds;
-    int R = 1;
-    int64_t K = 1;
-    for (;; R++) {
-        K = (p.num_chunks + waves * R - 1) / (waves * R);
-        if (K <= (a.K > 0 ? std::min(a.K, kSweepMaxK) : kSweepMaxK)) break;
+    const unsigned grid = (unsigned)(cus_per_xcd * kXcds);
+    // sets per workgroup: as few as keep a set's rows (on average, with some head room) inside the accumulators
+    const int cap = sweep_acc_rows(a.D);
+    int R = a.rounds;
+    if (R <= 0) {
+        const double rows = (double)std::max<int64_t>(1, a.rows_with_edges);
+        R = (int)std::max(1.0, std::ceil(rows / ((double)grid * 0.9 * (double)cap)));
     }
-    K = std::max<int64_t>(K, 1);
-    p.K = (int)K;
-    p.num_sets = (p.num_chunks + K - 1) / K;
-    p.sets_per_xcd = (p.num_sets + kXcds - 1) / kXcds;
-    p.rounds = (int)((p.sets_per_xcd + p.waves_per_xcd - 1) / p.waves_per_xcd);
-    const unsigned grid = (unsigned)(blocks_per_xcd * kXcds);
+    p.rounds = std::min(R, 4096);
     hipLaunchKernelGGL(k, dim3(grid), dim3(kSweepBlock), 0, stream, p);
-    e = hipGetLastError();
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
     count_event(CTR_SWEEP_LAUNCHES);
     return GNNA_OK;

@@ -176,10 +176,18 @@ class ShardedAggregator:
                  aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None,
                  overlap: bool = True, force_overlap: bool = False,
                  hint_fn: Optional[Callable] = None, scattered_sources: bool = True,
-                 pipeline_chunks: int = 0, exchange: str = "allgather"):
+                 pipeline_chunks: int = 0, exchange: str = "allgather", emulate: Optional[tuple] = None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # emulate = (rank, world): this process plays ONE rank of a `world`-rank job without a process group -- the
+        # shard, its local / remote split, the halo lists and the piece CSRs are built exactly as that rank would
+        # build them; only the collectives are missing (the receive buffers are filled by `emulated_receive`).
+        # Used to run BASELINE config 5's true per-rank shape on one GPU (bench.py, tests).
+        self.emulated = emulate is not None
+        if self.emulated:
+            assert not dist.is_initialized() or dist.get_world_size(group) == 1
+            self.rank, self.world = int(emulate[0]), int(emulate[1])
         assert len(bounds) == self.world + 1
         self.bounds = [int(b) for b in bounds]
         self.n_local = self.bounds[self.rank + 1] - self.bounds[self.rank]
@@ -297,7 +305,7 @@ class ShardedAggregator:
     # ---- collective set-up decisions ------------------------------------------------------------
     def _agree_max(self, value: int) -> int:
         """max of an integer over the ranks of the group (identity without a process group)."""
-        if not (dist.is_initialized() and self.world > 1):
+        if self.emulated or not (dist.is_initialized() and self.world > 1):
             return int(value)
         on_gpu = dist.get_backend(self.group) == "nccl"
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device if on_gpu else "cpu")
@@ -323,15 +331,21 @@ class ShardedAggregator:
         b = torch.as_tensor(self.bounds, dtype=torch.int64, device=uniq.device)
         owner = torch.searchsorted(b[1:], uniq, right=True)
         need = torch.bincount(owner, minlength=world)            # rows wanted from each peer
-        cdev = self._comm_device()
-        send_counts = torch.empty(world, dtype=torch.int64, device=cdev)
-        dist.all_to_all_single(send_counts, need.to(cdev), group=self.group)
-        need_l, send_l = need.tolist(), send_counts.tolist()
-        wanted = (uniq - b[owner]).to(cdev)                      # offsets inside the owner's block
-        asked = torch.empty(int(sum(send_l)), dtype=torch.int64, device=cdev)
-        dist.all_to_all_single(asked, wanted, output_split_sizes=send_l, input_split_sizes=need_l, group=self.group)
-        asked = asked.to(self.device)
-        assert not asked.numel() or (int(asked.min()) >= 0 and int(asked.max()) < self.n_local)
+        need_l = need.tolist()
+        if self.emulated:
+            # no peers to tell: the send side of this rank is not needed to run its own aggregation
+            send_l, asked = [0] * world, uniq[:0]
+        else:
+            cdev = self._comm_device()
+            send_counts = torch.empty(world, dtype=torch.int64, device=cdev)
+            dist.all_to_all_single(send_counts, need.to(cdev), group=self.group)
+            send_l = send_counts.tolist()
+            wanted = (uniq - b[owner]).to(cdev)                      # offsets inside the owner's block
+            asked = torch.empty(int(sum(send_l)), dtype=torch.int64, device=cdev)
+            dist.all_to_all_single(asked, wanted, output_split_sizes=send_l, input_split_sizes=need_l, group=self.group)
+            asked = asked.to(self.device)
+            assert not asked.numel() or (int(asked.min()) >= 0 and int(asked.max()) < self.n_local)
+        self.halo_rows_per_peer = need_l
 
         # piece k of a list of n rows = rows [k*c, (k+1)*c) with c = ceil(n / K); both sides derive it from n
         def pieces(n):
@@ -406,6 +420,36 @@ class ShardedAggregator:
                                                 async_op=True))
         self._in_flight = keep                                   # the send buffers live until the next exchange
         return buf, works
+
+    def emulated_receive(self, X_global: torch.Tensor) -> torch.Tensor:
+        """Emulation only: puts into this rank's receive buffer what the exchange would have delivered, from the
+        features of ALL ranks in global node order (row bounds[p] + i = row i of rank p).  -> the buffer the
+        remote part reads (the all-gather buffer in its padded / sub-block-major layout, or the compact halo
+        buffer)."""
+        assert self.emulated and X_global.shape[0] == self.bounds[-1]
+        D = X_global.shape[1]
+        if self.exchange == "halo":
+            buf = torch.zeros(self.remote_rows, D, dtype=X_global.dtype, device=X_global.device)
+            step = 1 << 22
+            for a in range(0, int(self._halo_ids.numel()), step):        # in slabs: bounded temporaries
+                buf.index_copy_(0, self._halo_pos[a:a + step], X_global.index_select(0, self._halo_ids[a:a + step]))
+            self._halo_buf = buf
+            return buf
+        even = all(self.bounds[i + 1] - self.bounds[i] == self.rows_per_rank for i in range(self.world))
+        if self.chunks == 1 and even:
+            self._gather_buf = X_global                                  # the padded rank-major layout IS global order
+            return X_global
+        buf = torch.zeros(self.world * self.rows_per_rank, D, dtype=X_global.dtype, device=X_global.device)
+        rk = self.chunk_rows
+        for pr in range(self.world):
+            lo, hi = self.bounds[pr], self.bounds[pr + 1]
+            for k in range(self.chunks):
+                a, b2 = lo + k * rk, min(hi, lo + (k + 1) * rk)
+                if b2 > a:
+                    at = k * self.world * rk + pr * rk if self.chunks > 1 else pr * self.rows_per_rank
+                    buf[at: at + (b2 - a)].copy_(X_global[a:b2])
+        self._gather_buf = buf
+        return buf
 
     def bytes_received_per_step(self, dim: int) -> int:
         """Feature bytes this rank receives from its peers per aggregation."""
@@ -565,23 +609,39 @@ class ShardedAggregator:
             if w is not None:
                 w.wait()
 
-    def aggregate_only(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """The kernels of one (sum) aggregation on the buffers as the last exchange left them: no collective."""
+    def aggregate_only(self, X_local: torch.Tensor, out: Optional[torch.Tensor] = None, mode: int = 0,
+                       degrees_local: Optional[torch.Tensor] = None, epsilon: float = 1.0) -> torch.Tensor:
+        """The kernels of one aggregation on the buffers as the last exchange (or `emulated_receive`) left them: no
+        collective.  mode 1 (gcn) reads the degree norms of the sources from the buffer `prepare_degrees` /
+        `emulated_receive_degrees` filled."""
+        deg_in = self._deg_all if mode == 1 else None
+        if mode == 1:
+            assert degrees_local is not None and deg_in is not None
         if not self.overlap:
-            X_all = X_local if self.world == 1 else self._gather_buf
-            return self.aggregate_fn(0, X_all, self.column_index, self.part_pointers, self.part2Node, self.n_local,
-                                     self.partSize, None, None, 1.0, out)
-        X_all = self._halo_buf if self.exchange == "halo" else (self._gather_buf if self.world > 1 else
+            X_all = X_local if (self.world == 1 and not self.emulated) else self._gather_buf
+            return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node, self.n_local,
+                                     self.partSize, degrees_local, deg_in, epsilon, out)
+        X_all = self._halo_buf if self.exchange == "halo" else (self._gather_buf if (self.world > 1 or self.emulated) else
                                                                 (self._pad_buf if self._pad_buf is not None else X_local))
         ci_l, pp_l, p2n_l = self.local_part
-        out = self.aggregate_fn(0, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize, None, None, 1.0, out)
+        out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize, degrees_local,
+                                degrees_local, epsilon, out)
         if X_all is None:
             return out
         for k, (ci_k, pp_k, p2n_k) in enumerate(self.remote_pieces if self.chunks > 1 else [self.remote_part]):
             if ci_k.numel():
-                out = self.aggregate_fn(0, self._piece_window(X_all, None, k)[0], ci_k, pp_k, p2n_k, self.n_local,
-                                        self.partSize, None, None, 1.0, out, accumulate=True)
+                X_k, deg_k = self._piece_window(X_all, deg_in, k)
+                out = self.aggregate_fn(mode, X_k, ci_k, pp_k, p2n_k, self.n_local,
+                                        self.partSize, degrees_local, deg_k, epsilon, out, accumulate=True)
         return out
+
+    def emulated_receive_degrees(self, deg_global: torch.Tensor) -> torch.Tensor:
+        """Emulation only: the degree norms of all nodes, in global order, laid out like the feature buffer."""
+        keep = (self._gather_buf, self._halo_buf)
+        buf = self.emulated_receive(deg_global.reshape(-1, 1).contiguous()).reshape(-1)
+        self._gather_buf, self._halo_buf = keep
+        self._deg_all = buf
+        return buf
 
     def calibrate(self, dims, reps: int = 3) -> dict:
         """Measured phase counts for the parts of this shard (no collective involved: every rank tunes its

@@ -285,3 +285,38 @@ def test_two_rank_sharded_layers_match_dense_autograd():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+@pytest.mark.parametrize("exchange,chunks,overlap", [("allgather", 1, True), ("allgather", 3, True), ("halo", 1, True),
+                                                      ("halo", 2, True), ("allgather", 1, False)])
+def test_one_process_emulation_of_every_rank_matches_the_whole_graph(exchange, chunks, overlap):
+    """`emulate=(rank, world)`: one process builds rank r's shard, split, halo lists and piece CSRs exactly as a
+    `world`-rank job would and gets its receive buffer from `emulated_receive` instead of a collective (how bench.py
+    and the GPU tests run BASELINE config 5's per-rank shape on one GPU).  Every rank's rows must equal the rows of
+    the single-graph result, in all three modes."""
+    n, e, dim, world = 157, 2600, 10, 3
+    g = graph.powerlaw_graph(n, e, 60, seed=9, locality=0.5, window=6)
+    bounds = balanced_row_splits(g.row_pointers, world)
+    X = torch.randn(n, dim, generator=torch.Generator().manual_seed(10))
+    rpn, cin = g.row_pointers.numpy(), g.column_index.numpy()
+    want = [oracle.csr_f64(0, X.numpy(), rpn, cin), oracle.csr_f64(1, X.numpy(), rpn, cin, g.degrees.numpy()),
+            oracle.csr_f64(2, X.numpy(), rpn, cin, None, 0.5)]
+    for rank in range(world):
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        agg = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate, build_part_fn=_oracle_build_part,
+                                overlap=overlap, force_overlap=overlap, pipeline_chunks=chunks, exchange=exchange,
+                                emulate=(rank, world))
+        assert agg.emulated and agg.world == world and agg.rank == rank and agg.exchange == exchange
+        if exchange == "halo":
+            assert sum(agg.halo_rows_per_peer) == agg.halo_rows and agg.halo_rows_per_peer[rank] == 0
+        buf = agg.emulated_receive(X)
+        assert buf.shape[0] == (agg.remote_rows if overlap else world * agg.rows_per_rank)
+        agg.emulated_receive_degrees(g.degrees)
+        Xl, dl = X[lo:hi].contiguous(), g.degrees[lo:hi].contiguous()
+        Ys = agg.aggregate_only(Xl)
+        Yg = agg.aggregate_only(Xl, mode=1, degrees_local=dl)
+        Yi = agg.aggregate_only(Xl, mode=2, epsilon=0.5)
+        assert np.allclose(Ys.numpy(), want[0][lo:hi], atol=1e-4), (rank, "sag")
+        assert np.allclose(Yg.numpy(), want[1][lo:hi], rtol=1e-4, atol=1e-2), (rank, "gcn")
+        assert np.allclose(Yi.numpy(), want[2][lo:hi], atol=1e-4), (rank, "gin")

@@ -1,8 +1,8 @@
 """Probe: the destination-blocked sweep kernel (gnna_sweep.hip) against the streaming kernel's sliced schedule.
 Kernel ms (HIP events) on one graph / width for
   * the streaming kernel at its own choice and at forced phase counts,
-  * the sweep kernel over phase counts x barrier slack (1 = strict, 1000 = none) x chunks per set K.
-usage: probe_sweep.py [config] [D] [phases,..] [slack,..] [K,..] [U]"""
+  * the sweep kernel over phase counts x barrier slack (1 = strict, 1000 = none) x sets per workgroup R (0 = automatic).
+usage: probe_sweep.py [config] [D] [phases,..] [slack,..] [R,..] [U]"""
 import json
 import os
 import sys
