@@ -77,7 +77,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-secondary", action="store_true", help="skip the HBM-resident second workload")
     ap.add_argument("--secondary-config", default="products-like")
     ap.add_argument("--no-config5", action="store_true",
-                    help="skip the third workload (BASELINE config 5's per-GPU shape: 1/8 of a papers100M-like graph, D = 128)")
+                    help="skip BASELINE config 5's true per-rank shape (rank 0 of 8 of a papers100M-like graph, D = 128, "
+                         "gathering from all 111 M source nodes)")
+    ap.add_argument("--config5-scale", type=float, default=1.0, help="shrink the config-5 graph (debug only)")
     ap.add_argument("--headline-only", action="store_true",
                     help="only the timed headline workload: no calibration, other modes, PMC children, second "
                          "workload or CPU baseline (used for rocprofv3 kernel-trace runs)")
@@ -86,6 +88,10 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="auto", choices=("auto", "halo", "allgather"),
                     help="multi-GPU source-feature exchange: only the referenced remote rows (all_to_all), whole "
                          "blocks (all-gather), or whichever moves clearly fewer bytes (decided collectively)")
+    ap.add_argument("--scaling", default="strong,config5",
+                    help="extra legs of the N-rank line besides the weak-scaling headline: 'strong' (the single-GPU graph "
+                         "split over the ranks), 'config5' (papers100M-like, D = 128; at 8 ranks), '' = none")
+    ap.add_argument("--config5-leg", action="store_true", help="run the config-5 leg at any world size (debug / tests)")
     ap.add_argument("--backend", default="nccl", help="debug: 'gloo' runs the N-rank path without RCCL")
     ap.add_argument("--share-gpu", action="store_true", help="debug: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
@@ -371,6 +377,10 @@ class RankOf8Workload:
                 "gcn_weighted_rows_ok": ok_g, "gcn_max_err_over_sum_abs": worst_g, "bound": 1e-4,
                 "verified": bool(exact and ok and ok_g)}
 
+    def release(self):
+        """Drops the device tensors (the record keeps what the roofline line and the PMC child need)."""
+        self.X_global = self.X_local = self.buf = self.out = self.agg = self.rp = self.ci_global = None
+
     def describe(self):
         a = self.agg
         D = self.dim
@@ -542,6 +552,7 @@ def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
            "compulsory_model": {"bytes_per_step": comp, "GBs": comp / t / 1e9 if t > 0 else 0.0}}
     if fabric:
         rec.update({"achieved": fabric / t / 1e9, "frac": fabric / t / 1e9 / HBM_PEAK_GBS,
+                    "frac_of_achievable_6300GBs": fabric / t / 1e9 / 6300.0,
                     "achieved_source": "measured fabric traffic (2*FETCH_SIZE + WRITE_SIZE, calibrated) / HIP-event kernel time",
                     "traffic": fabric / max(1, w.launches), "traffic_per_step": fabric,
                     "traffic_over_compulsory": fabric / comp,
@@ -651,6 +662,29 @@ def library_baselines(rp, ci, X, nnz, cores):
     return res
 
 
+def reference_style_ms(w, dims=(16, 64), warmup: int = 10, calls: int = 200):
+    """The reference's own timing method (GNNAdvisor/unitest.py:65-79: 10 warm-up calls, then `--num_epoches` = 200
+    calls of GNNA.SAG between two synchronisations, wall clock): through the pybind module `GNNAdvisor`, every call
+    allocating its output, at hidden = 16 and 64 -- the number comparable with its `=> SpMM profiling avg (ms)`."""
+    import torch
+    from gnnadvisor_osdi21_amd import load_extension
+    GNNA = load_extension()
+    g, res = w.g, {}
+    for d in dims:
+        X = w.X if d == w.dim else torch.randn(g.num_nodes, d, device=w.dev, generator=torch.Generator(device=w.dev).manual_seed(d))
+        for _ in range(warmup):
+            GNNA.SAG(X, g.row_pointers, g.column_index, g.degrees, w.ppd, w.p2nd, w.ps, 32, 4)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            GNNA.SAG(X, g.row_pointers, g.column_index, g.degrees, w.ppd, w.p2nd, w.ps, 32, 4)
+        torch.cuda.synchronize()
+        res[str(d)] = (time.perf_counter() - t0) * 1e3 / calls
+    res["method"] = (f"{warmup} warm-up + {calls} GNNA.SAG calls through the pybind module, fresh output tensor per call, "
+                     "wall clock between two synchronisations (reference unitest.py:65-79)")
+    return res
+
+
 def other_modes(w, steps: int = 10):
     """edges/s of the GCN-weighted and GIN entries on the bench graph (same partition, same knobs)."""
     import torch
@@ -688,20 +722,29 @@ def run_single(args, result_fd):
     extras = not args.headline_only
     tuning = _lib.get_tuning()
     modes = other_modes(w) if extras else None
+    ref_style = reference_style_ms(w) if extras else None
 
     second = None
     if extras and not args.no_secondary and args.scale == 1.0:
         w2 = Workload(args.secondary_config, 64, dev, manual=args.manual)
         e2, p2 = w2.time(max(5, args.steps // 2), 3)
         second = (w2, e2, p2, max(5, args.steps // 2), w2.verify(64))
-    third = None
+    # BASELINE config 5 in its true per-rank shape (rank 0 of 8; the 56.9 GB all-gather buffer, then the compact halo
+    # buffer the automatic exchange takes): one after the other -- each keeps the global features resident
+    fives = []
     if extras and not args.no_config5 and args.scale == 1.0:
-        w3 = Workload("papers100M-like", 128, dev, scale=0.125, manual=args.manual)
-        e3, p3 = w3.time(5, 2)
-        third = (w3, e3, p3, 5, w3.verify(32))
+        import gc
+        for form in ("allgather-one-call", "halo"):
+            w5 = RankOf8Workload(dev, 128, form=form, manual=args.manual, scale=args.config5_scale)
+            e5, p5 = w5.time(4, 2)
+            chk5 = w5.verify(200)
+            fives.append((w5, e5, p5, 4, chk5, w5.describe()))
+            w5.release()
+            gc.collect()
+            torch.cuda.empty_cache()
     traffic = {}
     if extras and not args.no_pmc:
-        ws = [w] + ([second[0]] if second else []) + ([third[0]] if third else [])
+        ws = [w] + ([second[0]] if second else []) + [f[0] for f in fives]
         for wl, t in zip(ws, measure_traffic(ws, args)):
             traffic[id(wl)] = t
 
@@ -736,22 +779,36 @@ def run_single(args, result_fd):
             "num_nodes": g2.num_nodes, "nnz": g2.nnz, "dim": 64, "partSize": w2.ps, "num_parts": w2.P,
             "column_phases_used": w2.phases, "calibrated_phases": w2.calibrated,
             "verified": chk2["verified"], "verification": chk2,
-            "roofline": roofline_record(w2, p2["main_ms"], p2["prologue_ms"], traffic.get(id(w2)), "hbm"),
+            "roofline": roofline_record(w2, p2["main_ms"], p2["prologue_ms"], traffic.get(id(w2)),
+                                        "fabric (HBM + Infinity Cache)"),
         }
         del w2
-    if third:
-        w3, e3, p3, k3, chk3 = third
-        g3 = w3.g
-        rec["config5_shard"] = {
-            "workload": "papers100M-like power-law graph, scale 1/8 = one GPU's destination shard of BASELINE config 5 "
-                        f"(features {g3.num_nodes * 128 * 4 / 1e9:.1f} GB, 64-bit row offsets)",
-            "value": g3.nnz * k3 / e3, "unit": "edges/s", "steps": k3, "ms_per_step": e3 * 1e3 / k3,
-            "num_nodes": g3.num_nodes, "nnz": g3.nnz, "dim": 128, "partSize": w3.ps, "num_parts": w3.P,
-            "column_phases_used": w3.phases, "calibrated_phases": w3.calibrated,
-            "verified": chk3["verified"], "verification": chk3,
-            "roofline": roofline_record(w3, p3["main_ms"], p3["prologue_ms"], traffic.get(id(w3)), "hbm"),
+    for w5, e5, p5, k5, chk5, desc5 in fives:
+        key = "config5_rank_of_8" if w5.form == "allgather-one-call" else "config5_rank_of_8_" + w5.form.replace("-", "_")
+        rec[key] = {
+            "workload": f"papers100M-like power-law graph, rank {w5.rank} of {w5.world} in its true shape: "
+                        f"{w5.n_local} destination rows gathering D = 128 rows of {w5.n_global} source nodes; "
+                        + ("ONE rectangular call over the resident all-gather buffer"
+                           if w5.form == "allgather-one-call" else
+                           "local-source part from the rank's own block + remote part piece by piece from the compact "
+                           "halo buffer (what --exchange auto takes)")
+                        + "; kernels only, receive buffer filled from the global features instead of by RCCL",
+            "value": w5.g.nnz * k5 / e5, "unit": "edges/s", "steps": k5, "ms_per_step": e5 * 1e3 / k5,
+            "num_nodes": w5.n_local, "nnz": w5.g.nnz, "dim": 128, "shape": desc5,
+            "column_phases_used": w5.phases, "verified": chk5["verified"], "verification": chk5,
+            "roofline": roofline_record(w5, p5["main_ms"], p5["prologue_ms"], traffic.get(id(w5)),
+                                        "hbm" if desc5["source_buffer_GB"] > 0.27 else "fabric (HBM + Infinity Cache)"),
         }
-        del w3
+    if ref_style:
+        rec["config"]["reference_style_ms"] = ref_style
+    # the driver keeps only the contract's keys of this line: everything else rides inside `config` / `roofline`
+    rec["config"]["verified"] = rec["verified"]
+    rec["config"]["verification"] = rec.pop("verification")
+    if modes:
+        rec["config"]["other_modes"] = rec.pop("other_modes")
+    others = {k: rec.pop(k) for k in list(rec) if k == "hbm_resident" or k.startswith("config5_")}
+    if others:
+        rec["roofline"]["other_workloads"] = others
     if extras and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.X.cpu(), w.pp, w.p2n, args.dim)
     os.write(result_fd, (json.dumps(rec) + "\n").encode())
@@ -759,45 +816,23 @@ def run_single(args, result_fd):
 
 # ---------------------------------------------------------------------------------------------- N ranks
 
-def run_sharded(args, result_fd, world, rank, local_rank):
-    import datetime
+def sharded_leg(args, dev, world, rank, name, rp, ci, bounds, D, feat, avg_span, steps, warmup, dist, exchange):
+    """One workload of the N-rank line: this rank's destination shard (local CSR rows `rp`, GLOBAL column ids `ci`),
+    `steps` timed aggregations (exchange + kernels) bracketed by barriers, then exchange-only / kernels-only timings
+    and the known-answer check on every rank.  -> dict of this leg's numbers (max / sum over the ranks)."""
     import torch
-    import torch.distributed as dist
-    if args.share_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29511")
-    os.environ.setdefault("RANK", "0")
-    os.environ.setdefault("WORLD_SIZE", "1")
-    limit = datetime.timedelta(seconds=300)                # a rank that dies must not hang the others for long
-    if args.backend == "nccl":
-        dist.init_process_group("nccl", device_id=dev, timeout=limit)
-    else:
-        dist.init_process_group(args.backend, timeout=limit)
-
-    from gnnadvisor_osdi21_amd import _lib, graph
+    from gnnadvisor_osdi21_amd import _lib
     from gnnadvisor_osdi21_amd.decider import inputProperty
     from gnnadvisor_osdi21_amd.dist import ShardedAggregator
-    _lib.load()
-    cfg = graph.CONFIGS[args.config]
-    D = args.dim
-    n_local = max(2, int(cfg["num_nodes"] * args.scale))
-    e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
-    n_global = n_local * world
-    rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
-                                  seed=cfg["seed"] * 1000 + rank, device=dev, locality=args.locality,
-                                  block_start=rank * n_local)
-    bounds = [i * n_local for i in range(world + 1)]
+    n_local = bounds[rank + 1] - bounds[rank]
+    n_global = bounds[-1]
 
     class _Profile:
         pass
     prof_obj = _Profile()
-    # sources are drawn from all ranks' nodes (span ~ n_global / 3) unless --locality keeps a share of them near
-    prof_obj.num_nodes, prof_obj.avg_degree = n_local, float(ci.numel()) / n_local
-    prof_obj.avg_edgeSpan = (1.0 - args.locality) * n_global / 3.0
-    prof_obj.num_features, prof_obj.reorder_flag = cfg["feat"], False
+    prof_obj.num_nodes, prof_obj.avg_degree = n_local, float(ci.numel()) / max(1, n_local)
+    prof_obj.avg_edgeSpan = avg_span
+    prof_obj.num_features, prof_obj.reorder_flag = feat, False
     prof_obj.rabbit_reorder = lambda: None
     info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=prof_obj,
                          enable_rabbit=False, manual_mode=args.manual)
@@ -806,7 +841,7 @@ def run_sharded(args, result_fd, world, rank, local_rank):
         info.apply_tuning()
     ps = args.partSize if args.partSize > 0 else info.partSize
     agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
-                            pipeline_chunks=args.pipeline_chunks, exchange=args.exchange)
+                            pipeline_chunks=args.pipeline_chunks, exchange=exchange)
     calibrated = agg.calibrate([D]) if not (args.manual or args.headline_only) else None
     nnz_local = agg.nnz_local
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -822,18 +857,19 @@ def run_sharded(args, result_fd, world, rank, local_rank):
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     sync_all()
-    _lib.profile_begin(args.steps * 64)                    # a sharded step is several library calls
+    _lib.profile_begin(steps * 64)                         # a sharded step is several library calls
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_end()
-    calls_per_step = prof["calls"] / max(1, args.steps)
+    calls_per_step = prof["calls"] / max(1, steps)
     kern_ms = prof["main_ms"] * calls_per_step
+    phases_last = _lib.last_num_phases()
 
     # the two halves of a step on their own (same buffers, after the timed loop): exchange only, kernels only
     def timed_ms(fn, n=5):
@@ -850,57 +886,161 @@ def run_sharded(args, result_fd, world, rank, local_rank):
     # verification of the timed configuration: X = ones everywhere -> exact row nnz on every rank
     ones = torch.ones_like(X)
     y1 = agg.sag(ones)
-    deg = (rp[1:] - rp[:-1]).to(torch.float32)
+    deg = (rp[1:] - rp[:-1]).to(torch.float32).to(dev)
     exact = torch.tensor([1.0 if bool((y1 == deg[:, None]).all()) else 0.0], dtype=torch.float64, device=dev)
     del ones, y1
 
     stats = torch.tensor([elapsed, kern_ms, float(agg.bytes_received_per_step(D)),
-                          float(agg.allgather_bytes_per_step(D)), exchange_ms, aggregate_ms], dtype=torch.float64, device=dev)
+                          float(agg.allgather_bytes_per_step(D)), exchange_ms, aggregate_ms, float(calls_per_step)],
+                         dtype=torch.float64, device=dev)
     sums = torch.tensor([float(nnz_local)], dtype=torch.float64, device=dev)
-    cpu = args.backend != "nccl"
-    if cpu:
+    if args.backend != "nccl":
         stats, sums, exact = stats.cpu(), sums.cpu(), exact.cpu()
     dist.all_reduce(stats, op=dist.ReduceOp.MAX)
     dist.all_reduce(sums, op=dist.ReduceOp.SUM)
     dist.all_reduce(exact, op=dist.ReduceOp.MIN)
     elapsed, kern_ms = float(stats[0]), float(stats[1])
     total_edges = float(sums[0])
+    t = kern_ms * 1e-3
+    comp = compulsory_bytes(nnz_local, n_local, n_global, D)
+    alg = gather_model_bytes(nnz_local, n_local, P, D)
+    leg = {
+        "leg": name, "value": total_edges * steps / elapsed, "unit": "edges/s", "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed * 1e3 / steps, "total_nnz": total_edges, "dim": D,
+        "verified": bool(float(exact[0]) == 1.0),
+        "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "partSize": ps, "num_parts_per_gpu": P,
+        "source_nodes": n_global, "parallelism": f"dst-range shards x{world} + " + agg.describe_exchange(),
+        "exchange": agg.exchange, "exchange_requested": exchange, "pieces": agg.chunks,
+        "bytes_received_per_rank_per_step": float(stats[2]), "allgather_bytes_per_rank_per_step": float(stats[3]),
+        "exchange_volume_vs_allgather": float(stats[2]) / float(stats[3]) if float(stats[3]) else None,
+        "exchange_only_ms": float(stats[4]), "aggregate_only_ms": float(stats[5]),
+        "exchange_GBs_per_rank": float(stats[2]) / (float(stats[4]) * 1e-3) / 1e9 if float(stats[4]) > 0 else None,
+        "calibrated_phases": calibrated,
+        "kernel": {"name": "stream_kernel (libgnna streaming kernel; one launch per library call)",
+                   "library_calls_per_step": float(stats[6]), "kernel_ms_per_step_max_over_ranks": kern_ms,
+                   "column_phases_last_call": phases_last,
+                   "kernel_edges_per_s": nnz_local / t if t > 0 else 0.0,
+                   "gather_model": {"bytes_per_step": alg, "GBs": alg / t / 1e9 if t > 0 else 0.0},
+                   "compulsory_model": {"bytes_per_step": comp, "GBs": comp / t / 1e9 if t > 0 else 0.0}},
+    }
+    del agg, X, out
+    torch.cuda.empty_cache()
+    return leg
 
+
+def run_sharded(args, result_fd, world, rank, local_rank):
+    """N ranks (one per GPU): the weak-scaling leg is the headline (`value`; every rank a Reddit-sized block -- at N = 1
+    exactly the single-GPU workload); `--scaling` adds the strong-scaling leg (the SAME Reddit-like graph split into N
+    nnz-balanced destination blocks) and, at 8 ranks (or with --config5-leg), BASELINE config 5 (papers100M-like,
+    D = 128, exchange chosen collectively)."""
+    import datetime
+    import torch
+    import torch.distributed as dist
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    limit = datetime.timedelta(seconds=600)                # a rank that dies must not hang the others for long
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev, timeout=limit)
+    else:
+        dist.init_process_group(args.backend, timeout=limit)
+
+    from gnnadvisor_osdi21_amd import _lib, graph
+    from gnnadvisor_osdi21_amd.dist import balanced_row_splits, shard_csr
+    _lib.load()
+    cfg = graph.CONFIGS[args.config]
+    D = args.dim
+    legs = {}
+
+    # ---- weak scaling (headline): every rank owns a Reddit-sized block whose sources are drawn from all ranks' nodes
+    n_local = max(2, int(cfg["num_nodes"] * args.scale))
+    e_target = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0))
+    n_global = n_local * world
+    rp, ci = graph.powerlaw_shard(n_local, n_global, e_target, min(cfg["max_degree"], n_global - 1),
+                                  seed=cfg["seed"] * 1000 + rank, device=dev, locality=args.locality,
+                                  block_start=rank * n_local)
+    bounds = [i * n_local for i in range(world + 1)]
+    legs["weak"] = sharded_leg(args, dev, world, rank, "weak", rp, ci, bounds, D, cfg["feat"],
+                               (1.0 - args.locality) * n_global / 3.0, args.steps, args.warmup, dist, args.exchange)
+    del rp, ci
+
+    want = [v for v in args.scaling.split(",") if v]
+    # ---- strong scaling: the SAME graph as the single-GPU line, split into `world` nnz-balanced destination blocks
+    if "strong" in want and world > 1:
+        g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
+        sb = balanced_row_splits(g.row_pointers, world)
+        srp, sci = shard_csr(g.row_pointers, g.column_index, sb[rank], sb[rank + 1])
+        span = g.avg_edgeSpan
+        n_all, nnz_all = g.num_nodes, g.nnz
+        del g
+        legs["strong"] = sharded_leg(args, dev, world, rank, "strong", srp, sci, sb, D, cfg["feat"], span,
+                                     args.steps, args.warmup, dist, args.exchange)
+        legs["strong"].update({"graph_nodes": n_all, "graph_nnz": nnz_all, "row_bounds": sb,
+                               "what": "the single-GPU line's graph split by nnz-balanced destination ranges"})
+        del srp, sci
+    # ---- BASELINE config 5: papers100M-like, D = 128, one destination shard per rank
+    if ("config5" in want and world == 8) or args.config5_leg:
+        c5 = graph.CONFIGS["papers100M-like"]
+        n5 = max(64, int(c5["num_nodes"] * args.config5_scale) // world)
+        e5 = int(c5["num_edges"] * args.config5_scale * c5.get("oversample", 1.0)) // world
+        rp5, ci5 = graph.powerlaw_shard(n5, n5 * world, e5, min(c5["max_degree"], n5 * world - 1),
+                                        seed=c5["seed"] * 1000 + rank, device=dev, block_start=rank * n5)
+        b5 = [i * n5 for i in range(world + 1)]
+        legs["config5"] = sharded_leg(args, dev, world, rank, "config5", rp5, ci5, b5, 128, c5["feat"],
+                                      n5 * world / 3.0, max(3, args.steps // 5), 2, dist, "auto")
+        legs["config5"]["what"] = ("BASELINE config 5: papers100M-like graph" + (f" at scale {args.config5_scale}" if args.config5_scale != 1.0 else "")
+                                   + f", D = 128, destination-partitioned over {world} ranks, exchange chosen collectively")
+        del rp5, ci5
+
+    # who ran: RCCL's view of the job and every rank's device
+    names = [None] * world
+    dist.all_gather_object(names, f"rank {rank}: {torch.cuda.get_device_name(dev)} (cuda:{local_rank})")
     if rank == 0:
-        t = kern_ms * 1e-3
-        comp = compulsory_bytes(nnz_local, n_local, n_global, D)
-        alg = gather_model_bytes(nnz_local, n_local, P, D)
+        weak = legs["weak"]
+        k = weak["kernel"]
+        t = k["kernel_ms_per_step_max_over_ranks"] * 1e-3
         rec = {
             "metric": "aggregated edges/sec, GCN sum-aggregation SpMM (SAG) hidden=64",
-            "value": total_edges * args.steps / elapsed, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "value": weak["value"], "unit": "edges/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": weak["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "verified": bool(float(exact[0]) == 1.0),
-            "verification": {"ones_exact_on_every_rank": bool(float(exact[0]) == 1.0)},
+            "verified": all(l["verified"] for l in legs.values()),
             "config": {"workload": f"{args.config} power-law graph, "
                                    + (f"id-local partition (locality={args.locality})" if args.locality else "random node order")
                                    + (f", scale={args.scale}" if args.scale != 1.0 else ""),
-                       "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "dim": D, "partSize": ps,
-                       "num_parts_per_gpu": P, "source_nodes": n_global,
-                       "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                       "num_nodes_per_gpu": weak["num_nodes_per_gpu"], "nnz_per_gpu": weak["nnz_per_gpu"], "dim": D,
+                       "partSize": weak["partSize"], "num_parts_per_gpu": weak["num_parts_per_gpu"],
+                       "source_nodes": weak["source_nodes"],
+                       "world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": names,
                        "device": str(dev) + (" (shared by all ranks)" if args.share_gpu else ""),
-                       "parallelism": f"dst-range shards x{world} + " + agg.describe_exchange(),
-                       "exchange": agg.exchange, "exchange_requested": args.exchange,
-                       "bytes_received_per_rank_per_step": float(stats[2]),
-                       "allgather_bytes_per_rank_per_step": float(stats[3]),
-                       "exchange_volume_vs_allgather": float(stats[2]) / float(stats[3]) if float(stats[3]) else None,
-                       "exchange_only_ms": float(stats[4]), "aggregate_only_ms": float(stats[5]),
-                       "exchange_GBs_per_rank": float(stats[2]) / (float(stats[4]) * 1e-3) / 1e9 if float(stats[4]) > 0 else None,
+                       "parallelism": weak["parallelism"], "exchange": weak["exchange"],
+                       "exchange_requested": args.exchange,
+                       "bytes_received_per_rank_per_step": weak["bytes_received_per_rank_per_step"],
+                       "allgather_bytes_per_rank_per_step": weak["allgather_bytes_per_rank_per_step"],
+                       "exchange_volume_vs_allgather": weak["exchange_volume_vs_allgather"],
+                       "exchange_only_ms": weak["exchange_only_ms"], "aggregate_only_ms": weak["aggregate_only_ms"],
+                       "exchange_GBs_per_rank": weak["exchange_GBs_per_rank"],
                        "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
-                       "calibrated_phases": calibrated, "tuning": _lib.get_tuning()},
+                       "calibrated_phases": weak["calibrated_phases"], "tuning": _lib.get_tuning(),
+                       "verified": all(l["verified"] for l in legs.values()),
+                       "verification": {n: {"ones_exact_on_every_rank": l["verified"]} for n, l in legs.items()},
+                       "legs": {n: l for n, l in legs.items() if n != "weak"},
+                       "values": {n: {"value": l["value"], "unit": "edges/s", "ms_per_step": l["ms_per_step"],
+                                      "scaling": "weak" if n == "weak" else ("strong" if n == "strong" else "config5 (fixed total graph)")}
+                                  for n, l in legs.items()}},
             "roofline": {"bound": "l2-fabric", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "achieved": comp / t / 1e9 if t > 0 else 0.0,
-                         "frac": comp / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
-                         "achieved_source": "compulsory model per rank (no PMC passes in multi-rank runs)",
-                         "traffic": None, "kernel": "agg_kernel", "kernel_ms": kern_ms,
-                         "library_calls_per_step": calls_per_step,
-                         "gather_model": {"bytes_per_step": alg, "GBs": alg / t / 1e9 if t > 0 else 0.0},
-                         "kernel_edges_per_s": nnz_local / t if t > 0 else 0.0},
+                         "achieved": k["compulsory_model"]["GBs"], "frac": k["compulsory_model"]["GBs"] / HBM_PEAK_GBS,
+                         "achieved_source": "compulsory model per rank (no PMC passes in multi-rank runs); the gather-model rate "
+                                            "is beside it",
+                         "traffic": None, "kernel": k["name"], "kernel_ms": k["kernel_ms_per_step_max_over_ranks"],
+                         "library_calls_per_step": k["library_calls_per_step"],
+                         "gather_model": k["gather_model"], "kernel_edges_per_s": k["kernel_edges_per_s"],
+                         "per_leg_kernels": {n: l["kernel"] for n, l in legs.items()}},
         }
         os.write(result_fd, (json.dumps(rec) + "\n").encode())
     dist.barrier()
