@@ -44,7 +44,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
-           "gnna_runtime_counters")
+           "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32")
 
 
 def load() -> ctypes.CDLL:
@@ -92,6 +92,14 @@ def load() -> ctypes.CDLL:
     L.gnna_csr_from_edges_i32.restype = ctypes.c_int64
     L.gnna_csr_from_edges_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                           ctypes.c_void_p, ctypes.c_void_p]
+    L.gnna_row_counts_i64.restype = ctypes.c_int
+    L.gnna_row_counts_i64.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+    L.gnna_row_splits_i64.restype = ctypes.c_int
+    L.gnna_row_splits_i64.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.gnna_csr_from_edges_range_i32.restype = ctypes.c_int64
+    L.gnna_csr_from_edges_range_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int64]
     L.gnna_degrees_f32.restype = ctypes.c_int
     L.gnna_degrees_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
     L.gnna_edge_span.restype = ctypes.c_int
@@ -206,6 +214,41 @@ def csr_from_edges(src, dst, num_nodes: int):
     ci = torch.empty(max(1, s.numel()), dtype=torch.int32)
     nnz = load().gnna_csr_from_edges_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes),
                                          rp.data_ptr(), ci.data_ptr())
+    if nnz < 0:
+        _check(int(nnz))
+    return rp, ci[:nnz].clone()
+
+
+def row_counts(rows, num_nodes: int, counts: torch.Tensor | None = None) -> torch.Tensor:
+    """int64 [num_nodes]: list entries per row, accumulated into `counts` when given (feed a long list in pieces)."""
+    r = _host_i32(rows)
+    if counts is None:
+        counts = torch.zeros(int(num_nodes), dtype=torch.int64)
+    assert counts.dtype == torch.int64 and counts.numel() == int(num_nodes) and counts.is_contiguous()
+    _check(load().gnna_row_counts_i64(r.data_ptr(), r.numel(), int(num_nodes), counts.data_ptr()))
+    return counts
+
+
+def row_splits(counts: torch.Tensor, world: int, want_row_pointers: bool = False):
+    """-> (bounds: list of world + 1 row boundaries of nnz-balanced contiguous blocks[, global int64 row_pointers])."""
+    assert counts.dtype == torch.int64 and counts.is_contiguous() and not counts.is_cuda
+    n = counts.numel()
+    bounds = torch.empty(int(world) + 1, dtype=torch.int64)
+    rp = torch.empty(n + 1, dtype=torch.int64) if want_row_pointers else None
+    _check(load().gnna_row_splits_i64(counts.data_ptr(), n, int(world), bounds.data_ptr(), _ptr(rp)))
+    return (bounds.tolist(), rp) if want_row_pointers else bounds.tolist()
+
+
+def csr_from_edges_range(src, dst, num_nodes: int, row_lo: int, row_hi: int, capacity: int | None = None):
+    """The CSR rows [row_lo, row_hi) of an edge list: (local int32 row_pointers rebased to 0, GLOBAL int32 column ids)."""
+    s, d = _host_i32(src), _host_i32(dst)
+    assert s.numel() == d.numel()
+    if capacity is None:
+        capacity = int(((s >= row_lo) & (s < row_hi)).sum()) if s.numel() else 0
+    rp = torch.empty(int(row_hi - row_lo) + 1, dtype=torch.int32)
+    ci = torch.empty(max(1, int(capacity)), dtype=torch.int32)
+    nnz = load().gnna_csr_from_edges_range_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes), int(row_lo),
+                                               int(row_hi), rp.data_ptr(), ci.data_ptr(), int(capacity))
     if nnz < 0:
         _check(int(nnz))
     return rp, ci[:nnz].clone()

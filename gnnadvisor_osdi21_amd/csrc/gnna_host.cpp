@@ -304,6 +304,125 @@ int64_t gnna_csr_from_edges_i32(const int32_t *src, const int32_t *dst, int64_t 
     return nnz;
 }
 
+// ---- sharded ingestion: 64-bit edge counts, one destination-row range per rank ---------------------------
+int gnna_row_counts_i64(const int32_t *rows, int64_t num_edges, int64_t num_nodes, int64_t *counts)
+{
+    if (num_edges < 0 || num_nodes < 0 || (num_nodes > 0 && !counts) || (num_edges > 0 && !rows))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad row count arguments");
+    // per-thread histograms over slabs of the edge list, then summed (an edge list of > 2^31 entries is fine)
+    unsigned hw = std::thread::hardware_concurrency();
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 16), num_edges / (1 << 22) + 1));
+    std::vector<std::vector<int64_t>> part((size_t)nt);
+    std::vector<int64_t> bad((size_t)nt, -1);
+    std::vector<std::thread> th;
+    const int64_t step = (num_edges + nt - 1) / nt;
+    for (int64_t t = 0; t < nt; t++) {
+        th.emplace_back([&, t] {
+            auto &h = part[(size_t)t];
+            h.assign((size_t)num_nodes, 0);
+            const int64_t lo = t * step, hi = std::min(num_edges, lo + step);
+            for (int64_t e = lo; e < hi; e++) {
+                const int32_t r = rows[e];
+                if (r < 0 || r >= num_nodes) { bad[(size_t)t] = e; return; }
+                h[(size_t)r]++;
+            }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int64_t t = 0; t < nt; t++)
+        if (bad[(size_t)t] >= 0)
+            return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld: row %d outside [0, %lld)", (long long)bad[(size_t)t],
+                              rows[bad[(size_t)t]], (long long)num_nodes);
+    parallel_rows(num_nodes, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++)
+            for (int64_t t = 0; t < nt; t++) counts[i] += part[(size_t)t][(size_t)i];
+    });
+    return GNNA_OK;
+}
+
+int gnna_row_splits_i64(const int64_t *counts, int64_t num_nodes, int world, int64_t *bounds, int64_t *row_pointers)
+{
+    if (num_nodes < 0 || world < 1 || !bounds || (num_nodes > 0 && !counts))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad row split arguments");
+    // global 64-bit row pointers (papers100M symmetrised has > 2^31 edges) ...
+    std::vector<int64_t> own;
+    int64_t *rp = row_pointers;
+    if (!rp) { own.resize((size_t)num_nodes + 1); rp = own.data(); }
+    rp[0] = 0;
+    for (int64_t i = 0; i < num_nodes; i++) {
+        if (counts[i] < 0) return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "negative count at row %lld", (long long)i);
+        rp[i + 1] = rp[i] + counts[i];
+    }
+    // ... cut into `world` contiguous blocks of about equal edge count: block b ends behind the first row whose
+    // running count reaches b / world of the total (the rule of dist.balanced_row_splits)
+    const int64_t nnz = rp[num_nodes];
+    bounds[0] = 0;
+    for (int b = 1; b < world; b++) {
+        const long double target = (long double)nnz * b / world;
+        const int64_t *it = std::lower_bound(rp + 1, rp + num_nodes + 1, target,
+                                             [](int64_t v, long double t) { return (long double)v < t; });
+        int64_t cut = (int64_t)(it - (rp + 1)) + 1;
+        cut = std::min<int64_t>(std::max<int64_t>(cut, bounds[b - 1]), num_nodes);
+        bounds[b] = cut;
+    }
+    bounds[world] = num_nodes;
+    return GNNA_OK;
+}
+
+int64_t gnna_csr_from_edges_range_i32(const int32_t *src, const int32_t *dst, int64_t num_edges, int64_t num_nodes,
+                                      int64_t row_lo, int64_t row_hi, int32_t *row_pointers, int32_t *column_index,
+                                      int64_t capacity)
+{
+    if (num_edges < 0 || num_nodes < 0 || row_lo < 0 || row_hi < row_lo || row_hi > num_nodes || !row_pointers ||
+        capacity < 0 || (num_edges > 0 && (!src || !dst)) || (capacity > 0 && !column_index))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad edge range arguments");
+    const int64_t rows = row_hi - row_lo;
+    // pass 1: the shard's rows (64-bit counts: the edge LIST may exceed 2^31 entries, the shard may not)
+    std::vector<int64_t> start((size_t)rows + 1, 0);
+    for (int64_t e = 0; e < num_edges; e++) {
+        const int32_t s = src[e], d = dst[e];
+        if (s < 0 || s >= num_nodes || d < 0 || d >= num_nodes)
+            return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)e, s, d,
+                              (long long)num_nodes);
+        if (s >= row_lo && s < row_hi) start[(size_t)(s - row_lo) + 1]++;
+    }
+    for (int64_t i = 0; i < rows; i++) start[(size_t)i + 1] += start[(size_t)i];
+    const int64_t mine = start[(size_t)rows];
+    if (mine > 0x7fffffffLL)
+        return gnna::fail(GNNA_ERR_UNSUPPORTED, "%lld edges in rows [%lld, %lld): more than 2^31-1 per shard -- use more ranks",
+                          (long long)mine, (long long)row_lo, (long long)row_hi);
+    // pass 2: bucket by row, then per-row sort + unique (scipy coo->csr semantics, dataset.py:108-118)
+    std::vector<int32_t> bucket((size_t)mine);
+    {
+        std::vector<int64_t> cursor(start.begin(), start.end() - 1);
+        for (int64_t e = 0; e < num_edges; e++) {
+            const int32_t s = src[e];
+            if (s >= row_lo && s < row_hi) bucket[(size_t)cursor[(size_t)(s - row_lo)]++] = dst[e];
+        }
+    }
+    std::vector<int32_t> uniq((size_t)rows, 0);
+    parallel_rows(rows, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++) {
+            int32_t *b = bucket.data() + start[(size_t)i], *e = bucket.data() + start[(size_t)i + 1];
+            std::sort(b, e);
+            uniq[(size_t)i] = (int32_t)(std::unique(b, e) - b);
+        }
+    });
+    int64_t nnz = 0;
+    for (int64_t i = 0; i < rows; i++) nnz += uniq[(size_t)i];
+    if (nnz > capacity)
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "column_index holds %lld entries, the shard has %lld", (long long)capacity,
+                          (long long)nnz);
+    nnz = 0;
+    row_pointers[0] = 0;
+    for (int64_t i = 0; i < rows; i++) {
+        std::copy_n(bucket.data() + start[(size_t)i], uniq[(size_t)i], column_index + nnz);
+        nnz += uniq[(size_t)i];
+        row_pointers[i + 1] = (int32_t)nnz;
+    }
+    return nnz;
+}
+
 int gnna_degrees_f32(const int32_t *row_pointers, int64_t num_nodes, float *degrees)
 {
     if (num_nodes < 0 || (num_nodes > 0 && (!row_pointers || !degrees)))

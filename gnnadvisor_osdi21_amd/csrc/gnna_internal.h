@@ -129,11 +129,12 @@ struct SweepLaunch {
     int rounds = 0;           // sets per workgroup (0: from rows_with_edges and the accumulator capacity)
     int64_t rows_with_edges = 0;
     int slack = 0;            // soft-barrier slack in steps (0: built-in, >= 1000: none)
+    int wgs_per_cu = 0;       // 1: one 16-wavefront workgroup per CU; else two (32 wavefronts, 64 VGPRs)
     bool plain_ok;
     float eps;
 };
 bool sweep_supports(int mode, int dim, size_t x_bytes);
-int sweep_acc_rows(int dim);   // destination rows a wavefront's LDS accumulators hold at this width
+int sweep_acc_rows(int dim, int wgs_per_cu);   // destination rows a workgroup's LDS accumulators hold at this width
 int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream);
 constexpr int kSweepSyncSlots = 64;    // ring of per-call counter blocks (kXcds x 64 bytes each)
 

@@ -52,8 +52,14 @@ constexpr int kSweepIdSlots = 512;   // column ids parked in LDS per wavefront a
 constexpr int kSweepBlock = 1024;
 constexpr int kSweepWaves = kSweepBlock / kWave;
 
-// LDS accumulator floats per workgroup: what 160 KiB leave next to the wavefronts' id lists.
-template <int LPR> constexpr int acc_floats() { return LPR >= 16 ? 32768 : 28672; }   // 128 KiB / 112 KiB
+// LDS accumulator floats per workgroup: what 160 KiB leave next to the wavefronts' id lists.  WGS = workgroups per
+// CU: 1 -> 16 wavefronts per CU with all of the LDS (128 / 112 KiB of accumulators, up to 128 VGPRs);
+// 2 -> 32 wavefronts per CU (two workgroups of 60 / 44 KiB of accumulators each, 64 VGPRs): twice the latency chains
+// in flight for the per-item round trips (descriptors -> ids -> rows), half the rows per set.
+template <int LPR, int WGS> constexpr int acc_floats()
+{
+    return WGS == 1 ? (LPR >= 16 ? 32768 : 28672) : (LPR >= 16 ? 15360 : 11264);
+}
 
 // ds_add_f32 on a pointer that is known to point into LDS (an if-converted choice between an LDS and a global
 // destination would otherwise become ONE flat atomic, which counts on vmcnt as well and stalls the load ring)
@@ -106,8 +112,8 @@ __device__ __forceinline__ int64_t lower_bound64(const int32_t *__restrict__ pp,
     return lo;
 }
 
-template <int LPR, int MODE, int U>
-__global__ void __launch_bounds__(kSweepBlock)
+template <int LPR, int MODE, int U, int WGS>
+__global__ void __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(4 * WGS, 4 * WGS)))
 sweep_kernel(const SweepParams p)
 {
     typedef typename VecOf<4>::T VT;
@@ -115,7 +121,7 @@ sweep_kernel(const SweepParams p)
     constexpr int RPI = kWave / LPR;                                   // neighbor rows per wave-wide load
     constexpr int RL = (kSweepIdSlots / RPI < kWave) ? kSweepIdSlots / RPI : kWave;   // loads per round
     static_assert(RL % U == 0, "a round is a whole number of batches");
-    constexpr int ACC = acc_floats<LPR>();
+    constexpr int ACC = acc_floats<LPR, WGS>();
     __shared__ float s_acc[ACC];                          // partial rows of the workgroup's set
     __shared__ uint32_t s_off[kSweepWaves][RL * RPI];     // per wavefront: the round's list slots as byte offsets into X
     __shared__ int64_t s_g[2];                            // the set's group range
@@ -425,34 +431,35 @@ sweep_kernel(const SweepParams p)
 
 typedef void (*SweepKernel)(const SweepParams);
 
-template <int LPR, int MODE>
+template <int LPR, int MODE, int WGS>
 SweepKernel pick_sweep_u(int u)
 {
     constexpr int RPI = kWave / LPR;
     constexpr int RL = (kSweepIdSlots / RPI < kWave) ? kSweepIdSlots / RPI : kWave;
-    if constexpr (RL % 8 == 0) {
-        if (u >= 8) return sweep_kernel<LPR, MODE, 8>;
+    if constexpr (RL % 8 == 0 && WGS == 1) {
+        if (u >= 8) return sweep_kernel<LPR, MODE, 8, WGS>;
     }
-    return sweep_kernel<LPR, MODE, 4>;
+    return sweep_kernel<LPR, MODE, 4, WGS>;
 }
 
-template <int MODE>
+template <int MODE, int WGS>
 SweepKernel pick_sweep(int lpr, int u)
 {
     switch (lpr) {
-    case 4: return pick_sweep_u<4, MODE>(u);
-    case 8: return pick_sweep_u<8, MODE>(u);
-    case 16: return pick_sweep_u<16, MODE>(u);
-    default: return pick_sweep_u<32, MODE>(u);
+    case 4: return pick_sweep_u<4, MODE, WGS>(u);
+    case 8: return pick_sweep_u<8, MODE, WGS>(u);
+    case 16: return pick_sweep_u<16, MODE, WGS>(u);
+    default: return pick_sweep_u<32, MODE, WGS>(u);
     }
 }
 
 }  // namespace
 
-int sweep_acc_rows(int dim)
+int sweep_acc_rows(int dim, int wgs)
 {
     const int pieces = (dim + 3) / 4;
-    const int acc = pieces <= 8 ? acc_floats<8>() : acc_floats<16>();
+    const int acc = wgs == 1 ? (pieces <= 8 ? acc_floats<8, 1>() : acc_floats<16, 1>())
+                             : (pieces <= 8 ? acc_floats<8, 2>() : acc_floats<16, 2>());
     return std::max(1, acc / std::max(1, dim));
 }
 
@@ -471,12 +478,14 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     int lpr = 4;
     const int pieces = (a.D + 3) / 4;
     while (lpr < 32 && lpr < pieces) lpr <<= 1;
-    SweepKernel k = a.mode == MODE_GIN ? pick_sweep<MODE_GIN>(lpr, a.U) : pick_sweep<MODE_SAG>(lpr, a.U);
-    // persistent grid: one workgroup per CU (all of the CU's LDS), the same number on every XCD
+    const int wgs = a.wgs_per_cu == 1 ? 1 : 2;
+    SweepKernel k = wgs == 1 ? (a.mode == MODE_GIN ? pick_sweep<MODE_GIN, 1>(lpr, a.U) : pick_sweep<MODE_SAG, 1>(lpr, a.U))
+                             : (a.mode == MODE_GIN ? pick_sweep<MODE_GIN, 2>(lpr, a.U) : pick_sweep<MODE_SAG, 2>(lpr, a.U));
+    // persistent grid: `wgs` workgroups per CU (together all of the CU's LDS), the same number on every XCD
     const int cus_per_xcd = std::max(1, ds->num_cus / kXcds);
-    const unsigned grid = (unsigned)(cus_per_xcd * kXcds);
+    const unsigned grid = (unsigned)(cus_per_xcd * kXcds * wgs);
     // sets per workgroup: as few as keep a set's rows (on average, with some head room) inside the accumulators
-    const int cap = sweep_acc_rows(a.D);
+    const int cap = sweep_acc_rows(a.D, wgs);
     int R = a.rounds;
     if (R <= 0) {
         const double rows = (double)std::max<int64_t>(1, a.rows_with_edges);

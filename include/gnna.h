@@ -90,6 +90,24 @@ GNNA_API int64_t gnna_csr_from_edges_i32(const int32_t *src, const int32_t *dst,
                                 int64_t num_nodes, int32_t *row_pointers /* [num_nodes + 1] */,
                                 int32_t *column_index /* [num_edges] */);
 
+/* Sharded ingestion (multi-GPU, SURVEY 8e "index width"; extends dataset.py:99-122, which builds one int32 CSR):
+ * the edge LIST may hold more than 2^31 entries (papers100M symmetrised: 3.2e9) and is counted with 64-bit
+ * arithmetic; every rank then builds only the CSR rows of its own destination range, whose edge count must fit
+ * int32 (GNNA_ERR_UNSUPPORTED otherwise: use more ranks).
+ *   gnna_row_counts_i64: counts[r] += number of list entries with rows[e] == r (accumulates, so a list can be fed
+ *     in pieces; raw entries -- duplicates are merged later, per shard);
+ *   gnna_row_splits_i64: global 64-bit row pointers of those counts (row_pointers may be NULL) and `world` + 1
+ *     row bounds that cut the rows into contiguous blocks of about equal edge count;
+ *   gnna_csr_from_edges_range_i32: the CSR of rows [row_lo, row_hi) only -- local int32 row_pointers
+ *     [row_hi - row_lo + 1] rebased to 0, GLOBAL column ids, duplicates merged, columns sorted per row (the
+ *     semantics of gnna_csr_from_edges_i32); returns the shard's nnz (<= capacity) or a negative gnna_status. */
+GNNA_API int gnna_row_counts_i64(const int32_t *rows, int64_t num_edges, int64_t num_nodes, int64_t *counts /* [num_nodes] */);
+GNNA_API int gnna_row_splits_i64(const int64_t *counts, int64_t num_nodes, int world, int64_t *bounds /* [world + 1] */,
+                                 int64_t *row_pointers /* [num_nodes + 1] or NULL */);
+GNNA_API int64_t gnna_csr_from_edges_range_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
+                                               int64_t num_nodes, int64_t row_lo, int64_t row_hi,
+                                               int32_t *row_pointers, int32_t *column_index, int64_t capacity);
+
 /* degrees[i] = sqrt(max(row_pointers[i+1] - row_pointers[i], 1))  (dataset.py:11-18,121-122) */
 GNNA_API int gnna_degrees_f32(const int32_t *row_pointers, int64_t num_nodes, float *degrees);
 

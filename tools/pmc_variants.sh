@@ -24,9 +24,8 @@ import csv, glob, os, sys, json
 out = sys.argv[1]
 print("| variant (GNNA_TUNE) | kernel ms | FETCH GB (x2 calibrated) | WRITE GB | L2 hit | L2 req M | EA RD M | EA WR M | EA ATOMIC M |")
 print("|---|---|---|---|---|---|---|---|---|")
-for vd in sorted(glob.glob(os.path.join(out, "v[0-9]*")), key=lambda p: int(os.path.basename(p)[1:])):
-    if not os.path.isdir(vd):
-        continue
+for vd in sorted((d for d in glob.glob(os.path.join(out, "v[0-9]*")) if os.path.isdir(d)),
+                 key=lambda p: int(os.path.basename(p)[1:])):
     var = open(os.path.join(vd, "VARIANT")).read().strip()
     vals = {}
     for f in glob.glob(os.path.join(vd, "**", "*counter_collection.csv"), recursive=True):
