@@ -28,7 +28,15 @@ import torch.nn.functional as F  # noqa: E402
 
 def build_parser():
     p = argparse.ArgumentParser(description="sharded GCN / GIN training epochs (one process per GPU)")
-    p.add_argument("--synthetic", type=str, default="papers100M-like", help="graph.CONFIGS name")
+    p.add_argument("--synthetic", type=str, default="papers100M-like", help="graph.CONFIGS name (used when no --dataset is given)")
+    p.add_argument("--dataDir", type=str, default="../osdi-ae-graphs", help="directory of the graph file (GNNA_main.py:20)")
+    p.add_argument("--dataset", type=str, default="", help="graph file stem: <dataDir>/<dataset>.npz (keys src_li, dst_li, "
+                                                             "num_nodes) or, with --loadFromTxt True, <dataDir>/<dataset> as a "
+                                                             "'src dst' text edge list; every rank builds only its own rows")
+    p.add_argument("--loadFromTxt", default="False", choices=["True", "False"])
+    p.add_argument("--enable_rabbit", default="False", choices=["True", "False"],
+                   help="renumber the nodes for locality (native community renumbering, once, on rank 0) before the split")
+    p.add_argument("--exchange", default="auto", choices=["auto", "halo", "allgather"])
     p.add_argument("--scale", type=float, default=1.0, help="shrink the whole graph (nodes and edges)")
     p.add_argument("--dim", type=int, default=0, help="input width (0: the config's)")
     p.add_argument("--hidden", type=int, default=0, help="hidden width (0: the config's)")
@@ -73,16 +81,32 @@ def main(argv=None):
     fin = args.dim or cfg["feat"]
     hidden = args.hidden or cfg["hidden"]
     ncls = args.classes or cfg["classes"]
-    n_global = max(world * 2, int(cfg["num_nodes"] * args.scale))
-    n_local = n_global // world                                   # equal blocks (the generator is uniform over rows)
-    n_global = n_local * world
-    e_local = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0)) // world
-    rp, ci = graph.powerlaw_shard(n_local, n_global, e_local, min(cfg["max_degree"], n_global - 1),
-                                  seed=cfg["seed"] * 1000 + rank, device=dev)
-    bounds = [i * n_local for i in range(world + 1)]
+    if args.dataset:
+        # a graph file: every rank reads the edge list and builds only the CSR rows of its nnz-balanced block
+        from .loader import load_graph_shard
+        txt = args.loadFromTxt == "True"
+        path = os.path.join(args.dataDir, args.dataset + ("" if txt else ".npz"))
+
+        def share(t, src_rank):
+            t = t.to(dev) if args.backend == "nccl" else t
+            dist.broadcast(t, src=src_rank)
+            return t.cpu()
+        shard = load_graph_shard(path, rank, world, load_from_txt=txt, reorder=args.enable_rabbit == "True",
+                                 share_fn=share if world > 1 else None, verbose=verbose)
+        rp, ci, bounds = shard.row_pointers.to(dev), shard.column_index.to(dev), shard.bounds
+        n_global = shard.num_nodes
+        n_local = bounds[rank + 1] - bounds[rank]
+    else:
+        n_global = max(world * 2, int(cfg["num_nodes"] * args.scale))
+        n_local = n_global // world                                   # equal blocks (the generator is uniform over rows)
+        n_global = n_local * world
+        e_local = int(cfg["num_edges"] * args.scale * cfg.get("oversample", 1.0)) // world
+        rp, ci = graph.powerlaw_shard(n_local, n_global, e_local, min(cfg["max_degree"], n_global - 1),
+                                      seed=cfg["seed"] * 1000 + rank, device=dev)
+        bounds = [i * n_local for i in range(world + 1)]
     avg_degree = ci.numel() / max(1, n_local)
     ps = args.partSize or choose_part_size(avg_degree, hidden)
-    agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, pipeline_chunks=args.pipeline_chunks)
+    agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, pipeline_chunks=args.pipeline_chunks, exchange=args.exchange)
     # sqrt(max(deg, 1)) of the local rows (dataset.py:121-122; in-degree == out-degree on a symmetric graph)
     deg_local = (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32).sqrt()
     gen = torch.Generator(device=dev).manual_seed(100 + rank)

@@ -139,3 +139,69 @@ class custom_dataset(torch.nn.Module):
             print("# Reorder time (s): {}".format(time.perf_counter() - start))
         self.avg_edgeSpan_after = _lib.edge_span(self.edge_index[0], self.edge_index[1])
         self._build_csr("# Re-Build CSR (s): {:.3f}")
+
+
+# ---------------------------------------------------------------------------------------------- sharded ingestion
+def read_edge_list(path, load_from_txt: bool):
+    """The reference's two file formats (dataset.py:59-91): -> (src, dst, num_nodes) as numpy arrays."""
+    if load_from_txt:
+        pairs = np.loadtxt(path, dtype=np.int64, ndmin=2, usecols=(0, 1))
+        src, dst = pairs[:, 0], pairs[:, 1]
+        return src, dst, (int(max(src.max(), dst.max())) + 1 if len(src) else 0)
+    if not str(path).endswith(".npz"):
+        raise ValueError("graph file must be a .npz file")
+    obj = np.load(path)
+    return obj["src_li"], obj["dst_li"], int(obj["num_nodes"])
+
+
+class GraphShard:
+    """One rank's part of a graph file: the CSR rows of its destination range (local int32 row_pointers, GLOBAL
+    int32 column ids), the nnz-balanced row bounds of all ranks, and the whole-graph statistics the Decider reads."""
+
+    def __init__(self, num_nodes, bounds, rank, row_pointers, column_index, num_edges, avg_degree, avg_edgeSpan, new_id):
+        self.num_nodes, self.bounds, self.rank = int(num_nodes), [int(b) for b in bounds], int(rank)
+        self.row_pointers, self.column_index = row_pointers, column_index
+        self.num_edges, self.avg_degree, self.avg_edgeSpan = int(num_edges), float(avg_degree), float(avg_edgeSpan)
+        self.new_id = new_id                                   # new_id[old id] when the nodes were renumbered, else None
+        self.degrees = _lib.degrees(row_pointers)              # sqrt(max(deg, 1)) of the local rows (dataset.py:121-122)
+
+    @property
+    def row_range(self):
+        return self.bounds[self.rank], self.bounds[self.rank + 1]
+
+
+def load_graph_shard(path, rank: int, world: int, load_from_txt: bool = False, reorder: bool = False,
+                     reorder_method: str = "community", share_fn=None, verbose: bool = False,
+                     _edges=None) -> GraphShard:
+    """Sharded counterpart of ``custom_dataset`` (dataset.py:55-122) for one-process-per-GPU jobs: every rank reads the
+    edge list, the rows are cut into ``world`` contiguous nnz-balanced blocks from 64-bit row counts (an edge list of
+    more than 2^31 entries -- papers100M symmetrised -- is fine; a single shard must stay below 2^31), and this rank
+    builds ONLY the CSR of its own block (duplicates merged, columns sorted: the loader's semantics).
+
+    ``reorder``: the nodes are renumbered for locality first (``gnna_reorder_community_i32``; the role of
+    dataset.py:138-172) -- by ONE rank, the others receive ``new_id`` through ``share_fn(tensor_or_None, src_rank=0)``
+    (e.g. a ``torch.distributed`` broadcast), so the permutation is computed once and is the same everywhere.  Fewer
+    remote sources per shard is what the halo exchange lives on."""
+    t0 = time.perf_counter()
+    src, dst, n = _edges if _edges is not None else read_edge_list(path, load_from_txt)
+    src = np.ascontiguousarray(src, dtype=np.int32)
+    dst = np.ascontiguousarray(dst, dtype=np.int32)
+    num_edges = int(len(src))
+    new_id = None
+    if reorder:
+        if share_fn is None or rank == 0:
+            renumber = _lib.reorder_rcm if reorder_method == "rcm" else _lib.reorder_community
+            new_id = renumber(src, dst, n)
+        if share_fn is not None:
+            new_id = share_fn(new_id if rank == 0 else torch.empty(n, dtype=torch.int32), 0)
+        perm = new_id.numpy()
+        src, dst = perm[src], perm[dst]
+    counts = _lib.row_counts(src, n)
+    bounds = _lib.row_splits(counts, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    rp, ci = _lib.csr_from_edges_range(src, dst, n, lo, hi, capacity=int(counts[lo:hi].sum()))
+    span = _lib.edge_span(src, dst)
+    if verbose:
+        print("# rank {}: rows [{}, {}) of {}, {} of {} edges, {:.3f} s".format(rank, lo, hi, n, ci.numel(), num_edges,
+                                                                                 time.perf_counter() - t0))
+    return GraphShard(n, bounds, rank, rp, ci, num_edges, num_edges / n if n else 0.0, span, new_id)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from gnnadvisor_osdi21_amd import _lib
+from gnnadvisor_osdi21_amd import _lib, graph
 from gnnadvisor_osdi21_amd.loader import custom_dataset
 
 
@@ -146,3 +146,80 @@ def test_reorder_hook_rebuilds_csr_and_degrees():
     np.testing.assert_array_equal(ds.degrees.numpy(), oracle.np_degrees(orp))
     # relabelling preserves the degree multiset
     assert sorted(np.diff(orp).tolist()) == sorted(np.diff(rp0.numpy()).tolist())
+
+
+# ---- sharded ingestion (every rank builds only its destination range; 64-bit edge counts) ------------------------
+def _edge_list_with_duplicates(n=700, e=12000, seed=5):
+    g = graph.powerlaw_graph(n, e, 80, seed=seed)
+    rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long()).numpy()
+    cols = g.column_index.numpy()
+    rng = np.random.default_rng(seed)
+    dup = rng.integers(0, len(rows), size=500)                       # duplicates: merged per shard, as by the loader
+    order = rng.permutation(len(rows) + len(dup))
+    return g, np.concatenate([rows, rows[dup]])[order], np.concatenate([cols, cols[dup]])[order]
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+@pytest.mark.parametrize("fmt", ["npz", "txt"])
+def test_sharded_loader_builds_exactly_each_ranks_rows(tmp_path, world, fmt):
+    from gnnadvisor_osdi21_amd import loader
+    g, src, dst = _edge_list_with_duplicates()
+    if fmt == "npz":
+        path = tmp_path / "g.npz"
+        np.savez(path, src_li=src, dst_li=dst, num_nodes=g.num_nodes)
+    else:
+        path = tmp_path / "g.txt"
+        np.savetxt(path, np.stack([src, dst], 1), fmt="%d")
+    total = 0
+    for rank in range(world):
+        sh = loader.load_graph_shard(str(path), rank, world, load_from_txt=(fmt == "txt"))
+        lo, hi = sh.row_range
+        assert sh.bounds[0] == 0 and sh.bounds[-1] == g.num_nodes and sh.bounds == sorted(sh.bounds)
+        want_rp = (g.row_pointers[lo:hi + 1] - g.row_pointers[lo]).int()
+        assert torch.equal(sh.row_pointers, want_rp)
+        assert torch.equal(sh.column_index, g.column_index[int(g.row_pointers[lo]):int(g.row_pointers[hi])])
+        assert torch.allclose(sh.degrees, g.degrees[lo:hi])
+        assert sh.num_edges == len(src) and abs(sh.avg_degree - len(src) / g.num_nodes) < 1e-9
+        total += sh.column_index.numel()
+    assert total == g.nnz
+    # blocks are balanced by edge count, not by row count
+    if world > 1:
+        per = [int(g.row_pointers[sh.bounds[r + 1]] - g.row_pointers[sh.bounds[r]]) for r in range(world)]
+        assert max(per) - min(per) <= 2 * int((g.row_pointers[1:] - g.row_pointers[:-1]).max()) + 600
+
+
+def test_row_counts_and_splits_are_64_bit():
+    """papers100M symmetrised has 3.2e9 edges: counts, global row pointers and the nnz-balanced bounds use int64; a
+    single shard beyond 2^31 - 1 edges is refused."""
+    counts = torch.full((1000,), 3_000_000, dtype=torch.int64)
+    counts[::7] += 1_234_567
+    bounds, rp = _lib.row_splits(counts, 8, want_row_pointers=True)
+    total = int(counts.sum())
+    assert total > 2 ** 31 and int(rp[-1]) == total and rp.dtype == torch.int64
+    assert bounds[0] == 0 and bounds[-1] == 1000
+    per = [int(rp[bounds[i + 1]] - rp[bounds[i]]) for i in range(8)]
+    assert max(per) - min(per) <= 2 * int(counts.max())
+    # accumulate in pieces (how a > 2^31-entry list is fed)
+    rows = torch.randint(0, 50, (10000,), dtype=torch.int32, generator=torch.Generator().manual_seed(1))
+    c = _lib.row_counts(rows[:4000], 50)
+    _lib.row_counts(rows[4000:], 50, c)
+    assert torch.equal(c, torch.bincount(rows.long(), minlength=50))
+    with pytest.raises(_lib.GnnaError):
+        _lib.row_counts(torch.tensor([0, 51], dtype=torch.int32), 50)
+    with pytest.raises(_lib.GnnaError):
+        _lib.csr_from_edges_range(torch.tensor([0, 1], dtype=torch.int32), torch.tensor([1, 0], dtype=torch.int32), 2, 0, 2,
+                                  capacity=1)                        # capacity too small
+
+
+def test_sharded_loader_with_renumbering_is_a_relabelled_graph():
+    from gnnadvisor_osdi21_amd import loader
+    g, src, dst = _edge_list_with_duplicates(n=400, e=6000, seed=8)
+    shards = [loader.load_graph_shard(None, r, 3, reorder=True, _edges=(src, dst, 400)) for r in range(3)]
+    new_id = shards[0].new_id.numpy()
+    assert sorted(new_id.tolist()) == list(range(400))
+    assert all(np.array_equal(s.new_id.numpy(), new_id) for s in shards)
+    # the union of the shards is the CSR of the relabelled edge list
+    rp_all, ci_all = _lib.csr_from_edges(new_id[src], new_id[dst], 400)
+    for s in shards:
+        lo, hi = s.row_range
+        assert torch.equal(s.column_index, ci_all[int(rp_all[lo]):int(rp_all[hi])])
