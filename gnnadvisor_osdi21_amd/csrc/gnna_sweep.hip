@@ -16,8 +16,10 @@
 //
 //   * the partial rows of the set (up to 512 rows of 64 floats) live in the CU's LDS (ds_add_f32; no global
 //     atomics, nothing read back) while the workgroup walks the source slices 0 .. B-1;
-//   * inside the workgroup the (chunk of 64 groups, slice) items of a set are a pool that the wavefronts drain
-//     dynamically (an LDS counter), in slice order: a wavefront that drew a short item simply draws the next;
+//   * inside the workgroup every wavefront owns an equal, contiguous share of the set's groups, so a destination
+//     row is touched by ONE wavefront (plain LDS read-add-write) unless it straddles the border between two
+//     wavefronts' shares (those two rows per wavefront use ds_add_f32: an LDS float atomic costs ~190 LDS cycles
+//     per wave-instruction -- with atomics for every row the LDS pipe was busy 1.3 ms of a 2.0 ms launch);
 //   * every row is written ONCE, after the last slice: a plain coalesced store when the set owns the row, one
 //     atomic add when the row continues in a neighbouring set;
 //   * the workgroups of an XCD (blockIdx % 8) walk the slices in step: a workgroup starts items of slice step t
@@ -125,7 +127,7 @@ sweep_kernel(const SweepParams p)
     __shared__ float s_acc[ACC];                          // partial rows of the workgroup's set
     __shared__ uint32_t s_off[kSweepWaves][RL * RPI];     // per wavefront: the round's list slots as byte offsets into X
     __shared__ int64_t s_g[2];                            // the set's group range
-    __shared__ int s_ctl[8];                              // 0 next item, 1 items done, 2 last seen XCD counter, 3 gave up
+    __shared__ int s_ctl[8];                              // 1 wavefront-steps done, 2 last seen XCD counter, 3 gave up
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -175,7 +177,6 @@ sweep_kernel(const SweepParams p)
         if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
         __syncthreads();
         const int64_t g_lo = s_g[0], g_hi = s_g[1];
-        const int nchunks = (int)((g_hi - g_lo + kWave - 1) / kWave);
         int row_first = 0, row_last = -1, set_prev_row = -1, set_next_row = -1;
         if (g_hi > g_lo) {
             row_first = p.p2n[g_lo];
@@ -188,20 +189,18 @@ sweep_kernel(const SweepParams p)
         for (int i = threadIdx.x; i < nrows * D; i += kSweepBlock) s_acc[i] = 0.f;
         __syncthreads();
 
-        const int total_items = nchunks * B;
-        if (nchunks == 0 && syncing && threadIdx.x == 0)                 // nothing to do: still counts as arrived
-            (void)__hip_atomic_fetch_add(ctr, (uint32_t)B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (true) {
-            int item = 0;
-            if (lane == 0) item = __hip_atomic_fetch_add(&s_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            item = __builtin_amdgcn_readfirstlane(item);
-            if (item >= total_items) break;
-            const int t = item / nchunks;                                // slice step of the item (items are drawn in step order)
-            const int chunk = item - t * nchunks;
+        // this wavefront's share of the set: an equal, contiguous range of its groups
+        const int64_t ng_set = g_hi - g_lo;
+        const int64_t gw_lo = g_lo + (ng_set * wib) / kSweepWaves, gw_hi = g_lo + (ng_set * (wib + 1)) / kSweepWaves;
+        const int nch_w = (int)((gw_hi - gw_lo + kWave - 1) / kWave);
+        // rows that continue in a neighbouring wavefront's share: the only accumulator rows two wavefronts add to
+        const int wave_prev_row = (gw_lo > g_lo && gw_hi > gw_lo) ? p.p2n[gw_lo - 1] : -1;
+        const int wave_next_row = (gw_hi < g_hi && gw_hi > gw_lo) ? p.p2n[gw_hi] : -1;
+        for (int t = 0; t < B; t++) {
             const int T = r * B + t;
 
             // ---- soft barrier: every workgroup of the XCD has finished step T - slack -------------------------
-            if (syncing && T >= p.slack) {
+            if (syncing && T >= p.slack && nch_w > 0) {
                 const uint32_t need = (uint32_t)nbx * (uint32_t)(T - p.slack + 1);
                 const int seen = __hip_atomic_load(&s_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int gave_up = __hip_atomic_load(&s_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -223,10 +222,11 @@ sweep_kernel(const SweepParams p)
                 }
             }
 
+            for (int chunk = 0; chunk < nch_w; chunk++)
             {
                 const int f_lo = t * p.S / B, f_hi = (t + 1) * p.S / B;
-                const int64_t g0 = g_lo + (int64_t)chunk * kWave;
-                const int ng = (int)(g_hi - g0 < (int64_t)kWave ? g_hi - g0 : (int64_t)kWave);
+                const int64_t g0 = gw_lo + (int64_t)chunk * kWave;
+                const int ng = (int)(gw_hi - g0 < (int64_t)kWave ? gw_hi - g0 : (int64_t)kWave);
 
                 // ---- 1. descriptors (all loads in flight together) -------------------------------------
                 const bool gl = lane < ng;
@@ -261,6 +261,7 @@ sweep_kernel(const SweepParams p)
                     const bool last_in_seg = n > 0 && (next_head == 64 || between != 0);
                     const int aslot = my_row - row_first;
                     const int over = (aslot < 0 || aslot >= nrows) ? 1 : 0;   // not in the accumulators: flushed per slice
+                    const int edge = (my_row == wave_prev_row || my_row == wave_next_row) ? 4 : 0;   // shared with a neighbour wavefront
 
                     // non-empty pieces compacted to lanes 0 .. Rn-1
                     const int rank = __popcll(NE & (upto >> 1));
@@ -269,7 +270,7 @@ sweep_kernel(const SweepParams p)
                     const int c_pbeg = __builtin_amdgcn_ds_permute(dstl, pa + beg);
                     const int t_n = __builtin_amdgcn_ds_permute(dstl, n);
                     const int c_n = lane < Rn ? t_n : 0;
-                    const int c_meta = __builtin_amdgcn_ds_permute(dstl, ((over ? my_row : aslot) << 2) | (last_in_seg ? 2 : 0) | over);
+                    const int c_meta = __builtin_amdgcn_ds_permute(dstl, ((over ? my_row : aslot) << 3) | edge | (last_in_seg ? 2 : 0) | over);
                     const int c_nl = (c_n + RPI - 1) / RPI;
                     const int c_offI = wave_inclusive_scan(c_nl);
                     const int c_offX = c_offI - c_nl;
@@ -345,20 +346,33 @@ sweep_kernel(const SweepParams p)
                                 const int meta = __builtin_amdgcn_readlane(k_meta, j);
                                 const VT rr = fold_row<LPR, MODE_SAG>(acc, 1.f);
                                 if (!(meta & 1)) {
-                                    // the set's own accumulator row: LDS add, no memory traffic
-                                    float *dst = s_acc + (meta >> 2) * D + dcol;
-                                    if constexpr (LPR <= 16) {
-                                        if (add_lane) lds_add(dst + comp, rr[0]);
-                                    } else {
-                                        if (add_lane) {
+                                    // the set's own accumulator row: LDS, no memory traffic.  A row inside this wavefront's
+                                    // share is its own (plain read-add-write); a border row is shared with one neighbour
+                                    float *dst = s_acc + (meta >> 3) * D + dcol;
+                                    if (meta & 4) {
+                                        if constexpr (LPR <= 16) {
+                                            if (add_lane) lds_add(dst + comp, rr[0]);
+                                        } else {
+                                            if (add_lane) {
 #pragma unroll
-                                            for (int q = 0; q < 4; q++)
-                                                if (q >= shift) lds_add(dst + q, rr[q]);
+                                                for (int q = 0; q < 4; q++)
+                                                    if (q >= shift) lds_add(dst + q, rr[q]);
+                                            }
+                                        }
+                                    } else {
+                                        if constexpr (LPR <= 16) {
+                                            if (add_lane) dst[comp] += rr[0];
+                                        } else {
+                                            if (add_lane) {
+#pragma unroll
+                                                for (int q = 0; q < 4; q++)
+                                                    if (q >= shift) dst[q] += rr[q];
+                                            }
                                         }
                                     }
                                 } else {
                                     // not in the accumulators: add to the (zero-filled) output now, as stream_kernel does
-                                    const int64_t row = meta >> 2;
+                                    const int64_t row = meta >> 3;
                                     float scale = 1.f;
                                     if constexpr (MODE == MODE_GIN) {
                                         scale = p.eps;
@@ -398,10 +412,10 @@ sweep_kernel(const SweepParams p)
                     }
                 }
             }
-            // ---- the item is done; the wavefront that completes a slice step of the workgroup arrives ---------
+            // ---- this wavefront's part of step t is done; the last one of the workgroup arrives for it -----------
             if (syncing && lane == 0) {
                 const int done = __hip_atomic_fetch_add(&s_ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
-                if (done % nchunks == 0)
+                if (done % kSweepWaves == 0)
                     (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }

@@ -320,3 +320,67 @@ def test_one_process_emulation_of_every_rank_matches_the_whole_graph(exchange, c
         assert np.allclose(Ys.numpy(), want[0][lo:hi], atol=1e-4), (rank, "sag")
         assert np.allclose(Yg.numpy(), want[1][lo:hi], rtol=1e-4, atol=1e-2), (rank, "gcn")
         assert np.allclose(Yi.numpy(), want[2][lo:hi], atol=1e-4), (rank, "gin")
+
+
+def _worker_file(rank, world, port, path, n, dim, seed, q, reorder):
+    """Two ranks ingest the same .npz: each builds only its own destination rows (loader.load_graph_shard) and
+    aggregates through the sharded path; with `reorder` the node renumbering is computed by rank 0 and broadcast."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnnadvisor_osdi21_amd.loader import load_graph_shard
+
+        def share(t, src):
+            dist.broadcast(t, src=src)
+            return t
+        sh = load_graph_shard(path, rank, world, reorder=reorder, share_fn=share)
+        lo, hi = sh.row_range
+        X_old = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1))   # features by ORIGINAL node id
+        X = X_old
+        if reorder:
+            X = torch.empty_like(X_old)
+            X[sh.new_id.long()] = X_old                                                 # row new_id[i] holds node i
+        agg = ShardedAggregator(sh.row_pointers, sh.column_index, sh.bounds, 4, aggregate_fn=_oracle_aggregate,
+                                build_part_fn=_oracle_build_part, exchange="auto")
+        Y = agg.sag(X[lo:hi].contiguous())
+        Yg = agg.aggregate(X[lo:hi].contiguous(), 1, degrees_local=sh.degrees)
+        q.put((rank, lo, hi, Y.numpy(), Yg.numpy(), None if sh.new_id is None else sh.new_id.numpy(), agg.exchange))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("reorder", [False, True])
+def test_two_ranks_ingest_a_graph_file_and_match_the_single_process_result(tmp_path, reorder):
+    n, dim, seed = 180, 6, 21
+    g = graph.powerlaw_graph(n, 3000, 50, seed=seed, locality=0.8, window=8)
+    rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long()).numpy()
+    perm = np.random.default_rng(3).permutation(n)                   # scramble the ids: something to renumber
+    src, dst = perm[rows], perm[g.column_index.numpy()]
+    path = str(tmp_path / "graph.npz")
+    np.savez(path, src_li=src, dst_li=dst, num_nodes=n)
+    # single-process reference on the file's own numbering (loader semantics: dedup + sort)
+    from gnnadvisor_osdi21_amd import _lib
+    rp1, ci1 = _lib.csr_from_edges(src, dst, n)
+    deg1 = _lib.degrees(rp1)
+    X_old = torch.randn(n, dim, generator=torch.Generator().manual_seed(seed + 1))
+    want = oracle.csr_f64(0, X_old.numpy(), rp1.numpy(), ci1.numpy())
+    want_g = oracle.csr_f64(1, X_old.numpy(), rp1.numpy(), ci1.numpy(), deg1.numpy())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_file, args=(r, 2, port, path, n, dim, seed, q, reorder)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    covered = 0
+    for rank, lo, hi, Y, Yg, new_id, exchange in res:
+        # row r of the shard is node `old` with new_id[old] == lo + r (identity without renumbering)
+        old = np.arange(lo, hi) if new_id is None else np.argsort(new_id)[lo:hi]
+        assert np.allclose(Y, want[old], atol=1e-4), rank
+        assert np.allclose(Yg, want_g[old], rtol=1e-4, atol=1e-2), rank
+        covered += hi - lo
+    assert covered == n

@@ -44,3 +44,40 @@ def assert_close_f64(got, ref64, rtol=1e-4, what="", scale=None):
 
 def oracle_inputs(g, X, pp, p2n):
     return (X.numpy(), g.column_index.numpy(), pp.numpy(), p2n.numpy())
+
+
+def dense_adjacency(g, dtype=torch.float64):
+    n = g.num_nodes
+    A = torch.zeros(n, n, dtype=dtype)
+    rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+    A[rows, g.column_index.long()] = 1.0
+    return A
+
+
+def gcn_gin_reference(g, F, W1, W2, wgt, eps=0.5):
+    """fp64 reference of  y = GIN(relu(GCN(F)))  = (eps A relu(Ahat (F W1))) W2  with loss = sum(y * wgt) on a SYMMETRIC
+    graph (scipy CSR, explicit backward), and the sum-of-|terms| scale of every result: the same network evaluated on
+    |F|, |W1|, |W2| with relu' = 1 (A, Ahat, wgt are non-negative), whose values / gradients bound the magnitude sums fp32
+    rounding errors are proportional to.  -> {name: (reference, scale)} for out, dF, dW1, dW2 -- compared as
+    |got - ref| <= 1e-4 * max(1, scale)."""
+    import scipy.sparse as sp
+    n = g.num_nodes
+    rp, ci, deg = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.double().numpy()
+    A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(n, n))
+    Ahat = sp.diags(deg) @ A @ sp.diags(deg)
+    w = wgt.detach().double().cpu().numpy()
+    res = {}
+    for tag in ("ref", "abs"):
+        f = (lambda t: t) if tag == "ref" else np.abs
+        Fn, W1n, W2n = (f(t.detach().double().cpu().numpy()) for t in (F, W1, W2))
+        H1 = Ahat @ (Fn @ W1n)
+        mask = (H1 > 0).astype(np.float64) if tag == "ref" else np.ones_like(H1)
+        Rl = np.maximum(H1, 0.0) if tag == "ref" else H1
+        T = eps * (A @ Rl)
+        Y = T @ W2n
+        dY = np.broadcast_to(w, Y.shape)
+        dW2 = T.T @ dY
+        dH1 = (eps * (A.T @ (dY @ W2n.T))) * mask
+        G = Ahat.T @ dH1
+        res[tag] = dict(out=Y, dF=G @ W1n.T, dW1=Fn.T @ G, dW2=dW2)
+    return {k: (res["ref"][k], res["abs"][k]) for k in res["ref"]}
