@@ -786,6 +786,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     const bool prescale = mode == MODE_GCN && (tune.gcn_prescale == 1 || (tune.gcn_prescale == 0 && hot_rows));
     int ldx = dim;
     if (tune.pad_rows == 1 || (tune.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);
+    if (tune.pad_rows > 2 && tune.pad_rows >= dim) ldx = tune.pad_rows;   // (experiments: an explicit row stride in floats)
     p.ldx = ldx;
     p.row_scale = nullptr;
     const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);

@@ -110,14 +110,23 @@ def test_bench_launches_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                          "--steps", "3", "--warmup", "1", "--scale", "0.1"], cwd=root, env=env, capture_output=True,
-                         text=True, timeout=600)
+                          "--steps", "3", "--warmup", "1", "--scale", "0.05", "--config5-leg", "--config5-scale", "0.01"],
+                         cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, res.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["world_size"] == 2 and rec["verified"] is True
     assert rec["value"] > 0 and rec["config"]["bytes_received_per_rank_per_step"] > 0
+    # the three legs of an N-rank line: weak scaling (the headline), strong scaling of the single-GPU graph, config 5
+    legs, values = rec["config"]["legs"], rec["config"]["values"]
+    assert set(values) == {"weak", "strong", "config5"} and set(legs) == {"strong", "config5"}
+    assert values["weak"]["value"] == rec["value"] and rec["scaling"] == "weak"
+    assert legs["strong"]["verified"] and legs["config5"]["verified"]
+    assert legs["strong"]["row_bounds"][0] == 0 and legs["strong"]["row_bounds"][-1] == legs["strong"]["graph_nodes"]
+    assert legs["config5"]["dim"] == 128 and legs["config5"]["bytes_received_per_rank_per_step"] > 0
+    assert len(rec["config"]["ranks"]) == 2 and "stream_kernel" in rec["roofline"]["kernel"]
+    assert set(rec["roofline"]["per_leg_kernels"]) == {"weak", "strong", "config5"}
 
 
 def test_drop_in_call_sequence_is_as_fast_as_the_tuned_path():

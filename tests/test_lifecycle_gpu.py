@@ -1,0 +1,143 @@
+"""Graph lifecycle of the C ABI (gnna_prepare_graph / gnna_release_graph), the launch path's promises after a
+prepare (no synchronisation, no allocation, no free; the sliced schedule also inside a stream capture), and
+BASELINE config 2's literal check (Citeseer-sized graph against dense torch.mm through the module GNNAdvisor)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib, graph, load_extension
+from util import assert_close_f64, dev, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_citeseer_like_vs_dense_torch_mm():
+    """BASELINE config 2: "Citeseer GCN ... SpMM correctness vs dense torch.mm" (reference unitest.py builds the same
+    comparison with torch_sparse): the dense 3,327 x 3,327 adjacency, X = ones exact and X = randn within 1e-4 of
+    the sum of |terms|, through GNNA.SAG with the reference's manual knobs (partSize 32, dimWorker 32, warpPerBlock 4)."""
+    GNNA = load_extension()
+    g = graph.make_config_graph("citeseer-like")
+    n, D = g.num_nodes, 16
+    assert n == 3327
+    partPtr, part2Node = GNNA.build_part(32, g.row_pointers)
+    rp, ci, deg, pp, p2n = dev(g.row_pointers, g.column_index, g.degrees, partPtr.int(), part2Node.int())
+    A = torch.zeros(n, n, device="cuda", dtype=torch.float64)
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (rp[1:] - rp[:-1]).long())
+    A[rows, ci.long()] = 1.0
+    ones = torch.ones(n, D, device="cuda")
+    y1 = GNNA.SAG(ones, rp, ci, deg, pp, p2n, 32, 32, 4)
+    assert torch.equal(y1.double(), torch.mm(A, ones.double()))                     # exact
+    assert torch.equal(y1, torch.mm(A.float(), ones))                               # ... also against the fp32 dense product
+    X = torch.randn(n, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    y = GNNA.SAG(X, rp, ci, deg, pp, p2n, 32, 32, 4)
+    ref, scale = torch.mm(A, X.double()), torch.mm(A, X.double().abs())
+    assert bool(((y.double() - ref).abs() <= 1e-4 * scale.clamp(min=1.0)).all())
+    for D2 in (6, 64):                                                              # the class count and a hidden width
+        X2 = torch.randn(n, D2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+        y2 = GNNA.SAG(X2, rp, ci, deg, pp, p2n, 32, 32, 4)
+        assert bool(((y2.double() - torch.mm(A, X2.double())).abs() <= 1e-4 * torch.mm(A, X2.double().abs()).clamp(min=1.0)).all())
+
+
+def _big_case(seed=31):
+    g = graph.make_config_graph("reddit-like", device="cuda", scale=0.25)
+    pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+    X = torch.randn(g.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(seed))
+    return g, X, pp.cuda(), p2n.cuda()
+
+
+def test_prepare_makes_the_launch_path_silent_and_capture_takes_the_sliced_schedule():
+    """After gnna_prepare_graph no aggregation on that graph synchronises, allocates or frees, the phase count it
+    reports is the one the calls use, and a call INSIDE a stream capture takes the sliced schedule (it used to
+    degrade to a single pass when the plan was missing)."""
+    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+        pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
+    g, X, ppd, p2nd = _big_case()
+    out = torch.empty_like(X)
+    side = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(side):
+            chosen = _lib.prepare_graph(g.column_index, ppd, p2nd, g.num_nodes, g.num_nodes, 64, [64, 16])
+        side.synchronize()
+        assert chosen[64] > 1, chosen
+        before = _lib.runtime_counters()
+        hg = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(hg, stream=side):                      # FIRST aggregation on this graph: inside a capture
+                _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4, out=out)
+                assert _lib.last_num_phases() == chosen[64] > 1
+        for _ in range(3):
+            _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4, out=out)   # eager calls too
+            assert _lib.last_num_phases() == chosen[64]
+        after = _lib.runtime_counters()
+        for k in ("plan_builds", "launch_syncs", "launch_frees", "launch_mallocs"):
+            assert after[k] == before[k], (k, before, after)
+        out.fill_(float("nan"))
+        hg.replay()
+        torch.cuda.synchronize()
+        rows = torch.randint(0, g.num_nodes, (100,), generator=torch.Generator().manual_seed(1)).tolist()
+        for r in rows:
+            b, e = int(g.row_pointers[r]), int(g.row_pointers[r + 1])
+            xs = X[g.column_index[b:e].long()].double()
+            assert bool(((out[r].double() - xs.sum(0)).abs() <= 1e-4 * xs.abs().sum(0).clamp(min=1.0)).all()), r
+    finally:
+        _lib.release_graph(g.column_index)
+
+
+def test_forty_prepared_graphs_cycle_without_a_free_on_the_launch_path():
+    """Prepared plans are pinned: they do not take part in the least-recently-used replacement of the 32 automatic
+    plans, so cycling through 40 graphs costs no counting pass, no synchronisation and no hipFree / hipMalloc."""
+    cases = []
+    for i in range(40):
+        g, X, pp, p2n = make_case(1500, 60000, 64, 16, seed=300 + i, kind="powerlaw")
+        Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+        _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 16, [64])
+        cases.append((g, X, Xd, rp, ci, deg, ppd, p2nd))
+    try:
+        _lib.set_tuning(column_phases=4)
+        for c in cases:                                                  # (scratch of the default stream, once)
+            _lib.sag(c[2], c[3], c[4], c[5], c[6], c[7], 16, 32, 4)
+        torch.cuda.synchronize()
+        before = _lib.runtime_counters()
+        outs = []
+        for rep in range(3):
+            for c in cases:
+                outs.append(_lib.sag(c[2], c[3], c[4], c[5], c[6], c[7], 16, 32, 4))
+                assert _lib.last_num_phases() == 4
+        torch.cuda.synchronize()
+        after = _lib.runtime_counters()
+        for k in ("plan_builds", "launch_syncs", "launch_frees", "launch_mallocs", "backoff_skips"):
+            assert after[k] == before[k], (k, before, after)
+        for i in (0, 17, 39):
+            g, X = cases[i][0], cases[i][1]
+            assert_close_f64(outs[80 + i].cpu().numpy(),
+                             oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()), what=f"graph {i}")
+    finally:
+        _lib.reset_tuning()
+        for c in cases:
+            _lib.release_graph(c[4])
+
+
+def test_unprepared_graphs_back_off_when_no_partition_is_seen_twice():
+    """Automatic plans: a stream of partitions that are each used once (tensors re-allocated per step) stops paying a
+    counting pass and a synchronisation per call after a streak of unused evictions; results stay correct."""
+    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+        pytest.skip("GNNA_TUNE forces the schedule")
+    _lib.release_graph(None)
+    g = graph.make_config_graph("reddit-like", device="cuda", scale=0.06)
+    X = torch.randn(g.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+    before = _lib.runtime_counters()
+    keep = []
+    for i in range(60):
+        ci = g.column_index.clone()                                      # a fresh address every step
+        keep.append(ci)
+        y = _lib.sag(X, g.row_pointers, ci, g.degrees, pp.cuda(), p2n.cuda(), 64, 32, 4)
+    after = _lib.runtime_counters()
+    assert after["backoff_skips"] > before["backoff_skips"], (before, after)
+    assert after["plan_builds"] - before["plan_builds"] < 60
+    r = 123
+    b, e = int(g.row_pointers[r]), int(g.row_pointers[r + 1])
+    xs = X[g.column_index[b:e].long()].double()
+    assert bool(((y[r].double() - xs.sum(0)).abs() <= 1e-4 * xs.abs().sum(0).clamp(min=1.0)).all())
+    _lib.release_graph(None)

@@ -276,7 +276,9 @@ def test_full_size_reddit_like_properties():
     yl = _lib.sag(2.0 * X - 0.5 * Z, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 32, 32, 4)
     ref = 2.0 * yx.double() - 0.5 * yz.double()
     err = (yl.double() - ref).abs()
-    assert bool((err <= 1e-4 * ref.abs().clamp(min=1.0) * 8).all()), float(err.max())
+    # both sides carry fp32 summation error proportional to the sum of |terms|: A (2 |X| + 0.5 |Z|)
+    scale = _lib.sag(2.0 * X.abs() + 0.5 * Z.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 32, 32, 4).double()
+    assert bool((err <= 1e-4 * scale.clamp(min=1.0)).all()), float((err / scale.clamp(min=1.0)).max())
     # sampled rows against the fp64 formula
     rows = torch.randperm(n, generator=torch.Generator().manual_seed(9))[:2000]
     rp_c, ci_c, X_c = g.row_pointers.cpu(), g.column_index.cpu(), X.cpu().double()
@@ -374,7 +376,7 @@ def test_config5_papers100M_like_shard():
         assert bool(((yg[r].double() - ref).abs() <= 1e-4 * scale).all()), r
 
 
-@pytest.mark.parametrize("phases", [2, 3, 8, 16])
+@pytest.mark.parametrize("phases", [2, 3, 8, 16, 24, 32])
 @pytest.mark.parametrize("partSize,dim", [(32, 64), (7, 16), (64, 100), (100, 8), (32, 257), (8, 602), (700, 64), (2000, 16)])
 def test_column_phased_schedule_matches_single_pass(phases, partSize, dim):
     """The column-phased schedule (X gathered in `phases` source-id ranges, one launch each)
@@ -528,10 +530,12 @@ def test_stale_slice_plan_costs_locality_not_correctness():
     each group's positions whatever they hold) -- also with unsorted ids."""
     g, X, pp, p2n = make_case(3000, 240000, 64, 16, seed=77, kind="powerlaw")
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
-    try:
-        _lib.set_tuning(column_phases=8)
+    for forced in (8, 32):
+      ci.copy_(g.column_index)
+      try:
+        _lib.set_tuning(column_phases=forced)
         y0 = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
-        assert _lib.last_num_phases() == 8
+        assert _lib.last_num_phases() == forced
         assert_close_f64(y0.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
                          what="fresh plan")
         gen = torch.Generator().manual_seed(5)
@@ -540,11 +544,11 @@ def test_stale_slice_plan_costs_locality_not_correctness():
                              ("all ids in the last slice", torch.full((g.nnz,), g.num_nodes - 1))):
             ci.copy_(new_ci.to(torch.int32))                       # in place: the cached plan now describes another graph
             y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
-            assert _lib.last_num_phases() == 8
+            assert _lib.last_num_phases() == forced
             ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), new_ci.to(torch.int32).numpy())
             scale = oracle.csr_f64(0, X.abs().numpy(), g.row_pointers.numpy(), new_ci.to(torch.int32).numpy())
             assert_close_f64(y.cpu().numpy(), ref, what=what, scale=scale)
-    finally:
+      finally:
         _lib.reset_tuning()
 
 
