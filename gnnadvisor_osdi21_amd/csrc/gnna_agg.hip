@@ -120,10 +120,11 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
 //   * a row that continues from the previous work item (both items add to it atomically).
 // One wavefront per 64 consecutive groups; every gap is cleared by the whole wavefront (coalesced).
 // The result is only meaningful for a canonical partition: the validation raises the flag as before and
-// zero_if_flag_kernel, launched behind this kernel, then clears the whole output.
+// post_prologue_kernel, launched behind this kernel, then clears the whole output.
 __global__ void __launch_bounds__(kBlock)
 sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *__restrict__ p2n,
-                       const int32_t *__restrict__ pp, int64_t P, int G, int32_t *flag, int32_t seq, int validate)
+                       const int32_t *__restrict__ pp, int64_t P, int G, int32_t *flag, int32_t seq, int validate,
+                       unsigned long long *gaps, int64_t big_rows)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -131,6 +132,18 @@ sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *_
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     const bool vec_ok = (D & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0;
     auto clear_rows = [&](int64_t lo, int64_t cnt) {      // wave-uniform arguments
+        // a long run of rows without edges (trailing isolated or padded rows of a multi-GB shard) is not one
+        // wavefront's job: it goes on the call's gap list and post_prologue_kernel clears it with the whole grid
+        if (gaps && cnt >= big_rows) {
+            unsigned long long idx = 0;
+            if (lane == 0) idx = atomicAdd(&gaps[0], 1ull);
+            idx = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(idx >> 32)) << 32) |
+                  (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+            if (idx < (unsigned long long)kGapEntries) {
+                if (lane == 0) { gaps[2 + 2 * idx] = (unsigned long long)lo; gaps[3 + 2 * idx] = (unsigned long long)cnt; }
+                return;
+            }
+        }
         float *base = Y + (size_t)lo * (size_t)D;
         const size_t n = (size_t)cnt * (size_t)D;
         if (vec_ok) {
@@ -178,15 +191,26 @@ sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *_
     if (validate && bad) *flag = seq;
 }
 
-// whole-output zero-fill when the validation behind a sparse prologue found the partition not canonical
-// (the streaming kernel then adds every row atomically); returns at once otherwise
+// behind a sparse prologue: the whole output when the validation found the partition not canonical (the streaming
+// kernel then adds every row atomically), else the long gaps the prologue put on the call's list; returns at once
+// when there is neither
 __global__ void __launch_bounds__(kBlock)
-zero_if_flag_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *flag, int32_t seq)
+post_prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, const int32_t *flag, int32_t seq,
+                     const unsigned long long *gaps)
 {
-    if (*flag != seq) return;
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = tid; i < n_floats; i += nthreads) Y[i] = 0.f;
+    if (*flag == seq) {
+        for (size_t i = tid; i < n_floats; i += nthreads) Y[i] = 0.f;
+        return;
+    }
+    if (!gaps) return;
+    const unsigned long long n = gaps[0] < (unsigned long long)kGapEntries ? gaps[0] : (unsigned long long)kGapEntries;
+    for (unsigned long long k = 0; k < n; k++) {
+        float *base = Y + (size_t)gaps[2 + 2 * k] * (size_t)D;
+        const size_t cnt = (size_t)gaps[3 + 2 * k] * (size_t)D;
+        for (size_t i = tid; i < cnt; i += nthreads) base[i] = 0.f;
+    }
 }
 
 // ---- GCN pre-scaling: Xs[j, :] = deg[j] * X[j, :] -------------------------------------------
@@ -590,7 +614,7 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     levels = std::min(levels, kSliceLevels);
     while (b > 1 && lvl < levels && piece(lvl) < 16.0) { b >>= 1; lvl++; }
     if (lvl >= levels) b = 1;
-    const size_t mall = (size_t)160 << 20;
+    const size_t mall = (size_t)250000000;   // (of 256 MiB; products-like D = 100: four slices of 245 MB, 7.0 ms against 7.8 with two)
     if (x_bytes > mall) {
         int bm = 2, lm = levels - 1;              // fewest slices that fit the Infinity Cache (cells[levels - 1] <-> 2 slices)
         while (bm < S && x_bytes / bm > mall) { bm <<= 1; lm--; }
@@ -731,11 +755,13 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         if (sparse_G > 0 && zero_fill && num_parts > 0) {
             int64_t blocks = (num_parts + kBlock - 1) / kBlock;
             blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
+            unsigned long long *gaps = ds->gap_lists + (size_t)((uint32_t)seq % kGapSlots) * kGapWords;
+            (void)hipMemsetAsync(gaps, 0, sizeof(unsigned long long), stream);
+            const int64_t big_rows = std::max<int64_t>(64, ((int64_t)1 << 20) / std::max(1, dim * 4));   // >= 1 MiB of zeros
             hipLaunchKernelGGL(sparse_prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, num_nodes, dim,
-                               part2Node, part_pointers, num_parts, sparse_G, flag, seq, validate);
-            if (validate)
-                hipLaunchKernelGGL(zero_if_flag_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(kBlock), 0, stream, out,
-                                   n_floats, flag, seq);
+                               part2Node, part_pointers, num_parts, sparse_G, flag, seq, validate, gaps, big_rows);
+            hipLaunchKernelGGL(post_prologue_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(kBlock), 0, stream, out,
+                               n_floats, dim, flag, seq, gaps);
         } else {
             size_t work = std::max(n_floats / 4, (size_t)num_parts);
             int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);

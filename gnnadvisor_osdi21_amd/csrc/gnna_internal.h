@@ -42,11 +42,14 @@ struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
     int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
+    unsigned long long *gap_lists = nullptr;   // ring of kGapSlots lists of kGapWords words
     uint32_t *sweep_sync = nullptr;  // ring of kSweepSyncSlots counter blocks for the sweep kernel's soft barrier
     std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
     std::map<hipStream_t, CursorOwner> cursor_owner;
 };
 constexpr int kFlagSlots = 1024;
+// per-call lists of long runs of rows without edges that the sparse prologue leaves to a grid-wide pass
+constexpr int kGapSlots = 64, kGapEntries = 63, kGapWords = 2 + 2 * kGapEntries;   // word 0: count, pairs (first row, rows)
 
 // State of the current device (lazily created: CU count, flag ring).
 int get_device_state(DeviceState **out);

@@ -39,6 +39,11 @@ int get_device_state(DeviceState **out)
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(flags): %s", hipGetErrorString(e));
             e = hipMemset(s.flags, 0, kFlagSlots * sizeof(int32_t));
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMemset(flags): %s", hipGetErrorString(e));
+            const size_t gap_bytes = (size_t)kGapSlots * kGapWords * sizeof(unsigned long long);
+            e = hipMalloc(reinterpret_cast<void **>(&s.gap_lists), gap_bytes);
+            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(gap lists): %s", hipGetErrorString(e));
+            e = hipMemset(s.gap_lists, 0, gap_bytes);
+            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMemset(gap lists): %s", hipGetErrorString(e));
             const size_t sync_bytes = (size_t)kSweepSyncSlots * 8 * 64;
             e = hipMalloc(reinterpret_cast<void **>(&s.sweep_sync), sync_bytes);
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(sweep counters): %s", hipGetErrorString(e));

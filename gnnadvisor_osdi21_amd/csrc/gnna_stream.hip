@@ -702,7 +702,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
     if (hit->uses > 0 && hit->last_stream != stream) hit->multi_stream = true;
     hit->last_stream = stream;
     hit->uses++;
-    if (hit->uses > 1) g_cold_evictions = 0;
+    if (hit->uses > 1) { g_cold_evictions = 0; g_skip_builds = 0; }   // partitions do come back: count again
     if (pin) hit->pinned = true;
     hit->stamp = ++g_plan_clock;
     out->cnt = hit->cnt;
@@ -721,6 +721,7 @@ int release_slice_plans(const void *column_index)
 {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     int dropped = 0;
+    if (!column_index) { g_cold_evictions = 0; g_skip_builds = 0; }
     for (size_t i = 0; i < g_plans.size();) {
         Plan *pl = g_plans[i];
         if (column_index && pl->col != column_index) { i++; continue; }

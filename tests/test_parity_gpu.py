@@ -240,6 +240,32 @@ def test_sparse_zero_fill_clears_exactly_the_rows_nobody_stores(G, dim):
         _lib.reset_tuning()
 
 
+@pytest.mark.parametrize("spacing,tail", [(5000, 0), (40, 450000), (1, 590000)])
+def test_sparse_zero_fill_hands_long_runs_of_empty_rows_to_the_whole_grid(spacing, tail):
+    """Rows without edges in runs of >= 1 MiB (trailing isolated / padded rows of a shard, or many long gaps: more than
+    the 63 a call's list holds) are cleared by a grid-wide pass behind the sparse prologue, not by the one wavefront
+    that finds the gap; every element of a NaN-poisoned output must still be written."""
+    n, dim, ps = 600000, 64, 8
+    rows_with_edges = torch.arange(0, n - tail, spacing)
+    gen = torch.Generator().manual_seed(spacing)
+    deg = torch.randint(1, 20, (rows_with_edges.numel(),), generator=gen)
+    src = torch.repeat_interleave(rows_with_edges, deg)
+    dst = torch.randint(0, n, (int(deg.sum()),), generator=gen)
+    g = graph.graph_from_edges(src, dst, n)
+    pp, p2n = _lib.build_part(ps, g.row_pointers)
+    X = torch.randn(n, dim, generator=gen)
+    Xd, rp, ci, degd, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    try:
+        _lib.set_tuning(zero_fill=1, column_phases=1)
+        y = _lib.sag(Xd, rp, ci, degd, ppd, p2nd, ps, 32, 4)             # fresh output: NaN-poisoned by the test config
+        yi = _lib.agg_gin(Xd, rp, ci, 0.5, ppd, p2nd, ps, 32, 4)
+    finally:
+        _lib.reset_tuning()
+    ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+    assert_close_f64(y.cpu().numpy(), ref, what=f"long gaps spacing={spacing} tail={tail}")
+    assert_close_f64(yi.cpu().numpy(), 0.5 * ref, what="long gaps gin")
+
+
 def test_invalid_arguments_are_reported():
     g, X, pp, p2n = make_case(10, 40, 8, 4, seed=1)
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
