@@ -713,6 +713,19 @@ def run_single(args, result_fd):
     _lib.load()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
+    if args.config.startswith("rank-of-"):
+        # profiling aid (tools/profile_gpu.sh): the timed loop of one config-5 form on its own, e.g.
+        #   bench.py --headline-only --config rank-of-8/allgather-one-call --dim 128 --steps 5 --warmup 2
+        world5, form5 = args.config[len("rank-of-"):].split("/")
+        w5 = RankOf8Workload(dev, args.dim, form=form5, world=int(world5), scale=args.scale, manual=args.manual)
+        e5, p5 = w5.time(args.steps, args.warmup)
+        rec = {"metric": "aggregated edges/sec, config 5 per-rank shape", "value": w5.g.nnz * args.steps / e5, "unit": "edges/s",
+               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": e5 * 1e3 / args.steps,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": args.config, "shape": w5.describe()},
+               "roofline": roofline_record(w5, p5["main_ms"], p5["prologue_ms"], None, "hbm")}
+        os.write(result_fd, (json.dumps(rec) + "\n").encode())
+        return
     w = Workload(args.config, args.dim, dev, scale=args.scale, locality=args.locality, manual=args.manual,
                  part_size=args.partSize, calibrate=not args.headline_only)
     elapsed, prof = w.time(args.steps, args.warmup)

@@ -864,7 +864,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         if (!cnt || B < 2) { B = 1; cnt = nullptr; }
         // Destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
         // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
-        if (cnt && tune.sweep == 1 && sweep_supports(mode, dim, x_bytes)) {
+        if (cnt && tune.sweep == 1 && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
             int Bs = B;
             if (tune.column_phases < 2) {             // not forced: slices of about half an XCD's L2
                 Bs = 2;
@@ -899,9 +899,26 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         t_last_launches = 1;
         a.wide = wide; a.plain_ok = (B == 1 && !accumulate_into_out); a.xcd_remap = tune.xcd_remap != 0;
         a.eps = p.eps;
+        if (tune.deterministic == 1) {
+            // ordered phase launches, owned rows read-modify-written, rows shared between chunks summed in chunk order
+            // from partials parked in the stream's scratch (slot 2): bit-reproducible for a canonical partition
+            const int G_eff = std::max(1, std::min(a.G, kWave));
+            const size_t chunks = (size_t)((num_parts + G_eff - 1) / G_eff);
+            const size_t part_bytes = ((chunks * 2 * (size_t)dim * sizeof(float)) + 255) & ~(size_t)255;
+            const size_t stamp_bytes = chunks * 2 * sizeof(int32_t);
+            void *ws = nullptr;
+            rc = get_workspace(ds, stream, 2, part_bytes + stamp_bytes, &ws);
+            if (rc != GNNA_OK) return rc;
+            a.det = true;
+            a.det_part = static_cast<float *>(ws);
+            a.det_stamp = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + part_bytes);
+            hipError_t em = hipMemsetAsync(a.det_stamp, 0, stamp_bytes, stream);
+            if (em != hipSuccess) return fail(GNNA_ERR_HIP, "deterministic schedule scratch: %s", hipGetErrorString(em));
+            t_last_launches = B;
+        }
         // single pass, nothing to add to: only the rows the kernel does not store need clearing -- worth a second
         // (empty) launch once the output is tens of MB
-        const bool sparse = a.plain_ok && tune.zero_fill != 2 &&
+        const bool sparse = !a.det && a.plain_ok && tune.zero_fill != 2 &&
                             (tune.zero_fill == 1 || n_floats * sizeof(float) >= ((size_t)32 << 20));
         rc = run_prologue(sparse ? std::max(1, std::min(a.G, kWave)) : 0);
         if (rc != GNNA_OK) return rc;

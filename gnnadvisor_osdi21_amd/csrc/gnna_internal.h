@@ -116,6 +116,8 @@ struct StreamLaunch {
     int D, ldx, G, U, S, B;
     bool wide, plain_ok, xcd_remap;
     float eps;
+    bool det = false;                              // deterministic schedule (ordered phase launches, no atomics)
+    float *det_part = nullptr; int32_t *det_stamp = nullptr;   // [num_chunks][2][D] partial rows / [num_chunks][2] stamps
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
 

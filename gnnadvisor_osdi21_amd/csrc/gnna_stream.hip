@@ -89,6 +89,14 @@ struct StreamParams {
     int32_t phase_lo;          // first phase of this launch
     int32_t plain_ok;          // 1: rows owned by one work item may be written with plain stores
     int32_t xcd_remap;
+    // deterministic schedule (gnna_tuning.deterministic): one launch per phase, in order; a row owned by the work item is
+    // read-modify-written, the partial of a row shared between chunks goes to det_part[chunk][slot][D] (slot 0: the
+    // chunk's first row when it continues from the previous chunk, slot 1: its last row) with det_stamp[chunk][slot] =
+    // stamp, and det_fixup_kernel adds the partials of every shared row in chunk order
+    float *det_part;
+    int32_t *det_stamp;
+    int32_t stamp;
+    int32_t det;
     float eps;
 };
 
@@ -201,19 +209,22 @@ __device__ __forceinline__ void park_row(const typename VecOf<4>::T r, float *__
     }
 }
 
-// emit_row: writes / adds a parked row piece of `width` floats to out[row, d0 : d0 + width], 64 consecutive
-// floats per instruction (one fully covered 256-byte run per wave-wide store / atomic).
+// emit_row: writes / adds a parked row piece of `width` floats to dst[0 : width], 64 consecutive floats per
+// instruction (one fully covered 256-byte run per wave-wide store / atomic).  how: 0 non-temporal store, 1 float
+// atomic add, 2 plain read-add-write (deterministic schedule: nobody else touches the row), 3 plain store
+// (a partial row parked in library scratch).
+enum { EMIT_STORE = 0, EMIT_ATOMIC = 1, EMIT_RMW = 2, EMIT_PART = 3 };
 template <int LPR>
-__device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *__restrict__ Y, int64_t row, int D, int d0,
-                                         int width, bool use_atomic, int lane)
+__device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *__restrict__ dst, int width, int how, int lane)
 {
-    float *dst = Y + (size_t)row * D + d0;
 #pragma unroll
     for (int i = 0; i < (4 * LPR + kWave - 1) / kWave; i++) {
         const int idx = i * kWave + lane;
         if (idx < width) {
-            if (!use_atomic) __builtin_nontemporal_store(buf[idx], dst + idx);
-            else unsafeAtomicAdd(dst + idx, buf[idx]);
+            if (how == EMIT_STORE) __builtin_nontemporal_store(buf[idx], dst + idx);
+            else if (how == EMIT_ATOMIC) unsafeAtomicAdd(dst + idx, buf[idx]);
+            else if (how == EMIT_RMW) dst[idx] = dst[idx] + buf[idx];
+            else dst[idx] = buf[idx];
         }
     }
 }
@@ -327,7 +338,7 @@ stream_kernel(const StreamParams p)
     const unsigned long long ss_above = SS & above;
     const int seg_last = ss_above ? __builtin_ctzll(ss_above) - 1 : ng - 1;
     const bool shared = canonical && ((seg_first == 0 && prev_row == my_row) || (seg_last == ng - 1 && next_row == my_row));
-    const int use_atomic_l = (shared || !canonical || !p.plain_ok) ? 1 : 0;
+    const int use_atomic_l = (shared || !canonical || (!p.plain_ok && !p.det)) ? 1 : 0;
 
     // non-empty pieces compacted to lanes 0 .. R-1 (forward permute to the piece's rank); piece r then
     // holds its first edge, edge count, row + flags, and the inclusive prefix of its wave-wide loads
@@ -356,7 +367,20 @@ stream_kernel(const StreamParams p)
         auto drain = [&]() {
             for (int q = 0; q < npend; q++) {
                 const int meta = __builtin_amdgcn_readlane(pend_meta, q);
-                emit_row<LPR>(pend + q * PEND_FLOATS, p.Y, meta >> 2, D, d0, sweep_width, (meta & 1) != 0, lane);
+                const int64_t row = meta >> 2;
+                float *dst = p.Y + (size_t)row * D + d0;
+                int how = (meta & 1) ? EMIT_ATOMIC : EMIT_STORE;
+                if (p.det && canonical) {
+                    how = EMIT_RMW;
+                    if (meta & 1) {       // shared with a neighbouring chunk: park the partial, det_fixup_kernel adds it in order
+                        const int first_row = __builtin_amdgcn_readfirstlane(my_row);
+                        const int slot_p = (row == first_row && prev_row == first_row) ? 0 : 1;
+                        dst = p.det_part + ((size_t)chunk * 2 + slot_p) * (size_t)D + d0;
+                        how = EMIT_PART;
+                        if (lane == 0) p.det_stamp[chunk * 2 + slot_p] = p.stamp;
+                    }
+                }
+                emit_row<LPR>(pend + q * PEND_FLOATS, dst, sweep_width, how, lane);
             }
             npend = 0;
         };
@@ -539,6 +563,54 @@ stream_kernel(const StreamParams p)
                 if (j < nr) consume(u, j);
             }
             if (npend > PEND / 2 || r0 + RL >= L) drain();   // between rounds: nothing of the ring waits behind these
+        }
+    }
+}
+
+// ---- deterministic schedule: shared rows ---------------------------------------------------------------
+// One wavefront per chunk.  The chunk in which a shared row FIRST appears (its last row continues in the next
+// chunk, and did not come from the previous one) is the head of that row's chain: it sums the partials the chunks of
+// the chain parked for this phase -- its own (slot 1), then slot 0 of every following chunk that starts with the
+// row -- in chunk order, and adds the sum to the output with a plain read-modify-write.  Only partials stamped by
+// this phase's launch count (a chunk without edges of the row in this phase wrote none); consumed stamps are cleared.
+__global__ void __launch_bounds__(kBlock)
+det_fixup_kernel(const int32_t *__restrict__ p2n, int64_t P, int G, int64_t num_chunks, float *__restrict__ Y, int D,
+                 const float *__restrict__ part, int32_t *__restrict__ stamps, int32_t stamp)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t c = wave; c < num_chunks; c += nwaves) {
+        const int64_t g0 = c * G;
+        const int64_t g1 = g0 + G < P ? g0 + G : P;
+        const int rf = p2n[g0], rl = p2n[g1 - 1];
+        const int prev = g0 > 0 ? p2n[g0 - 1] : -1, next = g1 < P ? p2n[g1] : -1;
+        const bool head = next == rl && !(rl == rf && prev == rf);
+        if (!head) continue;
+        for (int d0 = 0; d0 < D; d0 += kWave) {
+            const int i = d0 + lane;
+            float acc = 0.f;
+            // own partial: slot 1 (the row is not the front-shared first row of this chunk)
+            if (stamps[c * 2 + 1] == stamp && i < D) acc = part[((size_t)c * 2 + 1) * (size_t)D + i];
+            for (int64_t j = c + 1; j < num_chunks; j++) {
+                const int64_t h0 = j * G;
+                const int64_t h1 = h0 + G < P ? h0 + G : P;
+                if (p2n[h0] != rl) break;
+                if (stamps[j * 2] == stamp && i < D) acc += part[((size_t)j * 2) * (size_t)D + i];
+                if (!(p2n[h1 - 1] == rl && h1 < P && p2n[h1] == rl)) break;      // the row ends inside chunk j
+            }
+            if (i < D) Y[(size_t)rl * (size_t)D + i] += acc;
+        }
+        // clear what was consumed (a stale stamp must never match a later launch)
+        if (lane == 0) {
+            if (stamps[c * 2 + 1] == stamp) stamps[c * 2 + 1] = 0;
+            for (int64_t j = c + 1; j < num_chunks; j++) {
+                const int64_t h0 = j * G;
+                const int64_t h1 = h0 + G < P ? h0 + G : P;
+                if (p2n[h0] != rl) break;
+                if (stamps[j * 2] == stamp) stamps[j * 2] = 0;
+                if (!(p2n[h1 - 1] == rl && h1 < P && p2n[h1] == rl)) break;
+            }
         }
     }
 }
@@ -759,6 +831,23 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, 4) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
+    p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
+    if (a.det && a.mode != MODE_SDDMM) {
+        // deterministic schedule: the phases are separate launches in order, each followed by the ordered sum of
+        // the rows that chunks share
+        p.det = 1; p.det_part = a.det_part; p.det_stamp = a.det_stamp;
+        int64_t fblocks = std::max<int64_t>(1, std::min<int64_t>((p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock, 65535));
+        for (int ph = 0; ph < p.B; ph++) {
+            p.phase_lo = ph;
+            p.stamp = (int32_t)((((uint32_t)a.seq & 0x1ffffffu) << 6) | (uint32_t)ph);
+            hipLaunchKernelGGL(k, dim3((unsigned)items), dim3(kSBlock), 0, stream, p);
+            hipLaunchKernelGGL(det_fixup_kernel, dim3((unsigned)fblocks), dim3(kBlock), 0, stream, a.p2n, a.P, p.G, p.num_chunks,
+                               a.Y, a.D, a.det_part, a.det_stamp, p.stamp);
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
+        return GNNA_OK;
+    }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kSBlock), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));

@@ -248,6 +248,13 @@ typedef struct gnna_tuning {
     int sweep_slack;      /* sweep kernel: how many slice steps a wavefront may run ahead of the slowest wavefront of
                              its XCD (soft barrier on a per-XCD counter, bounded spin: only locality depends on it).
                              0 = built-in, n > 0 = n steps, >= 1000 = no synchronisation at all */
+    int deterministic;    /* 1 = bit-reproducible results of the streaming kernel for a canonical partition: the phases
+                             of the sliced schedule run as separate launches in order, a row owned by one work item is
+                             read-modify-written, and the partial sums of a row shared between work items are parked in
+                             library scratch and added in work-item order by a small second kernel -- no float atomics,
+                             so the association order of every output element is fixed.  Costs the per-phase launches
+                             and the read-back of the rows; 0 = the default schedule (atomics: reproducible to fp32
+                             rounding, exact where the sums are exactly representable) */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */

@@ -141,3 +141,42 @@ def test_unprepared_graphs_back_off_when_no_partition_is_seen_twice():
     xs = X[g.column_index[b:e].long()].double()
     assert bool(((y[r].double() - xs.sum(0)).abs() <= 1e-4 * xs.abs().sum(0).clamp(min=1.0)).all())
     _lib.release_graph(None)
+
+
+@pytest.mark.parametrize("dim,phases,prescale", [(64, 8, 0), (64, 1, 0), (100, 5, 1), (300, 3, 2), (16, 16, 0), (7, 4, 1)])
+def test_deterministic_schedule_is_bit_reproducible(dim, phases, prescale):
+    """gnna_tuning.deterministic = 1: ordered phase launches, read-modify-write for the rows a work item owns, partial
+    sums of the rows that work items share added in work-item order -- no float atomics, so repeated runs give the
+    same BITS (the default schedule is reproducible to fp32 rounding only), and the values still match the oracle."""
+    g, X, pp, p2n = make_case(20000, 1500000, dim, 16, seed=dim + phases, kind="powerlaw")    # hubs span many work items
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    rpn, cin, degn, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), X.numpy()
+    try:
+        _lib.set_tuning(deterministic=1, column_phases=phases, gcn_prescale=prescale)
+        runs = []
+        for rep in range(4):
+            ys = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+            yg = _lib.agg_gcn(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+            yi = _lib.agg_gin(Xd, rp, ci, 0.5, ppd, p2nd, 16, 32, 4)
+            assert _lib.last_num_phases() == phases
+            runs.append((ys, yg, yi))
+        torch.cuda.synchronize()
+        for rep in range(1, 4):
+            for a, b, what in zip(runs[0], runs[rep], ("sag", "gcn", "gin")):
+                assert torch.equal(a, b), (what, rep, float((a - b).abs().max()))
+        sscale = oracle.csr_f64(0, np.abs(Xn), rpn, cin)
+        assert_close_f64(runs[0][0].cpu().numpy(), oracle.csr_f64(0, Xn, rpn, cin), what="det sag", scale=sscale)
+        assert_close_f64(runs[0][1].cpu().numpy(), oracle.csr_f64(1, Xn, rpn, cin, degn), what="det gcn",
+                         scale=oracle.csr_f64(1, np.abs(Xn), rpn, cin, degn))
+        assert_close_f64(runs[0][2].cpu().numpy(), oracle.csr_f64(2, Xn, rpn, cin, None, 0.5), what="det gin", scale=sscale)
+        # accumulate on top of an existing output (the multi-GPU remote part): still the same bits every time
+        base = torch.randn(g.num_nodes, dim, generator=torch.Generator().manual_seed(3)).cuda()
+        acc = [_lib.agg_rect(0, Xd, ci, ppd, p2nd, g.num_nodes, 16, out=base.clone(), accumulate=True) for _ in range(3)]
+        assert torch.equal(acc[0], acc[1]) and torch.equal(acc[0], acc[2])
+        assert_close_f64(acc[0].cpu().numpy(), base.cpu().double().numpy() + oracle.csr_f64(0, Xn, rpn, cin), what="det accumulate",
+                         scale=sscale + np.abs(base.cpu().numpy()))
+        # exact on the reference's known-answer input
+        y1 = _lib.sag(torch.ones_like(Xd), rp, ci, deg, ppd, p2nd, 16, 32, 4)
+        assert torch.equal(y1, (rp[1:] - rp[:-1]).float()[:, None].expand(-1, dim))
+    finally:
+        _lib.reset_tuning()
