@@ -11,12 +11,18 @@ node order), D = 64 fp32 features; neighbor-group size and schedule are chosen b
 auto mode (`--manual` = the reference's manual mode, partSize 32, single pass).
 
 `--gpus N` with N > 1 launches N ranks by itself (re-exec under torch.distributed.run on
-127.0.0.1) unless the launcher's environment (WORLD_SIZE) is already there: weak scaling -- every
-rank owns a Reddit-sized block of destination rows whose sources are drawn from all ranks' nodes;
-each step exchanges source features over RCCL/xGMI (only the referenced remote rows when that is clearly
-less than the whole blocks, `--exchange`) and aggregates locally (gnnadvisor_osdi21_amd/dist.py).
+127.0.0.1) unless the launcher's environment (WORLD_SIZE) is already there.  The N-rank line's `value` is the
+weak-scaling leg -- every rank owns a Reddit-sized block of destination rows whose sources are drawn from all
+ranks' nodes; each step exchanges source features over RCCL/xGMI (only the referenced remote rows when that is
+clearly less than the whole blocks, `--exchange`) and aggregates locally (gnnadvisor_osdi21_amd/dist.py) -- so that
+N = 1 is the single-GPU workload.  `--scaling strong,config5` (default) adds, inside `config.legs` / `config.values`,
+the strong-scaling leg (the SAME Reddit-like graph as the single-GPU line, split into N nnz-balanced destination
+blocks) and, at 8 ranks (or with --config5-leg), BASELINE config 5 (papers100M-like, D = 128, exchange chosen
+collectively), each verified on every rank.
 
-Rank 0 prints ONE JSON line; `value` = total aggregated edges per second over all ranks.
+Rank 0 prints ONE JSON line; `value` = total aggregated edges per second over all ranks.  Everything beyond the
+contract's keys rides inside `config` (verification, other modes, the reference-style wall-clock timing, the N-rank
+legs) and `roofline` (`other_workloads`: the HBM-resident graph and config 5's per-rank shape).
 
 `verified`: after the timed loop the timed configuration itself is checked -- X = ones must give the
 exact row nnz in every column (the reference's own known-answer test, unitest.py:54-63), and 256
@@ -26,13 +32,19 @@ sampled rows of the timed randn output are compared with an fp64 gather-sum.
 fabric), so `achieved` is the MEASURED fabric traffic of the aggregation kernel (rocprofv3 PMC passes
 FETCH_SIZE and WRITE_SIZE of this very invocation: bench.py re-runs itself as a short child under
 rocprofv3, FETCH_SIZE calibrated on a 1 GiB device copy in the same child) divided by the kernel
-time measured with HIP events on the launch stream during the timed loop; `frac` = that / 8 TB/s.
-The gather-model rate of SURVEY.md 8(d) (bytes = nnz*(4D+4) + N*(4D+4) + P*8 per step, which
-counts every gathered row whether it came from L2, Infinity Cache or HBM and therefore may exceed
+time measured with HIP events on the launch stream during the timed loop; `frac` = that / 8 TB/s
+(`frac_of_achievable_6300GBs` beside it).  The gather-model rate of SURVEY.md 8(d) (bytes = nnz*(4D+4) + N*(4D+4) + P*8
+per step, which counts every gathered row whether it came from L2, Infinity Cache or HBM and therefore may exceed
 the HBM peak) and the compulsory-model rate are reported beside it, never as `frac`.
-`hbm_resident` repeats the measurement on a workload whose features (627 MB) exceed the 256 MiB
-Infinity Cache (products-like, D = 64), `config5_shard` on one GPU's share of BASELINE config 5 (1/8 of a
-papers100M-like graph, D = 128, 7.1 GB of features, 64-bit offsets).  `cpu_baseline` times the oracle (CPU port) on the host.
+`roofline.other_workloads.hbm_resident` repeats the measurement on a workload whose features (627 MB) exceed the
+256 MiB Infinity Cache (products-like, D = 64; bound "fabric (HBM + Infinity Cache)": a 157 MB slice still fits the
+cache), `config5_rank_of_8` / `config5_rank_of_8_halo` on BASELINE config 5 in its TRUE per-rank shape: rank 0 of 8 of a
+papers100M-like graph -- 13.9 M destination rows gathering D = 128 rows of all 111 M source nodes, from the resident
+56.9 GB all-gather buffer (one rectangular call, 64-bit offsets) and from the compact halo buffer the automatic
+exchange takes (local part + K pieces); one process plays the rank (`ShardedAggregator(emulate=...)`), the receive
+buffer is filled from the global features instead of by RCCL, so these are the KERNELS of a rank's step.
+`config.reference_style_ms`: the reference's own timing method (unitest.py:65-79: 10 warm-up + 200 GNNA.SAG calls
+through the pybind module, fresh outputs, wall clock).  `cpu_baseline` times the oracle (CPU port) on the host.
 """
 from __future__ import annotations
 
