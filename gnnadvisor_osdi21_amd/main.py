@@ -115,6 +115,12 @@ def main(argv=None):
     inputInfo.partPtr = partPtr.int().to(device)
     inputInfo.part2Node = part2Node.int().to(device)
     inputInfo.apply_tuning()      # scheduler knobs + this graph's hints (keyed by the device column_index)
+    # graph lifecycle: the counting pass, its one synchronisation and the scratch sizing happen here, next to
+    # build_part, instead of inside the first aggregation -- no epoch (and no captured epoch) synchronises or allocates
+    from . import _lib as _gnna_lib
+    _prep_widths = sorted({args.hidden, dataset.num_classes, dataset.num_features})
+    _gnna_lib.prepare_graph(inputInfo.column_index, inputInfo.partPtr, inputInfo.part2Node, dataset.num_nodes,
+                            dataset.num_nodes, inputInfo.partSize, _prep_widths)
     if not manual_mode and not (verify_spmm or single_spmm):
         # measured schedule for the widths the layers aggregate at (hidden, classes; GIN layer 1 aggregates
         # at the input width unless it is evaluated update-first)
