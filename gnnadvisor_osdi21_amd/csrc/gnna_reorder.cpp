@@ -27,6 +27,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -74,6 +75,14 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     const int64_t n = num_nodes;
     if (n == 0) return GNNA_OK;
     const int threads = host_threads();
+    const bool debug = std::getenv("GNNA_REORDER_DEBUG") != nullptr;
+    auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!debug) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[reorder] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_start).count());
+        t_start = now;
+    };
 
     // symmetrised, duplicate-free adjacency (reorder.cpp:31-97 does the same before aggregating)
     std::vector<int32_t> rp((size_t)n + 1), ci;
@@ -87,6 +96,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         ci.resize((size_t)nnz);
     }
 
+    lap("symmetrised adjacency");
     // ---- 1. backbone: edges with >= T common neighbours ------------------------------------------------------
     const double avg_deg = (double)ci.size() / (double)n;
     const int T = std::getenv("GNNA_REORDER_SUPPORT") ? std::atoi(std::getenv("GNNA_REORDER_SUPPORT"))
@@ -141,6 +151,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         std::fprintf(stderr, "[reorder] %lld nodes, %zu adjacency entries, backbone (>= %d common neighbours) keeps %zu\n",
                      (long long)n, ci.size(), T, bci.size());
 
+    lap("backbone");
     // ---- 2. breadth-first discovery order over the backbone ---------------------------------------------------
     std::vector<double> pos((size_t)n, -1.0), nxt((size_t)n);
     std::vector<char> in_backbone((size_t)n, 0);
@@ -155,20 +166,24 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         // overflowed from 32768 walks on -- common once unsupported edges and hubs are dropped on a large graph
         std::vector<int32_t> hit_tag((size_t)n, -1), hits((size_t)n, 0);
         std::vector<int32_t> depth((size_t)n, 0);
-        auto bfs = [&](int32_t seed, int32_t tag, std::vector<int32_t> &out) {   // nodes of comp `tag` in discovery order
+        // `only`: the walk may take nodes whose component tag is `only` and nothing else -- -1 (unassigned) in the first
+        // sweep, the component's own first-sweep tag in the second.  (Without the restriction a walk re-absorbed the
+        // nodes of components walked before it: with thousands of small components next to a giant one -- a graph of
+        // average degree ~50 -- the second sweep walked the giant component once per component, 65 s for 1e5 nodes.)
+        auto bfs = [&](int32_t seed, int32_t tag, int32_t only, std::vector<int32_t> &out) {   // nodes of comp `tag` in discovery order
             out.clear();
             out.push_back(seed);
             comp[(size_t)seed] = tag;
             depth[(size_t)seed] = 0;
             for (int32_t k = brp[(size_t)seed]; k < brp[(size_t)seed + 1]; k++) {
                 const int32_t u = bci[(size_t)k];
-                if (comp[(size_t)u] != tag) { comp[(size_t)u] = tag; depth[(size_t)u] = 0; out.push_back(u); }
+                if (comp[(size_t)u] == only) { comp[(size_t)u] = tag; depth[(size_t)u] = 0; out.push_back(u); }
             }
             for (size_t head = 0; head < out.size(); head++) {
                 const int32_t v = out[head];
                 for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
                     const int32_t u = bci[(size_t)k];
-                    if (comp[(size_t)u] == tag) continue;
+                    if (comp[(size_t)u] != only) continue;
                     if (hit_tag[(size_t)u] != tag) { hit_tag[(size_t)u] = tag; hits[(size_t)u] = 0; }   // counter of this walk
                     if (++hits[(size_t)u] >= theta) {
                         comp[(size_t)u] = tag;
@@ -253,27 +268,77 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         };
         // components by a first sweep (tags 0, 2, 4, ...), then re-walked from their last-discovered node
         // (tags 1, 3, 5, ...): a peripheral start keeps the levels thin
-        std::vector<std::pair<int64_t, int32_t>> comps;   // (-size, first sweep's last node)
-        std::vector<int32_t> walk;
+        std::vector<std::pair<int64_t, int32_t>> comps;   // (-size, index of the component)
+        std::vector<int32_t> walk, more;
+        std::vector<int32_t> first_order;                 // the first sweep's walks, one after the other
+        std::vector<int64_t> first_begin;                 // component i = first_order[first_begin[i] .. first_begin[i + 1])
+        first_order.reserve((size_t)n);
         int32_t tag = 0;
         for (int64_t v = 0; v < n; v++) {
             if (comp[(size_t)v] >= 0 || brp[(size_t)v + 1] == brp[(size_t)v]) continue;
-            bfs((int32_t)v, tag, walk);
-            comps.emplace_back(-(int64_t)walk.size(), walk.back());
+            bfs((int32_t)v, tag, -1, walk);
+            comps.emplace_back(-(int64_t)walk.size(), (int32_t)first_begin.size());
+            first_begin.push_back((int64_t)first_order.size());
+            first_order.insert(first_order.end(), walk.begin(), walk.end());
             tag += 2;
         }
+        first_begin.push_back((int64_t)first_order.size());
+        lap("first sweep (components)");
+        if (debug) std::fprintf(stderr, "[reorder] %zu backbone components\n", comps.size());
         std::sort(comps.begin(), comps.end());
         int64_t at = 0;
+        // Leftovers: with theta > 1 a node with fewer than theta backbone neighbours in a walk is never discovered and
+        // seeds a tiny walk of its own later.  Laid out as components of their own they would land far from the
+        // neighbourhood they belong to; they are placed afterwards, at the median position of their placed neighbours.
+        const int64_t leftover_below = theta > 1 ? 16 : 1;
+        std::vector<int32_t> leftovers;
         for (auto &c : comps) {
-            const int32_t seed = c.second;
-            bfs(seed, comp[(size_t)seed] + 1, walk);
+            const int64_t fb = first_begin[(size_t)c.second], fe = first_begin[(size_t)c.second + 1];
+            const int32_t seed = first_order[(size_t)(fe - 1)];       // the first sweep's last node: a peripheral start
+            const int32_t old_tag = comp[(size_t)seed];
+            bfs(seed, old_tag + 1, old_tag, walk);
+            // a walk from another start may stall before it has covered the component (a node needs theta walked
+            // neighbours): go on from the nodes it has not reached, in the first sweep's order
+            if ((int64_t)walk.size() < fe - fb) {
+                for (int64_t i = fb; i < fe; i++) {
+                    const int32_t v = first_order[(size_t)i];
+                    if (comp[(size_t)v] != old_tag) continue;
+                    const int32_t base_depth = walk.empty() ? 0 : depth[(size_t)walk.back()] + 1;
+                    bfs(v, old_tag + 1, old_tag, more);
+                    for (int32_t u : more) depth[(size_t)u] += base_depth;
+                    walk.insert(walk.end(), more.begin(), more.end());
+                }
+            }
+            if ((int64_t)walk.size() < leftover_below && -comps.front().first >= 16 * leftover_below) {
+                leftovers.insert(leftovers.end(), walk.begin(), walk.end());
+                continue;
+            }
             unfold(walk);
             for (int32_t v : walk) { pos[(size_t)v] = (double)at++; in_backbone[(size_t)v] = 1; }
         }
+        if (debug) std::fprintf(stderr, "[reorder] %zu leftover nodes of tiny walks\n", leftovers.size());
+        // a few rounds: a leftover whose neighbours are leftovers too gets its place once they have theirs
+        for (int round = 0; round < 3 && !leftovers.empty(); round++) {
+            std::vector<int32_t> still;
+            std::vector<double> nbp;
+            std::vector<std::pair<int32_t, double>> placed_now;
+            for (int32_t v : leftovers) {
+                nbp.clear();
+                for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
+                    if (pos[(size_t)ci[(size_t)k]] >= 0) nbp.push_back(pos[(size_t)ci[(size_t)k]]);
+                if (nbp.empty()) { still.push_back(v); continue; }
+                std::nth_element(nbp.begin(), nbp.begin() + nbp.size() / 2, nbp.end());
+                placed_now.emplace_back(v, nbp[nbp.size() / 2] + 0.5);       // next to the median neighbour
+            }
+            for (auto &pv : placed_now) { pos[(size_t)pv.first] = pv.second; in_backbone[(size_t)pv.first] = 1; }
+            leftovers.swap(still);
+        }
         for (int64_t v = 0; v < n; v++)
             if (pos[(size_t)v] < 0) pos[(size_t)v] = (double)at++;        // no backbone edge: placed in step 3
+        // (fractional positions of the leftovers become ranks at the first re-spread of step 3)
     }
 
+    lap("second sweep + unfold");
     // ---- 3. barycentre refinement ----------------------------------------------------------------------------
     std::vector<int32_t> perm((size_t)n);
     auto respread = [&] {   // positions -> ranks, so that the arrangement does not contract (ties: by node id)
@@ -315,6 +380,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         }
     });
     respread();
+    lap("median sweeps");
     for (int64_t v = 0; v < n; v++) new_id[(size_t)v] = (int32_t)pos[(size_t)v];
     return GNNA_OK;
 }
