@@ -327,6 +327,20 @@ class RankOf8Workload:
         elapsed = time.perf_counter() - t0
         prof = self._lib.profile_end()
         per_step = prof["calls"] / max(1, steps)
+        self.send_gather_ms = None
+        if self.agg.exchange == "halo":
+            # the send half of the halo exchange (rows the peers reference, gathered per piece into send buffers):
+            # by symmetry as many rows as this rank receives
+            for _ in range(2):
+                bufs = self.agg.send_side_gather(self.X_local)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                bufs = self.agg.send_side_gather(self.X_local)
+            torch.cuda.synchronize()
+            self.send_gather_ms = (time.perf_counter() - t1) * 1e3 / 3
+            self.send_gather_rows = int(sum(b.shape[0] for b in bufs))
+            del bufs
         return elapsed, {"main_ms": prof["main_ms"] * per_step, "prologue_ms": prof["prologue_ms"] * per_step,
                          "calls": prof["calls"]}
 
@@ -408,6 +422,10 @@ class RankOf8Workload:
             d["halo_rows"] = a.halo_rows
             d["halo_share_of_remote_rows"] = a.halo_rows / max(1, (self.world - 1) * self.n_local)
             d["bytes_received_per_step"] = a.bytes_received_per_step(D)
+            if getattr(self, "send_gather_ms", None) is not None:
+                d["send_side_gather_ms"] = self.send_gather_ms
+                d["send_side_gather_rows"] = self.send_gather_rows
+                d["send_side_gather_GBs"] = 2 * self.send_gather_rows * D * 4 / (self.send_gather_ms * 1e-3) / 1e9
         d["allgather_bytes_received_per_step"] = a.allgather_bytes_per_step(D)
         return d
 

@@ -333,8 +333,10 @@ class ShardedAggregator:
         need = torch.bincount(owner, minlength=world)            # rows wanted from each peer
         need_l = need.tolist()
         if self.emulated:
-            # no peers to tell: the send side of this rank is not needed to run its own aggregation
-            send_l, asked = [0] * world, uniq[:0]
+            # no peers to ask.  By symmetry of the generator the rows the peers want from this rank look like the rows this
+            # rank wants from them (offsets inside the owner's block): they stand in for the send lists, so that the
+            # send-side gather (index_select per piece) can be timed too; the aggregation itself does not use them
+            send_l, asked = list(need_l), (uniq - b[owner]).clamp_(0, max(0, self.n_local - 1)).to(self.device)
         else:
             cdev = self._comm_device()
             send_counts = torch.empty(world, dtype=torch.int64, device=cdev)
@@ -450,6 +452,13 @@ class ShardedAggregator:
                     buf[at: at + (b2 - a)].copy_(X_global[a:b2])
         self._gather_buf = buf
         return buf
+
+    def send_side_gather(self, X_local: torch.Tensor):
+        """The send half of one halo exchange without the collective: per piece, the rows of this rank's block that the
+        peers reference, gathered into a contiguous send buffer (what `exchange_halo` does before `all_to_all_single`).
+        -> list of the K send buffers."""
+        assert self.exchange == "halo"
+        return [X_local.index_select(0, self._send_index[k]) for k in range(self.chunks)]
 
     def bytes_received_per_step(self, dim: int) -> int:
         """Feature bytes this rank receives from its peers per aggregation."""

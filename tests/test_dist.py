@@ -310,6 +310,8 @@ def test_one_process_emulation_of_every_rank_matches_the_whole_graph(exchange, c
         assert agg.emulated and agg.world == world and agg.rank == rank and agg.exchange == exchange
         if exchange == "halo":
             assert sum(agg.halo_rows_per_peer) == agg.halo_rows and agg.halo_rows_per_peer[rank] == 0
+            sent = agg.send_side_gather(X[lo:hi].contiguous())          # stand-in send lists: as many rows as are received
+            assert len(sent) == agg.chunks and sum(t.shape[0] for t in sent) == agg.halo_rows
         buf = agg.emulated_receive(X)
         assert buf.shape[0] == (agg.remote_rows if overlap else world * agg.rows_per_rank)
         agg.emulated_receive_degrees(g.degrees)
