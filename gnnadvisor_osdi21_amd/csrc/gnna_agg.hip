@@ -1053,7 +1053,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
     gnna_tuning tune;
     gnna_get_tuning(&tune);
     const bool hot = plan.stats.edges >= 32.0 * (double)num_in_rows;
-    size_t staged = 0;
+    size_t staged = 0, det_bytes = 0;
     for (int i = 0; i < num_dims; i++) {
         const int dim = dims[i];
         if (dim <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_prepare_graph: dims[%d] = %d", i, dim);
@@ -1074,6 +1074,17 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
                                   t.nonlocal_ids == 1);
         }
         if (phases_out) phases_out[i] = std::max(1, B);
+        if (t.deterministic == 1 && dim >= 4) {   // the deterministic schedule parks partial rows in the stream's scratch (slot 2)
+            const int G_eff = std::max(1, std::min(kWave, t.groups_per_chunk * std::max(1, B)));
+            const size_t chunks = (size_t)((num_parts + G_eff - 1) / G_eff);
+            det_bytes = std::max(det_bytes, (((chunks * 2 * (size_t)dim * sizeof(float)) + 255) & ~(size_t)255) +
+                                                chunks * 2 * sizeof(int32_t));
+        }
+    }
+    if (det_bytes) {
+        void *ws = nullptr;
+        rc = get_workspace(ds, stream, 2, det_bytes, &ws);
+        if (rc != GNNA_OK) return rc;
     }
     if (staged) {
         void *ws = nullptr;
