@@ -70,8 +70,8 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     using gnna::fail;
     if (num_edges < 0 || num_nodes < 0 || (num_nodes > 0 && !new_id) || (num_edges > 0 && (!src || !dst)))
         return fail(GNNA_ERR_INVALID_ARGUMENT, "bad reorder arguments");
-    if (num_nodes > 0x7fffffffLL || 2 * num_edges > 0x7fffffffLL)
-        return fail(GNNA_ERR_UNSUPPORTED, "graph too large for int32 reorder");
+    if (num_nodes > 0x7fffffffLL)
+        return fail(GNNA_ERR_UNSUPPORTED, "graph too large for int32 node ids");
     const int64_t n = num_nodes;
     if (n == 0) return GNNA_OK;
     const int threads = host_threads();
@@ -84,16 +84,56 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         t_start = now;
     };
 
-    // symmetrised, duplicate-free adjacency (reorder.cpp:31-97 does the same before aggregating)
-    std::vector<int32_t> rp((size_t)n + 1), ci;
+    // symmetrised, duplicate-free adjacency (reorder.cpp:31-97 does the same before aggregating).  64-bit row offsets:
+    // the list may hold more than 2^31 entries once both directions are in (papers100M symmetrised: 3.2e9); built in
+    // parallel over slabs of the edge list (atomic degree counts and cursors), then sorted and de-duplicated per row.
+    std::vector<int64_t> rp((size_t)n + 1, 0);
+    std::vector<int32_t> ci;
     {
-        std::vector<int32_t> s2((size_t)2 * num_edges), d2((size_t)2 * num_edges);
-        std::copy_n(src, num_edges, s2.begin()); std::copy_n(dst, num_edges, s2.begin() + num_edges);
-        std::copy_n(dst, num_edges, d2.begin()); std::copy_n(src, num_edges, d2.begin() + num_edges);
-        ci.resize((size_t)2 * num_edges);
-        const int64_t nnz = gnna_csr_from_edges_i32(s2.data(), d2.data(), 2 * num_edges, n, rp.data(), ci.data());
-        if (nnz < 0) return (int)nnz;
-        ci.resize((size_t)nnz);
+        for (int64_t e = 0; e < num_edges; e++)
+            if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n)
+                return fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)e, src[e], dst[e], (long long)n);
+        std::vector<int64_t> cursor((size_t)n + 1, 0);
+        auto over_edges = [&](auto &&fn) {
+            const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(threads, num_edges / (1 << 20) + 1));
+            std::vector<std::thread> th;
+            const int64_t step = (num_edges + nt - 1) / nt;
+            for (int64_t t = 0; t < nt; t++) {
+                const int64_t lo = t * step, hi = std::min(num_edges, lo + step);
+                if (lo >= hi) break;
+                th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+            }
+            for (auto &t : th) t.join();
+        };
+        over_edges([&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++) {
+                __atomic_fetch_add(&cursor[(size_t)src[e] + 1], 1, __ATOMIC_RELAXED);
+                __atomic_fetch_add(&cursor[(size_t)dst[e] + 1], 1, __ATOMIC_RELAXED);
+            }
+        });
+        for (int64_t v = 0; v < n; v++) cursor[(size_t)v + 1] += cursor[(size_t)v];
+        std::vector<int64_t> start(cursor.begin(), cursor.end());
+        std::vector<int32_t> bucket((size_t)(2 * num_edges));
+        over_edges([&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++) {
+                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)src[e]], 1, __ATOMIC_RELAXED)] = dst[e];
+                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)dst[e]], 1, __ATOMIC_RELAXED)] = src[e];
+            }
+        });
+        std::vector<int32_t> uniq((size_t)n, 0);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t v = lo; v < hi; v++) {
+                int32_t *b = bucket.data() + start[(size_t)v], *e = bucket.data() + start[(size_t)v + 1];
+                std::sort(b, e);                                   // (the scatter order depends on the threads, the sorted row does not)
+                uniq[(size_t)v] = (int32_t)(std::unique(b, e) - b);
+            }
+        });
+        for (int64_t v = 0; v < n; v++) rp[(size_t)v + 1] = rp[(size_t)v] + uniq[(size_t)v];
+        ci.resize((size_t)rp[(size_t)n]);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t v = lo; v < hi; v++)
+                std::copy_n(bucket.data() + start[(size_t)v], uniq[(size_t)v], ci.data() + rp[(size_t)v]);
+        });
     }
 
     lap("symmetrised adjacency");
@@ -110,19 +150,20 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         if (d <= (double)hub) sum_d2 += d * d;
     }
     const double chance = sum_d2 / ((double)ci.size() * (double)ci.size());
-    std::vector<int32_t> brp((size_t)n + 1, 0), bci;
+    std::vector<int64_t> brp((size_t)n + 1, 0);
+    std::vector<int32_t> bci;
     {
         std::vector<uint8_t> keep(ci.size(), 0);
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
             for (int64_t u = lo; u < hi; u++) {
-                const int32_t ub = rp[(size_t)u], ue = rp[(size_t)u + 1];
+                const int64_t ub = rp[(size_t)u], ue = rp[(size_t)u + 1];
                 if (ue - ub > hub) continue;
-                for (int32_t k = ub; k < ue; k++) {
+                for (int64_t k = ub; k < ue; k++) {
                     const int32_t v = ci[(size_t)k];
-                    const int32_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
+                    const int64_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
                     if (ve - vb > hub || v == u) continue;
                     const int32_t need = std::max<int32_t>(T, (int32_t)std::ceil(3.0 * chance * (double)(ue - ub) * (double)(ve - vb)));
-                    int32_t i = ub, j = vb, common = 0;
+                    int64_t i = ub, j = vb; int32_t common = 0;
                     while (i < ue && j < ve && common < need) {
                         const int32_t a = ci[(size_t)i], b2 = ci[(size_t)j];
                         common += a == b2;
@@ -134,15 +175,15 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
             }
         });
         for (int64_t u = 0; u < n; u++) {
-            int32_t c = 0;
-            for (int32_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++) c += keep[(size_t)k];
+            int64_t c = 0;
+            for (int64_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++) c += keep[(size_t)k];
             brp[(size_t)u + 1] = brp[(size_t)u] + c;
         }
         bci.resize((size_t)brp[(size_t)n]);
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
             for (int64_t u = lo; u < hi; u++) {
-                int32_t at = brp[(size_t)u];
-                for (int32_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++)
+                int64_t at = brp[(size_t)u];
+                for (int64_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++)
                     if (keep[(size_t)k]) bci[(size_t)at++] = ci[(size_t)k];
             }
         });
@@ -175,13 +216,13 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
             out.push_back(seed);
             comp[(size_t)seed] = tag;
             depth[(size_t)seed] = 0;
-            for (int32_t k = brp[(size_t)seed]; k < brp[(size_t)seed + 1]; k++) {
+            for (int64_t k = brp[(size_t)seed]; k < brp[(size_t)seed + 1]; k++) {
                 const int32_t u = bci[(size_t)k];
                 if (comp[(size_t)u] == only) { comp[(size_t)u] = tag; depth[(size_t)u] = 0; out.push_back(u); }
             }
             for (size_t head = 0; head < out.size(); head++) {
                 const int32_t v = out[head];
-                for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
                     const int32_t u = bci[(size_t)k];
                     if (comp[(size_t)u] != only) continue;
                     if (hit_tag[(size_t)u] != tag) { hit_tag[(size_t)u] = tag; hits[(size_t)u] = 0; }   // counter of this walk
@@ -221,7 +262,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                         const int32_t v = stack.back();
                         stack.pop_back();
                         sz++;
-                        for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                        for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
                             const int32_t u = bci[(size_t)k];
                             if (arm[(size_t)u] == -1 && depth[(size_t)u] == L) { arm[(size_t)u] = id; stack.push_back(u); }
                         }
@@ -244,7 +285,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                     if (i < hi) a = arm[(size_t)v] == parts[0].second ? 1 : (arm[(size_t)v] == parts[1].second ? 2 : 0);
                     if (a == 0) {
                         int64_t c1 = 0, c2 = 0;
-                        for (int32_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                        for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
                             const int32_t u = bci[(size_t)k];
                             if (depth[(size_t)u] <= depth[(size_t)v] && comp[(size_t)u] == comp[(size_t)v]) {
                                 c1 += arm[(size_t)u] == 1;
@@ -324,7 +365,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
             std::vector<std::pair<int32_t, double>> placed_now;
             for (int32_t v : leftovers) {
                 nbp.clear();
-                for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
+                for (int64_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
                     if (pos[(size_t)ci[(size_t)k]] >= 0) nbp.push_back(pos[(size_t)ci[(size_t)k]]);
                 if (nbp.empty()) { still.push_back(v); continue; }
                 std::nth_element(nbp.begin(), nbp.begin() + nbp.size() / 2, nbp.end());
@@ -353,11 +394,11 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
             std::vector<double> nbp;
             for (int64_t v = lo; v < hi; v++) {
-                const int32_t b = brp[(size_t)v], e = brp[(size_t)v + 1];
+                const int64_t b = brp[(size_t)v], e = brp[(size_t)v + 1];
                 if (e == b) { nxt[(size_t)v] = pos[(size_t)v]; continue; }
                 // the MEDIAN position of the neighbours: a stray long-range neighbour must not drag the node away
                 nbp.resize((size_t)(e - b));
-                for (int32_t k = b; k < e; k++) nbp[(size_t)(k - b)] = pos[(size_t)bci[(size_t)k]];
+                for (int64_t k = b; k < e; k++) nbp[(size_t)(k - b)] = pos[(size_t)bci[(size_t)k]];
                 std::nth_element(nbp.begin(), nbp.begin() + (e - b) / 2, nbp.end());
                 nxt[(size_t)v] = nbp[(size_t)((e - b) / 2)];
             }
@@ -371,7 +412,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
             nxt[(size_t)v] = pos[(size_t)v];
             if (in_backbone[(size_t)v]) continue;
             std::vector<double> nbp;
-            for (int32_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
+            for (int64_t k = rp[(size_t)v]; k < rp[(size_t)v + 1]; k++)
                 if (in_backbone[(size_t)ci[(size_t)k]]) nbp.push_back(pos[(size_t)ci[(size_t)k]]);
             if (!nbp.empty()) {
                 std::nth_element(nbp.begin(), nbp.begin() + nbp.size() / 2, nbp.end());

@@ -121,10 +121,13 @@ GNNA_API int gnna_edge_span(const int32_t *src, const int32_t *dst, int64_t num_
 GNNA_API int gnna_reorder_rcm_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
                          int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
 
-/* Locality renumbering by communities: writes new_id[old_id] (a permutation).  Size-capped label propagation
- * on the symmetrised graph (multi-threaded, deterministic), the communities laid out as a chain by their
- * ties, positions refined by barycentre sweeps -- the role of rabbit.reorder (community-based Rabbit Order,
- * rabbit_module/src/reorder.cpp:235-295) with a different, reproducible algorithm (gnna_reorder.cpp). */
+/* Locality renumbering by communities: writes new_id[old_id] (a permutation).  On the symmetrised graph
+ * (multi-threaded, deterministic): the triangle-supported backbone of the graph (edges whose end points share
+ * neighbours), a breadth-first order over it in which a node is discovered once several of its backbone neighbours
+ * have been walked (unfolded when the walk runs on two fronts), then median sweeps -- the role of rabbit.reorder
+ * (community-based Rabbit Order, rabbit_module/src/reorder.cpp:235-295) with a different, reproducible algorithm
+ * (gnna_reorder.cpp).  Node ids are int32; the edge list may hold any number of entries (64-bit
+ * offsets inside: papers100M symmetrised has 3.2e9). */
 GNNA_API int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
                                int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
 
