@@ -256,6 +256,7 @@ class RankOf8Workload:
                  config="papers100M-like", keep_global=True):
         import torch
         from gnnadvisor_osdi21_amd import _lib, graph
+        from gnnadvisor_osdi21_amd.decider import choose_part_size
         from gnnadvisor_osdi21_amd.dist import ShardedAggregator
         self._lib, self.dev, self.dim, self.form, self.world, self.rank, self.scale = _lib, dev, dim, form, world, rank, scale
         self.config = f"rank-of-{world}/{form}"
@@ -268,7 +269,7 @@ class RankOf8Workload:
         self.rp, self.ci_global = rp, ci
         bounds = [i * n_local for i in range(world + 1)]
         avg = ci.numel() / n_local
-        self.ps = 32 if manual else int(min(64, max(16, 1 << max(0, round(__import__("math").log2(max(1.0, avg)))))))
+        self.ps = 32 if manual else choose_part_size(avg, dim)
         kw = dict(device=dev, emulate=(rank, world))
         if form == "allgather-one-call":      # the whole shard in one rectangular call over the all-gather buffer
             self.agg = ShardedAggregator(rp, ci, bounds, self.ps, overlap=False, exchange="allgather", **kw)

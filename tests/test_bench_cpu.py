@@ -16,6 +16,20 @@ def test_defaults_follow_the_driver_contract():
     assert a.gpus == 1 and a.steps > 0 and a.warmup > 0 and a.dim == 64 and a.config == "reddit-like"
     a = bench.parse_args(["--gpus", "8", "--steps", "5", "--warmup", "2"])
     assert (a.gpus, a.steps, a.warmup) == (8, 5, 2) and a.backend == "nccl" and a.exchange == "auto"
+    # N-rank line: the weak-scaling headline plus the strong-scaling and (at 8 ranks) config-5 legs by default
+    assert a.scaling == "strong,config5" and not a.config5_leg and a.config5_scale == 1.0
+
+
+def test_kernel_labels_name_what_ran():
+    class W:
+        launches, phases = 1, 8
+    assert "sliced schedule" in bench.kernel_label(W)
+    W.phases = 1
+    assert bench.kernel_label(W) == "stream_kernel"
+    W.calls = 5
+    assert "5 library calls" in bench.kernel_label(W)
+    W.calls, W.launches = 1, 4
+    assert "agg_kernel" in bench.kernel_label(W)
 
 
 def test_gpus_n_launches_n_ranks_on_localhost(monkeypatch):
