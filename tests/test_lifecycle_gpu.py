@@ -152,7 +152,7 @@ def test_deterministic_schedule_is_bit_reproducible(dim, phases, prescale):
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     rpn, cin, degn, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), X.numpy()
     try:
-        _lib.set_tuning(deterministic=1, column_phases=phases, gcn_prescale=prescale)
+        _lib.set_tuning(deterministic=1, column_phases=phases, gcn_prescale=prescale, stream_kernel=0)
         runs = []
         for rep in range(4):
             ys = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)

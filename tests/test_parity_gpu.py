@@ -559,7 +559,7 @@ def test_stale_slice_plan_costs_locality_not_correctness():
     for forced in (8, 32):
       ci.copy_(g.column_index)
       try:
-        _lib.set_tuning(column_phases=forced)
+        _lib.set_tuning(column_phases=forced, stream_kernel=0)
         y0 = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
         assert _lib.last_num_phases() == forced
         assert_close_f64(y0.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
