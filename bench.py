@@ -1020,6 +1020,11 @@ def run_sharded(args, result_fd, world, rank, local_rank):
         try:
             g = graph.make_config_graph(args.config, device=dev, locality=args.locality, scale=args.scale)
             sb = balanced_row_splits(g.row_pointers, world)
+            # every rank generated the graph itself (same seed): the row bounds are taken from rank 0 so that the ranks
+            # agree on them even if a generator ever differed between devices
+            holder = [sb]
+            dist.broadcast_object_list(holder, src=0)
+            sb = [int(v) for v in holder[0]]
             srp, sci = shard_csr(g.row_pointers, g.column_index, sb[rank], sb[rank + 1])
             span = g.avg_edgeSpan
             n_all, nnz_all = g.num_nodes, g.nnz
