@@ -881,7 +881,8 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             w.P = num_parts; w.D = dim; w.ldx = ldx; w.U = tune.loads_in_flight; w.S = S; w.B = Bs;
             w.rows_with_edges = plan.stats.valid ? (int64_t)std::min((double)num_nodes, plan.stats.groups) : num_nodes;
             if (tune.groups_per_chunk > 64) w.rounds = tune.groups_per_chunk / 64;   // experiments: G = 64 * (sets per workgroup)
-            w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;   // (experiments: BPC = 1 / 2 workgroups per CU)
+            w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;
+            w.dynamic = tune.xcd_remap != 0;      // (experiments: XCD=0 selects the fixed shares per wavefront)   // (experiments: BPC = 1 / 2 workgroups per CU)
             w.plain_ok = !accumulate_into_out; w.eps = p.eps;
             t_last_phases = Bs;
             t_last_launches = 1;

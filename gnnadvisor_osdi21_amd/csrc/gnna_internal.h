@@ -134,7 +134,8 @@ struct SweepLaunch {
     int rounds = 0;           // sets per workgroup (0: from rows_with_edges and the accumulator capacity)
     int64_t rows_with_edges = 0;
     int slack = 0;            // soft-barrier slack in steps (0: built-in, >= 1000: none)
-    int wgs_per_cu = 0;       // 1: one 16-wavefront workgroup per CU; else two (32 wavefronts, 64 VGPRs)
+    int wgs_per_cu = 0;       // 2: two 16-wavefront workgroups per CU (64 VGPRs, half the accumulators each); else one
+    bool dynamic = true;      // item pool with chunk locks (false: fixed share of the groups per wavefront)
     bool plain_ok;
     float eps;
 };

@@ -53,6 +53,7 @@ namespace {
 constexpr int kSweepIdSlots = 512;   // column ids parked in LDS per wavefront and round of an item
 constexpr int kSweepBlock = 1024;
 constexpr int kSweepWaves = kSweepBlock / kWave;
+constexpr int kSweepLockWords = 128;  // chunk locks of the dynamic pool: up to 4096 chunks per set
 
 // LDS accumulator floats per workgroup: what 160 KiB leave next to the wavefronts' id lists.  WGS = workgroups per
 // CU: 1 -> 16 wavefronts per CU with all of the LDS (128 / 112 KiB of accumulators, up to 128 VGPRs);
@@ -90,6 +91,8 @@ struct SweepParams {
     int32_t B;
     int32_t rounds;            // sets per workgroup
     int32_t plain_ok;          // 1: rows owned by one set are written with plain stores (out is not accumulated into)
+    int32_t dynamic;           // 1: the wavefronts of a workgroup draw (chunk, slice) items from a pool (chunk locks in LDS)
+                               // 0: every wavefront owns a fixed share of the set's groups
     int32_t slack;             // a workgroup starts step t once every workgroup of its XCD has finished step t - slack
                                // (1 = strict barrier); >= 1000: no synchronisation
     float eps;
@@ -127,7 +130,8 @@ sweep_kernel(const SweepParams p)
     __shared__ float s_acc[ACC];                          // partial rows of the workgroup's set
     __shared__ uint32_t s_off[kSweepWaves][RL * RPI];     // per wavefront: the round's list slots as byte offsets into X
     __shared__ int64_t s_g[2];                            // the set's group range
-    __shared__ int s_ctl[8];                              // 1 wavefront-steps done, 2 last seen XCD counter, 3 gave up
+    __shared__ int s_ctl[8];                              // 0 next item, 1 items / wavefront-steps done, 2 last seen XCD counter, 3 gave up
+    __shared__ unsigned s_lock[kSweepLockWords];          // dynamic pool: one bit per chunk of the set (a chunk's rows are one wavefront's at a time)
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -189,18 +193,40 @@ sweep_kernel(const SweepParams p)
         for (int i = threadIdx.x; i < nrows * D; i += kSweepBlock) s_acc[i] = 0.f;
         __syncthreads();
 
-        // this wavefront's share of the set: an equal, contiguous range of its groups
+        // Two ways to hand the set's (chunk, slice) items to the 16 wavefronts:
+        //  * static (p.dynamic == 0): every wavefront owns an equal, contiguous share of the set's groups for all slices;
+        //    a destination row is then one wavefront's, except the rows at the borders of its share;
+        //  * dynamic: the items are a pool in slice order that the wavefronts drain (an LDS counter) -- a wavefront that
+        //    drew a short item draws the next.  A bit per chunk in LDS makes a chunk's rows one wavefront's at a time
+        //    (items of one chunk in consecutive slices are ~nchunks draws apart, so the lock is almost never contended);
+        //    only the rows a chunk shares with its neighbours are added atomically.
         const int64_t ng_set = g_hi - g_lo;
-        const int64_t gw_lo = g_lo + (ng_set * wib) / kSweepWaves, gw_hi = g_lo + (ng_set * (wib + 1)) / kSweepWaves;
-        const int nch_w = (int)((gw_hi - gw_lo + kWave - 1) / kWave);
-        // rows that continue in a neighbouring wavefront's share: the only accumulator rows two wavefronts add to
-        const int wave_prev_row = (gw_lo > g_lo && gw_hi > gw_lo) ? p.p2n[gw_lo - 1] : -1;
-        const int wave_next_row = (gw_hi < g_hi && gw_hi > gw_lo) ? p.p2n[gw_hi] : -1;
-        for (int t = 0; t < B; t++) {
+        const int nchunks = (int)((ng_set + kWave - 1) / kWave);
+        const bool dyn = p.dynamic != 0 && nchunks <= kSweepLockWords * 32;
+        const int64_t gw_lo = dyn ? g_lo : g_lo + (ng_set * wib) / kSweepWaves;
+        const int64_t gw_hi = dyn ? g_hi : g_lo + (ng_set * (wib + 1)) / kSweepWaves;
+        const int nch_w = (int)((gw_hi - gw_lo + kWave - 1) / kWave);        // chunks this wavefront may work on
+        const int per_step = nch_w > 0 ? nch_w : 1;
+        if (dyn)
+            for (int i = threadIdx.x; i < kSweepLockWords; i += kSweepBlock) s_lock[i] = 0u;
+        __syncthreads();
+        const int total_items = dyn ? nchunks * B : per_step * B;
+        int it = 0, last_T = -1;
+        while (true) {
+            int item = it++;
+            if (dyn) {
+                if (lane == 0) item = __hip_atomic_fetch_add(&s_ctl[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                item = __builtin_amdgcn_readfirstlane(item);
+            }
+            if (item >= total_items) break;
+            const int t = item / per_step;                              // items come in slice order
+            const int chunk = item - t * per_step;
             const int T = r * B + t;
+            const int64_t g0 = gw_lo + (int64_t)chunk * kWave;
+            const int ng = nch_w > 0 ? (int)(gw_hi - g0 < (int64_t)kWave ? gw_hi - g0 : (int64_t)kWave) : 0;
 
             // ---- soft barrier: every workgroup of the XCD has finished step T - slack -------------------------
-            if (syncing && T >= p.slack && nch_w > 0) {
+            if (syncing && T >= p.slack && T != last_T) {
                 const uint32_t need = (uint32_t)nbx * (uint32_t)(T - p.slack + 1);
                 const int seen = __hip_atomic_load(&s_ctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const int gave_up = __hip_atomic_load(&s_ctl[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -221,12 +247,26 @@ sweep_kernel(const SweepParams p)
                     }
                 }
             }
+            last_T = T;
+            // rows that continue outside this item's groups: the only accumulator rows another wavefront may add to
+            int wave_prev_row = -1, wave_next_row = -1;
+            if (ng > 0) {
+                if (g0 > g_lo) wave_prev_row = p.p2n[g0 - 1];
+                if (g0 + ng < g_hi) wave_next_row = p.p2n[g0 + ng];
+                if (!dyn) {           // static share: only the share's own borders are shared
+                    if (chunk > 0) wave_prev_row = -1;
+                    if (chunk + 1 < nch_w) wave_next_row = -1;
+                }
+            }
+            if (dyn && lane == 0) {   // the chunk's rows are this wavefront's until the item is done
+                const unsigned bit = 1u << (chunk & 31);
+                while (__hip_atomic_fetch_or(&s_lock[chunk >> 5], bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)
+                    __builtin_amdgcn_s_sleep(2);
+            }
 
-            for (int chunk = 0; chunk < nch_w; chunk++)
+            if (ng > 0)
             {
                 const int f_lo = t * p.S / B, f_hi = (t + 1) * p.S / B;
-                const int64_t g0 = gw_lo + (int64_t)chunk * kWave;
-                const int ng = (int)(gw_hi - g0 < (int64_t)kWave ? gw_hi - g0 : (int64_t)kWave);
 
                 // ---- 1. descriptors (all loads in flight together) -------------------------------------
                 const bool gl = lane < ng;
@@ -412,13 +452,18 @@ sweep_kernel(const SweepParams p)
                     }
                 }
             }
-            // ---- this wavefront's part of step t is done; the last one of the workgroup arrives for it -----------
-            if (syncing && lane == 0) {
+            if (dyn && lane == 0)
+                (void)__hip_atomic_fetch_and(&s_lock[chunk >> 5], ~(1u << (chunk & 31)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- arrival: the workgroup has finished a slice step when all its items (dynamic) / all its wavefronts'
+            // shares (static) of that step are done
+            if (syncing && lane == 0 && (dyn || chunk == per_step - 1)) {
                 const int done = __hip_atomic_fetch_add(&s_ctl[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1;
-                if (done % kSweepWaves == 0)
+                if (done % (dyn ? nchunks : kSweepWaves) == 0)
                     (void)__hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
+        if (dyn && nchunks == 0 && syncing && threadIdx.x == 0)        // nothing to do: still counts as arrived
+            (void)__hip_atomic_fetch_add(ctr, (uint32_t)B, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
 
         // ---- every accumulator row is written once ----------------------------------------------------------
@@ -489,10 +534,11 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     p.flag = a.flag; p.seq = a.seq; p.trust = a.trust; p.sync = a.sync;
     p.P = a.P; p.D = a.D; p.ldx = a.ldx; p.S = a.S; p.B = a.B; p.plain_ok = a.plain_ok ? 1 : 0; p.eps = a.eps;
     p.slack = a.slack > 0 ? a.slack : 2;
+    p.dynamic = a.dynamic ? 1 : 0;
     int lpr = 4;
     const int pieces = (a.D + 3) / 4;
     while (lpr < 32 && lpr < pieces) lpr <<= 1;
-    const int wgs = a.wgs_per_cu == 1 ? 1 : 2;
+    const int wgs = a.wgs_per_cu == 2 ? 2 : 1;
     SweepKernel k = wgs == 1 ? (a.mode == MODE_GIN ? pick_sweep<MODE_GIN, 1>(lpr, a.U) : pick_sweep<MODE_SAG, 1>(lpr, a.U))
                              : (a.mode == MODE_GIN ? pick_sweep<MODE_GIN, 2>(lpr, a.U) : pick_sweep<MODE_SAG, 2>(lpr, a.U));
     // persistent grid: `wgs` workgroups per CU (together all of the CU's LDS), the same number on every XCD

@@ -19,9 +19,9 @@ pytestmark = pytest.mark.gpu
 class sweep_forced:
     """Process-wide knobs for one case: sweep kernel on, `phases` forced, optional sets per workgroup and slack."""
 
-    def __init__(self, phases, rounds=0, slack=0, wgs=0, **kw):
+    def __init__(self, phases, rounds=0, slack=0, wgs=0, dynamic=1, **kw):
         # wgs: workgroups per CU (1: 16 wavefronts with all of the CU's LDS, 2: 32 wavefronts, half the rows each)
-        self.kw = dict(column_phases=phases, sweep=1, sweep_slack=slack, blocks_per_cu=wgs, deterministic=0, stream_kernel=0, **kw)
+        self.kw = dict(column_phases=phases, sweep=1, sweep_slack=slack, blocks_per_cu=wgs, deterministic=0, stream_kernel=0, xcd_remap=dynamic, **kw)
         if rounds:
             self.kw["groups_per_chunk"] = 64 * rounds
 
@@ -55,10 +55,10 @@ def check_modes(g, X, pp, p2n, ps, eps=0.5, what="", sum_scale=False):
 
 
 @pytest.mark.parametrize("dim", [4, 6, 7, 16, 22, 32, 41, 47, 64, 100, 128])
-@pytest.mark.parametrize("phases,wgs", [(2, 1), (5, 2), (32, 1), (32, 2)])
-def test_sweep_matches_oracle_over_widths_and_phase_counts(dim, phases, wgs):
+@pytest.mark.parametrize("phases,wgs,dynamic", [(2, 1, 1), (5, 2, 1), (32, 1, 0), (32, 2, 1), (8, 1, 0)])
+def test_sweep_matches_oracle_over_widths_and_phase_counts(dim, phases, wgs, dynamic):
     g, X, pp, p2n = make_case(3000, 200000, dim, 16, seed=dim * 7 + phases, kind="powerlaw")
-    with sweep_forced(phases, wgs=wgs, gcn_prescale=1) as s:
+    with sweep_forced(phases, wgs=wgs, dynamic=dynamic, gcn_prescale=1) as s:
         check_modes(g, X, pp, p2n, 16, what=f"sweep dim={dim} phases={phases}")
         assert s.launches() == 3, "the sweep kernel did not run"
         assert _lib.last_num_phases() == phases
@@ -90,8 +90,8 @@ def test_sweep_rows_beyond_the_accumulators_take_the_atomic_path():
     CU's LDS holds (256 rows of 128 floats, 512 of 64) -- the rows beyond are flushed per slice with atomics."""
     for dim, n, e in ((128, 150000, 500000), (64, 300000, 900000), (16, 600000, 1500000)):
         g, X, pp, p2n = make_case(n, e, dim, 4, seed=dim + 1)
-        for rounds, wgs in ((1, 1), (3, 2)):
-            with sweep_forced(4, rounds=rounds, wgs=wgs, gcn_prescale=1) as s:
+        for rounds, wgs, dynamic in ((1, 1, 1), (3, 2, 0)):
+            with sweep_forced(4, rounds=rounds, wgs=wgs, dynamic=dynamic, gcn_prescale=1) as s:
                 check_modes(g, X, pp, p2n, 4, what=f"sweep overflow dim={dim} rounds={rounds}")
                 assert s.launches() == 3
 
@@ -104,8 +104,8 @@ def test_sweep_hub_row_spanning_many_sets_and_rows_without_edges():
     gg = graph.graph_from_edges(src[keep], dst[keep], n)
     pp, p2n = _lib.build_part(4, gg.row_pointers)
     X = torch.randn(n, 64, generator=torch.Generator().manual_seed(4))
-    for slack in (1, 2, 1000):
-        with sweep_forced(6, slack=slack, gcn_prescale=1) as s:
+    for slack, dynamic in ((1, 1), (2, 0), (1000, 1)):
+        with sweep_forced(6, slack=slack, dynamic=dynamic, gcn_prescale=1) as s:
             check_modes(gg, X, pp, p2n, 4, what=f"sweep hub slack={slack}", sum_scale=True)
             assert s.launches() == 3
 

@@ -63,12 +63,12 @@ for K in Ks:
         for B in phases:
             _lib.reset_tuning()
             kw = dict(loads_in_flight=U, sweep=1, sweep_slack=sl, column_phases=B,
-                      blocks_per_cu=int(os.environ.get("PROBE_WGS", "0")))
+                      blocks_per_cu=int(os.environ.get("PROBE_WGS", "0")), xcd_remap=int(os.environ.get("PROBE_DYN", "1")))
             if K:
                 kw["groups_per_chunk"] = 64 * K
             _lib.set_tuning(**kw)
             before = _lib.runtime_counters()["sweep_launches"]
             res[B] = timeit() + (exact(),)
             assert _lib.runtime_counters()["sweep_launches"] > before
-        print(json.dumps(dict(kernel="sweep", cfg=cfg, D=D, ps=ps, U=U, wgs=os.environ.get("PROBE_WGS", "0"), R=K, slack=sl, ms_main_prologue_exact=res)), flush=True)
+        print(json.dumps(dict(kernel="sweep", cfg=cfg, D=D, ps=ps, U=U, wgs=os.environ.get("PROBE_WGS", "0"), dynamic=os.environ.get("PROBE_DYN", "1"), R=K, slack=sl, ms_main_prologue_exact=res)), flush=True)
 _lib.reset_tuning()
