@@ -16,10 +16,13 @@
 //
 //   * the partial rows of the set (up to 512 rows of 64 floats) live in the CU's LDS (ds_add_f32; no global
 //     atomics, nothing read back) while the workgroup walks the source slices 0 .. B-1;
-//   * inside the workgroup every wavefront owns an equal, contiguous share of the set's groups, so a destination
-//     row is touched by ONE wavefront (plain LDS read-add-write) unless it straddles the border between two
-//     wavefronts' shares (those two rows per wavefront use ds_add_f32: an LDS float atomic costs ~190 LDS cycles
-//     per wave-instruction -- with atomics for every row the LDS pipe was busy 1.3 ms of a 2.0 ms launch);
+//   * inside the workgroup the set's (64-group chunk, slice) items are drawn from a counter in LDS, slice-major
+//     (or, `dynamic = 0`, every wavefront owns an equal contiguous share of the set's groups).  A wavefront holds
+//     the chunk's bit of an LDS lock word while it runs an item, so the chunk's interior rows are touched by one
+//     wavefront at a time (plain LDS read-add-write); only the rows that continue into a neighbouring chunk
+//     (static: into a neighbouring wavefront's share -- from ANY chunk of the share) use ds_add_f32: an LDS
+//     float atomic costs ~190 LDS cycles per wave-instruction -- with atomics for every row the LDS pipe was
+//     busy 1.3 ms of a 2.0 ms launch;
 //   * every row is written ONCE, after the last slice: a plain coalesced store when the set owns the row, one
 //     atomic add when the row continues in a neighbouring set;
 //   * the workgroups of an XCD (blockIdx % 8) walk the slices in step: a workgroup starts items of slice step t
@@ -251,12 +254,11 @@ sweep_kernel(const SweepParams p)
             // rows that continue outside this item's groups: the only accumulator rows another wavefront may add to
             int wave_prev_row = -1, wave_next_row = -1;
             if (ng > 0) {
-                if (g0 > g_lo) wave_prev_row = p.p2n[g0 - 1];
-                if (g0 + ng < g_hi) wave_next_row = p.p2n[g0 + ng];
-                if (!dyn) {           // static share: only the share's own borders are shared
-                    if (chunk > 0) wave_prev_row = -1;
-                    if (chunk + 1 < nch_w) wave_next_row = -1;
-                }
+                // static share: the rows at the SHARE's borders, in every chunk of it (a long row can reach from an
+                // interior chunk to the share's end); dynamic pool: the rows at the chunk's own borders
+                const int64_t lo = dyn ? g0 : gw_lo, hi = dyn ? g0 + ng : gw_hi;
+                if (lo > g_lo) wave_prev_row = p.p2n[lo - 1];
+                if (hi < g_hi) wave_next_row = p.p2n[hi];
             }
             if (dyn && lane == 0) {   // the chunk's rows are this wavefront's until the item is done
                 const unsigned bit = 1u << (chunk & 31);

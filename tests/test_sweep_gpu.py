@@ -85,6 +85,22 @@ def test_sweep_ones_is_exact():
             assert np.array_equal(y, want), (dim, phases)
 
 
+@pytest.mark.parametrize("dynamic", [0, 1])
+def test_sweep_long_rows_crossing_the_chunks_of_a_wavefront_share_are_exact(dynamic):
+    """Part size 1 makes every edge a group: a wavefront's share is several 64-group chunks and most rows reach from
+    an interior chunk of one share into the next share -- the rows two wavefronts add to concurrently.  (The static
+    shares once marked only the first / last CHUNK's border rows as shared and lost updates on full-size graphs.)"""
+    g, X, pp, p2n = make_case(3000, 1200000, 64, 1, seed=77, kind="powerlaw", x="ones")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    want = (g.row_pointers[1:] - g.row_pointers[:-1]).to(torch.float32)[:, None].expand(-1, 64)
+    for phases, slack in ((6, 1000), (8, 2), (16, 1)):
+        with sweep_forced(phases, slack=slack, dynamic=dynamic) as s:
+            for rep in range(4):
+                y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 1, 32, 4).cpu()
+                assert torch.equal(y, want), (dynamic, phases, slack, rep, int((y != want).any(1).sum()))
+            assert s.launches() == 4
+
+
 def test_sweep_rows_beyond_the_accumulators_take_the_atomic_path():
     """Low-degree rows: a set (1/256 of the edges with one set per workgroup) spans more destination rows than the
     CU's LDS holds (256 rows of 128 floats, 512 of 64) -- the rows beyond are flushed per slice with atomics."""
