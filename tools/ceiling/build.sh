@@ -1,0 +1,5 @@
+#!/bin/bash
+# builds the measurement-only gather floor kernel next to this script
+set -e
+cd "$(dirname "$0")"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared gather_ceiling.hip -o libceiling.so

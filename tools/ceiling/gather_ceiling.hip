@@ -1,0 +1,144 @@
+// gather_ceiling.hip -- measurement tool, not part of the library: what does the bare ACCESS STREAM of the sliced
+// aggregation cost on this chip?  The kernel walks a prepared list of source-row ids (the ids in the order the
+// streaming kernel consumes them: phase-major, then edge order) in segments of `seg` ids per wavefront, keeps U
+// wave-wide row loads (64 / LPR rows each) in flight, sums them and writes one vector per wavefront.  No partition,
+// no pieces, no flushes: the time of this kernel is the floor any schedule with the same slices and the same
+// dispatch order has to live with.  D = 4 * LPR floats per row.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int LPR, int U>
+__global__ void __launch_bounds__(256) gather_ceiling(const float *__restrict__ X, const int32_t *__restrict__ ids,
+                                                      int64_t n, int seg, float *__restrict__ out)
+{
+    constexpr int RPI = 64 / LPR;                 // rows per wave-wide load
+    constexpr int LOADS = 64 / RPI;               // loads per tile of 64 ids
+    static_assert(LOADS % U == 0, "");
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t base = wave * (int64_t)seg;
+    if (base + seg > n) return;
+    const int lslot = lane / LPR, c = lane % LPR;
+    const char *xb = reinterpret_cast<const char *>(X) + c * 16;
+    const uint32_t row_bytes = LPR * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int idv = __builtin_nontemporal_load(ids + base + lane);
+    for (int t = 0; t < seg; t += 64) {
+        const int idn = (t + 64 < seg) ? __builtin_nontemporal_load(ids + base + t + 64 + lane) : 0;
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t id = (uint32_t)__shfl(idv, u * RPI + lslot);
+            v[u] = *reinterpret_cast<const f32x4 *>(xb + id * row_bytes);
+        }
+#pragma unroll
+        for (int b = 1; b < LOADS / U; b++) {
+            uint32_t nn[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) nn[u] = (uint32_t)__shfl(idv, (b * U + u) * RPI + lslot) * row_bytes;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                acc += v[u];
+                v[u] = *reinterpret_cast<const f32x4 *>(xb + nn[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u];
+        idv = idn;
+    }
+    reinterpret_cast<f32x4 *>(out)[wave * 64 + lane] = acc;
+}
+
+// Variant with a cache of hot rows in LDS: 1024-thread workgroups (one per CU: 16 wavefronts), `hub_rows` rows of
+// the table `hub` copied to LDS up front; an id with the top bit set is "0x80000000 | slot" and is read from LDS.
+// (hub_rows = 0: the same kernel shape without the cache -- the floor at 16 wavefronts per CU.)
+template <int LPR, int U>
+__global__ void __launch_bounds__(1024) gather_ceiling_hub(const float *__restrict__ X, const int32_t *__restrict__ ids,
+                                                           int64_t n, int seg, float *__restrict__ out,
+                                                           const float *__restrict__ hub, int hub_rows, int lds_bytes_used)
+{
+    constexpr int RPI = 64 / LPR;
+    constexpr int LOADS = 64 / RPI;
+    extern __shared__ float s_hub[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < hub_rows * LPR * 4; i += 1024) s_hub[i] = hub[i];
+    __syncthreads();
+    const int wib = threadIdx.x >> 6;
+    const int lslot = lane / LPR, c = lane % LPR;
+    const char *xb = reinterpret_cast<const char *>(X) + c * 16;
+    const char *hb = reinterpret_cast<const char *>(s_hub) + c * 16;
+    const uint32_t row_bytes = LPR * 16;
+    const int64_t waves_total = (int64_t)gridDim.x * 16;
+    const int64_t nseg = n / seg;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // persistent: wavefront w takes segments w, w + W, ... (phase-major order is kept chip-wide)
+    for (int64_t sgi = (int64_t)blockIdx.x * 16 + wib; sgi < nseg; sgi += waves_total) {
+        const int64_t base = sgi * (int64_t)seg;
+        int idv = __builtin_nontemporal_load(ids + base + lane);
+        for (int t = 0; t < seg; t += 64) {
+            const int idn = (t + 64 < seg) ? __builtin_nontemporal_load(ids + base + t + 64 + lane) : 0;
+            auto load = [&](uint32_t id) -> f32x4 {
+                if (id >> 31) return *reinterpret_cast<const f32x4 *>(hb + (id & 0x7fffffffu) * row_bytes);
+                return *reinterpret_cast<const f32x4 *>(xb + id * row_bytes);
+            };
+            f32x4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = load((uint32_t)__shfl(idv, u * RPI + lslot));
+#pragma unroll
+            for (int b = 1; b < LOADS / U; b++) {
+                uint32_t nn[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) nn[u] = (uint32_t)__shfl(idv, (b * U + u) * RPI + lslot);
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    acc += v[u];
+                    v[u] = load(nn[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) acc += v[u];
+            idv = idn;
+        }
+    }
+    reinterpret_cast<f32x4 *>(out)[((int64_t)blockIdx.x * 16 + wib) * 64 + lane] = acc;
+}
+
+extern "C" __attribute__((visibility("default")))
+int gather_ceiling_hub_launch(const float *X, const int32_t *ids, int64_t n, int dim, int seg, int U, float *out,
+                              const float *hub, int hub_rows, int lds_bytes, int blocks)
+{
+    if (seg % 64 != 0 || seg <= 0 || dim != 64) return -1;
+    if ((size_t)hub_rows * dim * 4 > (size_t)lds_bytes) return -4;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    if (U == 4) hipLaunchKernelGGL((gather_ceiling_hub<16, 4>), dim3(blocks), dim3(1024), lds_bytes, 0, X, ids, n, seg, out, hub, hub_rows, lds_bytes);
+    else if (U == 8) hipLaunchKernelGGL((gather_ceiling_hub<16, 8>), dim3(blocks), dim3(1024), lds_bytes, 0, X, ids, n, seg, out, hub, hub_rows, lds_bytes);
+    else return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" __attribute__((visibility("default")))
+int gather_ceiling_launch(const float *X, const int32_t *ids, int64_t n, int dim, int seg, int U, float *out)
+{
+    if (seg % 64 != 0 || seg <= 0) return -1;
+    const int64_t waves = n / seg;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (grid == 0) return 0;
+#define GO(L, UU) hipLaunchKernelGGL((gather_ceiling<L, UU>), dim3(grid), dim3(256), 0, 0, X, ids, n, seg, out)
+    if (dim == 64 && U == 4) GO(16, 4);
+    else if (dim == 64 && U == 8) GO(16, 8);
+    else if (dim == 64 && U == 16) GO(16, 16);
+    else if (dim == 128 && U == 4) GO(32, 4);
+    else if (dim == 128 && U == 8) GO(32, 8);
+    else if (dim == 32 && U == 4) GO(8, 4);
+    else if (dim == 32 && U == 8) GO(8, 8);
+    else return -2;
+#undef GO
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
