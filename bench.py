@@ -88,6 +88,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the HBM-resident second workload")
     ap.add_argument("--secondary-config", default="products-like")
+    ap.add_argument("--no-prepare", action="store_true",
+                    help="do not call gnna_prepare_graph (column ids are then read from column_index, no packed copy)")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip BASELINE config 5's true per-rank shape (rank 0 of 8 of a papers100M-like graph, D = 128, "
                          "gathering from all 111 M source nodes)")
@@ -150,7 +152,7 @@ class Workload:
     """One single-GPU aggregation workload: graph + partition + features, and its step()."""
 
     def __init__(self, config, dim, dev, *, scale=1.0, locality=0.0, manual=False, part_size=0,
-                 calibrate=True, force_phases=0):
+                 calibrate=True, force_phases=0, prepare=True):
         import torch
         from gnnadvisor_osdi21_amd import _lib, graph
         from gnnadvisor_osdi21_amd.decider import inputProperty, calibrate_phases
@@ -182,10 +184,17 @@ class Workload:
             # Decider auto mode, measuring part: register this graph's hints and let the tuner time the
             # rule's phase count against its neighbours on the actual graph (set-up, outside the timed region)
             _lib.set_graph_hints(g.column_index, g.nnz / g.num_nodes, g.avg_edgeSpan > 0.28 * g.num_nodes)
+            # graph lifecycle as in the driver (main.py): gnna_prepare_graph declares the graph immutable, does the
+            # counting pass and -- gnna_tuning.pack_ids -- keeps the column ids in the order the sliced schedule reads them
+            if prepare:
+                _lib.prepare_graph(g.column_index, self.ppd, self.p2nd, g.num_nodes, g.num_nodes, self.ps, [dim])
             if force_phases > 0:
                 _lib.set_graph_phases(g.column_index, dim, force_phases)
             elif calibrate:
                 self.calibrated = calibrate_phases(g.column_index, self.ppd, self.p2nd, g.num_nodes, self.ps, [dim])
+            if prepare:
+                _lib.prepare_graph(g.column_index, self.ppd, self.p2nd, g.num_nodes, g.num_nodes, self.ps, [dim])
+        self.prepared = bool(prepare and not manual)
         self._lib = _lib
 
     def step(self, X=None, out=None):
@@ -451,7 +460,8 @@ def pmc_child(args):
                                 keep_global=False)
         else:
             w = Workload(cfg, int(dim), dev, scale=float(scale), locality=args.locality, manual=args.manual,
-                         part_size=int(ps), calibrate=False, force_phases=0 if args.manual else int(phases))
+                         part_size=int(ps), calibrate=False, force_phases=0 if args.manual else int(phases),
+                         prepare=not args.no_prepare)
         warm, steps = 1, 3
         for _ in range(warm + steps):
             w.step()
@@ -480,6 +490,8 @@ def run_pmc_pass(counters, specs, args, workdir):
              "--pmc-workloads", ",".join(specs), "--scale", str(args.scale), "--locality", str(args.locality)]
     if args.manual:
         child.append("--manual")
+    if args.no_prepare:
+        child.append("--no-prepare")
     cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "agg_kernel|stream_kernel|sweep_kernel|copyBuffer", "-T",
            "-d", outdir, "-o", "pmc", "-f", "csv", "--", *child]
     env = dict(os.environ, TMPDIR="/tmp")
@@ -733,6 +745,25 @@ def other_modes(w, steps: int = 10):
             fn()
         torch.cuda.synchronize()
         res[name + "_edges_per_s"] = g.nnz * steps / (time.perf_counter() - t0)
+    if getattr(w, "prepared", False):
+        # the same SAG calls with the ids read from column_index (gnna_tuning.pack_ids = 2): what a caller gets who
+        # uses the six reference functions only, without gnna_prepare_graph
+        _lib.set_tuning(pack_ids=2)
+        try:
+            for _ in range(3):
+                w.step()
+            torch.cuda.synchronize()
+            _lib.profile_begin(steps)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                w.step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            pr = _lib.profile_end()
+            res["sag_without_prepare_graph"] = {"edges_per_s": g.nnz * steps / el, "ms_per_step": el * 1e3 / steps,
+                                                "kernel_ms": pr["main_ms"], "what": "column ids read from column_index (no packed copy)"}
+        finally:
+            _lib.set_tuning(pack_ids=0)
     return res
 
 
@@ -758,7 +789,7 @@ def run_single(args, result_fd):
         os.write(result_fd, (json.dumps(rec) + "\n").encode())
         return
     w = Workload(args.config, args.dim, dev, scale=args.scale, locality=args.locality, manual=args.manual,
-                 part_size=args.partSize, calibrate=not args.headline_only)
+                 part_size=args.partSize, calibrate=not args.headline_only, prepare=not args.no_prepare)
     elapsed, prof = w.time(args.steps, args.warmup)
     g = w.g
     kern_ms, pro_ms = prof["main_ms"], prof["prologue_ms"]
@@ -807,7 +838,9 @@ def run_single(args, result_fd):
                    "partSize": w.ps, "num_parts_per_gpu": w.P, "source_nodes": g.num_nodes,
                    "feature_MB": x_mb, "parallelism": "single GPU", "world_size": 1, "device": str(dev),
                    "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
-                   "column_phases_used": w.phases, "calibrated_phases": w.calibrated, "tuning": tuning},
+                   "column_phases_used": w.phases, "calibrated_phases": w.calibrated, "tuning": tuning,
+                   "graph_lifecycle": ("gnna_prepare_graph before the timed region (as the driver does): plan pinned, column ids "
+                                       "packed in the order the sliced schedule reads them" if w.prepared else "none (six reference functions only)")},
         "roofline": roofline_record(w, kern_ms, pro_ms, traffic.get(id(w)),
                                     "l2-fabric" if x_mb * 1e6 < (256 << 20) else "hbm"),
     }

@@ -917,6 +917,13 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             if (em != hipSuccess) return fail(GNNA_ERR_HIP, "deterministic schedule scratch: %s", hipGetErrorString(em));
             t_last_launches = B;
         }
+        // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
+        // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
+        if (cnt && plan.handle && tune.pack_ids != 2 && mode != MODE_SDDMM) {
+            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, &a.ids_packed, &a.item_off);
+            if (rc != GNNA_OK) return rc;
+            if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
+        }
         // single pass, nothing to add to: only the rows the kernel does not store need clearing -- worth a second
         // (empty) launch once the output is tens of MB
         const bool sparse = !a.det && a.plain_ok && tune.zero_fill != 2 &&
@@ -1075,6 +1082,11 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
                                   t.nonlocal_ids == 1);
         }
         if (phases_out) phases_out[i] = std::max(1, B);
+        if (B >= 2 && t.pack_ids != 2 && plan.handle && t.sweep != 1) {
+            const int32_t *ids = nullptr; const uint32_t *off = nullptr;
+            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, &ids, &off);
+            if (rc != GNNA_OK) return rc;
+        }
         if (t.deterministic == 1 && dim >= 4) {   // the deterministic schedule parks partial rows in the stream's scratch (slot 2)
             const int G_eff = std::max(1, std::min(kWave, t.groups_per_chunk * std::max(1, B)));
             const size_t chunks = (size_t)((num_parts + G_eff - 1) / G_eff);

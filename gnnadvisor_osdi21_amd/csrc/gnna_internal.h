@@ -79,6 +79,7 @@ struct SlicePlan {
     int S = 0;                       // fine slices of the plan
     uint32_t slice_rows = 0;         // source rows per fine slice
     SlicePlanStats stats;
+    void *handle = nullptr;          // the plan itself when it is pinned (get_packed_ids), else null
 };
 // Fine slicing of `num_in_rows` source rows: S = kMaxSlices slices of ceil(num_in_rows / S) rows.
 inline uint32_t slice_rows_for(int64_t num_in_rows)
@@ -94,6 +95,9 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
                    const int32_t *part2Node, int64_t num_parts, int64_t num_in_rows, bool want_stats, bool pin,
                    SlicePlan *out);
 void drop_slice_plans();
+// Packed column ids of a pinned plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.
+int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build,
+                   const int32_t **ids, const uint32_t **item_off);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
 int release_slice_plans(const void *column_index);
 // Number of phases of the sliced schedule from the statistics of the partition (gnna_agg.hip).
@@ -101,7 +105,7 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
                   bool square, bool hinted_scattered);
 // Events on the launch path that the contract promises not to happen after gnna_prepare_graph (gnna_runtime_counters).
 enum { CTR_PLAN_BUILDS = 0, CTR_LAUNCH_SYNCS = 1, CTR_LAUNCH_FREES = 2, CTR_LAUNCH_MALLOCS = 3, CTR_BACKOFF_SKIPS = 4,
-       CTR_SWEEP_LAUNCHES = 5, CTR_COUNT = 8 };
+       CTR_SWEEP_LAUNCHES = 5, CTR_PACK_BUILDS = 6, CTR_PACKED_LAUNCHES = 7, CTR_COUNT = 8 };
 void count_event(int which);
 
 struct StreamLaunch {
@@ -118,6 +122,7 @@ struct StreamLaunch {
     float eps;
     bool det = false;                              // deterministic schedule (ordered phase launches, no atomics)
     float *det_part = nullptr; int32_t *det_stamp = nullptr;   // [num_chunks][2][D] partial rows / [num_chunks][2] stamps
+    const int32_t *ids_packed = nullptr; const uint32_t *item_off = nullptr;   // packed ids of a prepared graph for (B, G)
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
 

@@ -98,6 +98,10 @@ struct StreamParams {
     int32_t stamp;
     int32_t det;
     float eps;
+    // packed column ids of a prepared graph (gnna_prepare_graph): the ids of work item (phase, chunk) contiguous at
+    // ids_packed[item_off[phase * num_chunks + chunk] ...], groups in order -- or null: ids are read from `col`
+    const int32_t *ids_packed;
+    const uint32_t *item_off;
 };
 
 // ---- slice counts ---------------------------------------------------------------------------------
@@ -302,6 +306,9 @@ stream_kernel(const StreamParams p)
     int prev_row = -1, next_row = -1;
     if (g0 > 0) prev_row = p.p2n[g0 - 1];
     if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
+    const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr;
+    const uint32_t item_base = packed ? p.item_off[(size_t)phase * (size_t)p.num_chunks + (size_t)chunk] : 0u;
+    const int32_t *__restrict__ ids = packed ? p.ids_packed : p.col;
 
     const int len = pb > pa ? pb - pa : 0;
     // positions [beg, end) of the group belong to this phase.  The stored bytes are non-decreasing in the
@@ -321,10 +328,12 @@ stream_kernel(const StreamParams p)
     const unsigned long long above = ~upto;                             // lanes > lane
     // pieces of consecutive groups of one row that are adjacent in the edge array (sorted ids: the row's
     // part of the slice) are merged into one piece, headed by the first: no padding, no bookkeeping between them
+    // (packed ids: the item's edges are contiguous in group order, so consecutive non-empty groups always are)
     const int up_end = __shfl_up(pa + end, 1), up_n = __shfl_up(n_own, 1);
-    const bool cont = n_own > 0 && !seg_start && up_n > 0 && up_end == pa + beg;
+    const bool cont = n_own > 0 && !seg_start && up_n > 0 && (packed || up_end == pa + beg);
     const unsigned long long NE = __ballot(n_own > 0 && !cont);        // piece heads
     const int n_cum = wave_inclusive_scan(n_own);
+    const int own_beg = packed ? (int)item_base + (n_cum - n_own) : pa + beg;    // first edge of this group's part
     const unsigned long long heads_above = NE & above;
     const int next_head = heads_above ? __builtin_ctzll(heads_above) : 64;
     const int chain_cum = __shfl(n_cum, next_head - 1);   // (every lane takes part: the sources are not heads)
@@ -345,7 +354,7 @@ stream_kernel(const StreamParams p)
     const int rank = __popcll(NE & (upto >> 1));
     const int R = __popcll(NE);
     const int dst = (n > 0 ? rank : 63) << 2;       // empty pieces all land on lane 63 (unused unless R == 64, then none is empty)
-    const int c_pbeg = __builtin_amdgcn_ds_permute(dst, pa + beg);
+    const int c_pbeg = __builtin_amdgcn_ds_permute(dst, own_beg);
     const int t_n = __builtin_amdgcn_ds_permute(dst, n);   // (executed by every lane: the senders are not the receivers)
     const int c_n = lane < R ? t_n : 0;
     const int c_meta = __builtin_amdgcn_ds_permute(dst, (my_row << 2) | (last_in_seg ? 2 : 0) | use_atomic_l);
@@ -423,19 +432,19 @@ stream_kernel(const StreamParams p)
                         typedef i32x4 i32x4u __attribute__((aligned(4)));
 #pragma unroll
                         for (int s4 = 0; s4 < RPI; s4 += 4) {
-                            const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(p.col + e_j + s4));
+                            const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(ids + e_j + s4));
                             o[s4] = (uint32_t)t[0]; o[s4 + 1] = (uint32_t)t[1]; o[s4 + 2] = (uint32_t)t[2]; o[s4 + 3] = (uint32_t)t[3];
                         }
                     } else {
 #pragma unroll
-                        for (int s = 0; s < RPI; s++) o[s] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + s);
+                        for (int s = 0; s < RPI; s++) o[s] = (uint32_t)__builtin_nontemporal_load(ids + e_j + s);
                     }
                 } else {
-                    const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(p.col + e_j) : 0u;
+                    const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(ids + e_j) : 0u;
 #pragma unroll
                     for (int s = 0; s < RPI; s++) {
                         o[s] = first;
-                        if (s > 0 && s < v_j) o[s] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + s);
+                        if (s > 0 && s < v_j) o[s] = (uint32_t)__builtin_nontemporal_load(ids + e_j + s);
                     }
                 }
                 if constexpr (MODE == MODE_GCN) {
@@ -615,6 +624,91 @@ det_fixup_kernel(const int32_t *__restrict__ p2n, int64_t P, int G, int64_t num_
     }
 }
 
+// ---- packed column ids of a prepared graph -------------------------------------------------------------
+// In the sliced schedule a work item (chunk of G groups, phase) reads, of every group, only the ids of the phase's
+// slices: 64 fragments of a few ids each, every one a whole 128-byte line of `column_index` that the other phases
+// fetch again (Reddit-like, 8 phases: ~2.7 GB of the 7.9 GB a step moves are id lines fetched ~6 times).  For a graph
+// that gnna_prepare_graph has declared immutable the plan keeps, per (B, G) in use, a copy of the ids in the order the
+// kernel consumes them -- phase-major, then chunk, then group, then edge -- and the start of every item in it: an
+// item then reads its ids once, contiguously.  (Not for automatic plans: a copy of ids cannot follow a
+// column_index that is rewritten in place, the cumulative counts can.)
+__device__ __forceinline__ int group_part(const int32_t *__restrict__ pp, const uint8_t *__restrict__ cnt, int64_t P, int S, int B,
+                                          int phase, int64_t g, int *first)
+{
+    const int pa = pp[g], pb = pp[g + 1];
+    const int f_lo = phase * S / B, f_hi = (phase + 1) * S / B;
+    int cum_lo = 0, cum_hi = 0x7fffffff;
+    if (f_lo > 0) cum_lo = cnt[(size_t)(f_lo - 1) * (size_t)P + (size_t)g];
+    if (f_hi < S) cum_hi = cnt[(size_t)(f_hi - 1) * (size_t)P + (size_t)g];
+    const int len = pb > pa ? pb - pa : 0;
+    const int beg = cum_lo < len ? cum_lo : len;
+    int end = cum_hi < len ? cum_hi : len;
+    end = end > beg ? end : beg;
+    *first = pa + beg;
+    return end - beg;
+}
+
+// counts[phase * num_chunks + chunk] = edges of the item; one wavefront per item
+__global__ void __launch_bounds__(kBlock)
+item_count_kernel(const int32_t *__restrict__ pp, const uint8_t *__restrict__ cnt, int64_t P, int64_t num_chunks, int G, int S, int B,
+                  uint32_t *__restrict__ counts)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t items = num_chunks * B;
+    for (int64_t q = wave; q < items; q += nwaves) {
+        const int phase = (int)(q / num_chunks);
+        const int64_t g = (q % num_chunks) * G + lane;
+        int first = 0;
+        const int n = (lane < G && g < P) ? group_part(pp, cnt, P, S, B, phase, g, &first) : 0;
+        const int tot = __builtin_amdgcn_readlane(wave_inclusive_scan(n), kWave - 1);
+        if (lane == 0) counts[q] = (uint32_t)tot;
+    }
+}
+
+// in-place exclusive prefix of v[0 .. n) plus the total in v[n]; one workgroup
+__global__ void __launch_bounds__(1024)
+item_scan_kernel(uint32_t *__restrict__ v, int64_t n)
+{
+    __shared__ uint32_t part[1024];
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (int64_t i = lo; i < hi; i++) sum += v[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+    for (int64_t i = lo; i < hi; i++) { const uint32_t c = v[i]; v[i] = run; run += c; }
+    if (threadIdx.x == 1023) v[n] = part[1023];
+}
+
+// ids_packed[item_off[q] + (edges of the item's earlier groups) + j] = col[first edge of the group's part + j]
+__global__ void __launch_bounds__(kBlock)
+item_pack_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp, const uint8_t *__restrict__ cnt, int64_t P,
+                 int64_t num_chunks, int G, int S, int B, const uint32_t *__restrict__ item_off, int32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t items = num_chunks * B;
+    for (int64_t q = wave; q < items; q += nwaves) {
+        const int phase = (int)(q / num_chunks);
+        const int64_t g = (q % num_chunks) * G + lane;
+        int first = 0;
+        const int n = (lane < G && g < P) ? group_part(pp, cnt, P, S, B, phase, g, &first) : 0;
+        const int incl = wave_inclusive_scan(n);
+        int32_t *dst = out + item_off[q] + (uint32_t)(incl - n);
+        for (int j = 0; j < n; j++) dst[j] = col[first + j];
+    }
+}
+
 // ---- plan cache -------------------------------------------------------------------------------------
 struct Plan {
     const void *col = nullptr, *pp = nullptr, *p2n = nullptr;
@@ -632,7 +726,18 @@ struct Plan {
     bool pinned = false;             // made by gnna_prepare_graph: never evicted, only gnna_release_graph drops it
     uint64_t stamp = 0;
     uint32_t uses = 0;
+    // packed column ids (pinned plans only), one copy per (phases, groups per chunk) in use
+    struct Packed {
+        int B = 0, G = 0;
+        int32_t *ids = nullptr;          // nnz ids, then (at item_off) B * num_chunks + 1 item starts
+        uint32_t *item_off = nullptr;
+        hipEvent_t ready = nullptr;
+        hipStream_t made_on = nullptr;
+        uint64_t stamp = 0;
+    };
+    std::vector<Packed> packed;
 };
+constexpr int kMaxPacked = 3;   // copies per plan (a GCN / GIN model aggregates at two or three widths)
 constexpr int kMaxPlans = 32;   // unpinned plans kept (31 bytes per neighbor-group each; Reddit-like: 59 MB): small next to
                                 // 288 GB, and a working set of graphs larger than the table would recount on every call
 std::vector<Plan *> g_plans;    // pinned plans are unbounded
@@ -778,6 +883,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
     if (pin) hit->pinned = true;
     hit->stamp = ++g_plan_clock;
     out->cnt = hit->cnt;
+    out->handle = hit->pinned ? hit : nullptr;
     out->S = S;
     out->slice_rows = slice_rows;
     out->stats.valid = hit->have_stats;
@@ -799,6 +905,10 @@ int release_slice_plans(const void *column_index)
         if (column_index && pl->col != column_index) { i++; continue; }
         if (pl->cnt) (void)hipFree(pl->cnt);             // (hipFree waits for the device: kernels still reading it finish first)
         if (pl->ready) (void)hipEventDestroy(pl->ready);
+        for (auto &pk : pl->packed) {
+            if (pk.ids) (void)hipFree(pk.ids);
+            if (pk.ready) (void)hipEventDestroy(pk.ready);
+        }
         delete pl;
         g_plans.erase(g_plans.begin() + (long)i);
         dropped++;
@@ -807,6 +917,74 @@ int release_slice_plans(const void *column_index)
 }
 
 void drop_slice_plans() { (void)release_slice_plans(nullptr); }
+
+// Packed ids of a pinned plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
+// capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
+// plan that already holds kMaxPacked is replaced after a device synchronisation).  *ids stays null when there is none.
+int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build,
+                   const int32_t **ids, const uint32_t **item_off)
+{
+    *ids = nullptr; *item_off = nullptr;
+    if (!plan_handle || B < 2 || G < 1) return GNNA_OK;
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    Plan *pl = nullptr;
+    for (Plan *q : g_plans) if (q == plan_handle) { pl = q; break; }
+    if (!pl || !pl->pinned || !pl->cnt) return GNNA_OK;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cap);
+    for (auto &pk : pl->packed) {
+        if (pk.B == B && pk.G == G && pk.ids) {
+            if (pk.made_on != stream && cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, pk.ready, 0);
+            pk.stamp = ++g_plan_clock;
+            *ids = pk.ids; *item_off = pk.item_off;
+            return GNNA_OK;
+        }
+    }
+    if (!may_build || cap != hipStreamCaptureStatusNone) return GNNA_OK;
+    const int64_t num_chunks = (pl->P + G - 1) / G;
+    const int64_t items = num_chunks * B;
+    // nnz: the last part pointer (one 4-byte read; builds are rare)
+    int32_t nnz = 0;
+    hipError_t e = hipMemcpyAsync(&nnz, static_cast<const int32_t *>(pl->pp) + pl->P, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids (edge count): %s", hipGetErrorString(e));
+    if (nnz <= 0) return GNNA_OK;
+    Plan::Packed *slot = nullptr;
+    if ((int)pl->packed.size() < kMaxPacked) {
+        pl->packed.emplace_back();
+        slot = &pl->packed.back();
+    } else {
+        for (auto &pk : pl->packed) if (!slot || pk.stamp < slot->stamp) slot = &pk;
+        (void)hipDeviceSynchronize();           // kernels of any stream may still read the copy that goes
+        count_event(CTR_LAUNCH_SYNCS);
+        if (slot->ids) { (void)hipFree(slot->ids); count_event(CTR_LAUNCH_FREES); }
+        slot->ids = nullptr; slot->item_off = nullptr;
+    }
+    const size_t id_bytes = (((size_t)nnz * sizeof(int32_t)) + 255) & ~(size_t)255;
+    const size_t bytes = id_bytes + ((size_t)items + 1) * sizeof(uint32_t);
+    e = hipMalloc(reinterpret_cast<void **>(&slot->ids), bytes);
+    count_event(CTR_LAUNCH_MALLOCS);
+    if (e != hipSuccess) {
+        slot->ids = nullptr; slot->B = 0;
+        (void)hipGetLastError();
+        return GNNA_OK;                          // no memory for the copy: the ids are read from column_index
+    }
+    slot->item_off = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(slot->ids) + id_bytes);
+    slot->B = B; slot->G = G; slot->made_on = stream; slot->stamp = ++g_plan_clock;
+    if (!slot->ready) (void)hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming);
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)ds->num_cus * 16));
+    hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->pp),
+                       pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off);
+    hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, stream, slot->item_off, items);
+    hipLaunchKernelGGL(item_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col),
+                       static_cast<const int32_t *>(pl->pp), pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off, slot->ids);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids launch: %s", hipGetErrorString(e));
+    (void)hipEventRecord(slot->ready, stream);
+    count_event(CTR_PACK_BUILDS);
+    *ids = slot->ids; *item_off = slot->item_off;
+    return GNNA_OK;
+}
 
 int launch_stream(const StreamLaunch &a, hipStream_t stream)
 {
@@ -832,6 +1010,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, 4) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
     p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
+    p.ids_packed = a.mode == MODE_SDDMM ? nullptr : a.ids_packed; p.item_off = a.item_off;
     if (a.det && a.mode != MODE_SDDMM) {
         // deterministic schedule: the phases are separate launches in order, each followed by the ordered sum of
         // the rows that chunks share

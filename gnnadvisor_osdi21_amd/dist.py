@@ -652,6 +652,28 @@ class ShardedAggregator:
         self._deg_all = buf
         return buf
 
+    def _parts(self):
+        """(column ids, part pointers, part2Node, source rows) of every CSR this shard aggregates with."""
+        n_all = self.remote_rows if self.overlap else self.world * self.rows_per_rank
+        if not self.overlap:
+            return [(self.column_index, self.part_pointers, self.part2Node, n_all if self.world > 1 else self.n_local)]
+        parts = [self.local_part + (self.n_local,)]
+        if self.chunks == 1:
+            parts.append(self.remote_part + (n_all,))
+        else:
+            parts += [pc + (self.piece_rows,) for pc in self.remote_pieces]
+        return [pt for pt in parts if pt[0].numel()]
+
+    def prepare(self, dims) -> None:
+        """Graph lifecycle for the shard's CSRs (``gnna_prepare_graph``): plans pinned, phase counts chosen and the
+        column ids packed for the widths in ``dims`` up front -- the CSRs of a shard never change.  Only with the real
+        kernel on a GPU."""
+        if self.aggregate_fn is not _default_aggregate or self.device.type != "cuda":
+            return
+        from . import _lib
+        for ci, pp, p2n, n_in in self._parts():
+            _lib.prepare_graph(ci, pp, p2n, int(n_in), self.n_local, self.partSize, [int(d) for d in dims])
+
     def calibrate(self, dims, reps: int = 3) -> dict:
         """Measured phase counts for the parts of this shard (no collective involved: every rank tunes its
         own kernels on random features).  Every part -- local, remote, or the K pieces of the remote part -- goes
@@ -661,6 +683,13 @@ class ShardedAggregator:
         from . import _lib
         from .decider import calibrate_phases
         res = {}
+        self.prepare(dims)
+        try:
+            return self._calibrate(dims, res, calibrate_phases)
+        finally:
+            self.prepare(dims)       # the measured schedule's phase counts get their packed copies now
+
+    def _calibrate(self, dims, res, calibrate_phases) -> dict:
         n_all = self.remote_rows if self.overlap else self.world * self.rows_per_rank
         if not self.overlap:
             res["whole"] = calibrate_phases(self.column_index, self.part_pointers, self.part2Node, self.n_local,

@@ -128,6 +128,9 @@ def main(argv=None):
         if args.model == 'gin' and dataset.num_features <= 2 * args.hidden:
             widths.add(dataset.num_features)
         inputInfo.calibrate(widths)
+        # the measured schedule may use other phase counts than the rule's: make their packed id copies now, not in an epoch
+        _gnna_lib.prepare_graph(inputInfo.column_index, inputInfo.partPtr, inputInfo.part2Node, dataset.num_nodes,
+                                dataset.num_nodes, inputInfo.partSize, _prep_widths)
     degrees = inputInfo.degrees
 
     # ---- single-SpMM verification / profiling (GNNA_main.py:116-137) -------------------------------

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 300 /* 0.3.0: gnna_tuning grew (sweep, sweep_slack), graph lifecycle, 64-bit CSR builder */
+#define GNNA_VERSION 301 /* 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -262,6 +262,10 @@ typedef struct gnna_tuning {
                              so the association order of every output element is fixed.  Costs the per-phase launches
                              and the read-back of the rows; 0 = the default schedule (atomics: reproducible to fp32
                              rounding, exact where the sums are exactly representable) */
+    int pack_ids;         /* prepared graphs (gnna_prepare_graph) only: keep, per phase count in use, a copy of the column
+                             ids in the order the sliced schedule consumes them, so that a work item reads its ids once
+                             and contiguously instead of one cache line per neighbor-group and phase (nnz x 4 bytes per
+                             copy, up to 3 copies per graph).  0 = automatic (on for prepared graphs), 1 = on, 2 = off */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
@@ -302,7 +306,8 @@ GNNA_API int gnna_release_graph(const int32_t *column_index);
 /* Events of the library's launch path since load (for tests and monitoring):
  *   [0] counting passes run, [1] stream / device synchronisations inside aggregation calls, [2] hipFree and
  *   [3] hipMalloc inside aggregation calls, [4] counting passes skipped by the back-off for partitions that are
- *   never seen twice, [5] launches of the sweep kernel; [6..7] reserved (0). */
+ *   never seen twice, [5] launches of the sweep kernel, [6] packed-id copies built, [7] aggregation launches that
+ *   read packed ids. */
 GNNA_API void gnna_runtime_counters(int64_t out[8]);
 
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gnna.h but not exported by libgnna.so"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.gnna_version() == 300
+    assert lib.gnna_version() == 301
 
 
 def test_build_part_c_abi_bit_exact_vs_oracle_and_golden(golden_dir):
@@ -113,7 +113,7 @@ def test_tuning_roundtrip():
         assert _lib.get_tuning() == dict(groups_per_chunk=8, loads_in_flight=4, blocks_per_cu=2,
                                          xcd_remap=0, trust_canonical=1, column_phases=0, avg_degree=0,
                                          nonlocal_ids=0, gcn_prescale=0, pad_rows=0, stream_kernel=0, zero_fill=0,
-                                         sweep=0, sweep_slack=0, deterministic=0)
+                                         sweep=0, sweep_slack=0, deterministic=0, pack_ids=0)
         _lib.set_tuning(column_phases=8)
         assert _lib.get_tuning()["column_phases"] == 8
         _lib.set_tuning(groups_per_chunk=32)      # others keep their values

@@ -1,0 +1,179 @@
+"""Packed column ids of a prepared graph (gnna_prepare_graph + gnna_tuning.pack_ids): the sliced schedule reads a
+plan-owned copy of the ids in the order it consumes them.  Same parity bars as test_parity_gpu.py (X = ones exact --
+reference unitest.py:27,54-63 -- and random inputs within 1e-4 * scale of the fp64 CSR formula), every case checks
+through gnna_runtime_counters that the packed path really ran."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib, graph
+from util import assert_close_f64, dev, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def counters():
+    c = _lib.runtime_counters()
+    return c["pack_builds"], c["packed_launches"]
+
+
+def check_all_modes(g, X, pp, p2n, ps, Xd, rp, ci, deg, ppd, p2nd, what):
+    Xn, cin, rpn, degn = X.numpy(), g.column_index.numpy(), g.row_pointers.numpy(), g.degrees.numpy()
+    ys = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    yg = _lib.agg_gcn(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    yi = _lib.agg_gin(Xd, rp, ci, 0.5, ppd, p2nd, ps, 32, 4)
+    assert_close_f64(ys.cpu().numpy(), oracle.csr_f64(0, Xn, rpn, cin), what=what + " sag")
+    assert_close_f64(yg.cpu().numpy(), oracle.csr_f64(1, Xn, rpn, cin, degn), what=what + " gcn",
+                     scale=oracle.csr_f64(1, np.abs(Xn), rpn, cin, degn))
+    assert_close_f64(yi.cpu().numpy(), oracle.csr_f64(2, Xn, rpn, cin, None, 0.5), what=what + " gin")
+    assert_close_f64(ys.cpu().numpy(), oracle.sag(Xn, cin, pp.numpy(), p2n.numpy()), what=what + " sag vs oracle")
+
+
+@pytest.mark.parametrize("dim", [4, 7, 16, 41, 64, 100, 128, 300])
+@pytest.mark.parametrize("phases,ps,gpc", [(2, 16, 16), (5, 3, 16), (8, 64, 16), (32, 32, 16), (8, 100, 4), (3, 1, 5)])
+def test_packed_ids_match_the_oracle(dim, phases, ps, gpc):
+    g, X, pp, p2n = make_case(3000, 200000, dim, ps, seed=dim * 3 + phases, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    _lib.reset_tuning()
+    _lib.set_tuning(column_phases=phases, groups_per_chunk=gpc, deterministic=0, sweep=0, stream_kernel=0)
+    try:
+        for prescale in (1, 2):        # pre-scaled and per-edge GCN forms
+            _lib.set_tuning(gcn_prescale=prescale)
+            got = _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, ps, [dim])
+            assert got[dim] == phases
+            b0, l0 = counters()
+            check_all_modes(g, X, pp, p2n, ps, Xd, rp, ci, deg, ppd, p2nd, f"packed dim={dim} phases={phases} ps={ps}")
+            b1, l1 = counters()
+            assert l1 - l0 == 3, "the packed path did not run"
+            assert b1 == b0, "a copy was built inside an aggregation although prepare had the width"
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
+
+
+def test_packed_ones_is_exact_and_off_switch():
+    g, X, pp, p2n = make_case(5000, 600000, 64, 32, seed=3, kind="powerlaw", x="ones")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    want = (g.row_pointers[1:] - g.row_pointers[:-1]).to(torch.float32)[:, None].expand(-1, 64)
+    _lib.reset_tuning()
+    try:
+        for phases in (2, 8, 16, 32):
+            _lib.set_tuning(column_phases=phases)
+            _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 32, [64])
+            b0, l0 = counters()
+            y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4).cpu()
+            assert counters()[1] == l0 + 1
+            assert torch.equal(y, want), phases
+        _lib.set_tuning(pack_ids=2)
+        l0 = counters()[1]
+        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4).cpu()
+        assert counters()[1] == l0 and torch.equal(y, want)
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
+
+
+def test_more_phase_counts_than_copies_and_release():
+    """Three copies per graph: a fourth phase count replaces the least recently used one (built at first use, outside
+    captures); after the release the ids are read from column_index again."""
+    g, X, pp, p2n = make_case(4000, 300000, 64, 16, seed=9, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+    _lib.reset_tuning()
+    try:
+        _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 16, [])
+        b0, l0 = counters()
+        for rep in range(2):
+            for phases in (2, 4, 8, 16, 32):
+                _lib.set_tuning(column_phases=phases)
+                y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+                assert_close_f64(y.cpu().numpy(), ref, what=f"phases {phases}")
+        b1, l1 = counters()
+        assert l1 - l0 == 10 and b1 - b0 == 10          # five phase counts cycle through three slots
+        _lib.release_graph(ci)
+        l0 = counters()[1]
+        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+        assert counters()[1] == l0
+        assert_close_f64(y.cpu().numpy(), ref, what="after release")
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
+
+
+def test_packed_non_canonical_rectangular_accumulate_and_deterministic():
+    # shuffled groups (part2Node not monotone), a destination shard with its own source range, accumulate, and the
+    # ordered schedule: all read the same packed copies
+    g, X, pp, p2n = make_case(1500, 90000, 64, 8, seed=11, kind="powerlaw")
+    P = p2n.numel()
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(5))
+    beg, end = pp[:-1][perm], pp[1:][perm]
+    ci_new = torch.cat([g.column_index[int(b):int(e)] for b, e in zip(beg.tolist(), end.tolist())]).contiguous()
+    pp_new = torch.zeros(P + 1, dtype=torch.int32)
+    pp_new[1:] = torch.cumsum((end - beg).to(torch.int64), 0).to(torch.int32)
+    p2n_new = p2n[perm].contiguous()
+    Xd, cid, ppd, p2nd = dev(X, ci_new, pp_new, p2n_new)
+    ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+    _lib.reset_tuning()
+    _lib.set_tuning(column_phases=4)
+    try:
+        _lib.prepare_graph(cid, ppd, p2nd, g.num_nodes, g.num_nodes, 8, [64])
+        l0 = counters()[1]
+        y = _lib.sag(Xd, None, cid, None, ppd, p2nd, 8, 32, 4)
+        assert counters()[1] == l0 + 1
+        assert_close_f64(y.cpu().numpy(), ref, what="packed, shuffled groups")
+    finally:
+        _lib.release_graph(cid)
+    n_out, n_in = 1200, 9000
+    rp, ci = graph.powerlaw_shard(n_out, n_in, 150000, 4000, seed=3)
+    pp2, p2n2 = _lib.build_part(16, rp)
+    X2 = torch.randn(n_in, 64, generator=torch.Generator().manual_seed(8))
+    X2d, ci2d, pp2d, p2n2d = dev(X2, ci, pp2, p2n2)
+    ref2 = oracle.csr_f64(0, X2.numpy(), rp.numpy(), ci.numpy())
+    try:
+        _lib.set_tuning(column_phases=8)
+        _lib.prepare_graph(ci2d, pp2d, p2n2d, n_in, n_out, 16, [64])
+        l0 = counters()[1]
+        y = _lib.agg_rect(0, X2d, ci2d, pp2d, p2n2d, n_out, 16)
+        y2 = _lib.agg_rect(0, X2d, ci2d, pp2d, p2n2d, n_out, 16, out=y.clone(), accumulate=True)
+        _lib.set_tuning(deterministic=1)
+        y3 = _lib.agg_rect(0, X2d, ci2d, pp2d, p2n2d, n_out, 16)
+        y4 = _lib.agg_rect(0, X2d, ci2d, pp2d, p2n2d, n_out, 16)
+        assert counters()[1] == l0 + 4
+        assert_close_f64(y.cpu().numpy(), ref2, what="packed rect")
+        assert_close_f64(y2.cpu().numpy(), 2 * ref2, what="packed rect accumulate")
+        assert_close_f64(y3.cpu().numpy(), ref2, what="packed rect deterministic")
+        assert torch.equal(y3, y4)
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci2d)
+
+
+def test_packed_in_a_captured_graph():
+    g, X, pp, p2n = make_case(6000, 700000, 64, 32, seed=21, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    out = torch.empty_like(Xd)
+    _lib.reset_tuning()
+    _lib.set_tuning(column_phases=8)
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 32, [64])
+            _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4, out=out)      # warm-up (scratch)
+            side.synchronize()
+            before = _lib.runtime_counters()
+            graph_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_, stream=side):
+                _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4, out=out)
+        after = _lib.runtime_counters()
+        assert after["packed_launches"] == before["packed_launches"] + 1
+        for k in ("plan_builds", "pack_builds", "launch_syncs", "launch_frees", "launch_mallocs"):
+            assert after[k] == before[k], k
+        out.fill_(float("nan"))
+        graph_.replay()
+        torch.cuda.synchronize()
+        assert_close_f64(out.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                         what="packed replay")
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
