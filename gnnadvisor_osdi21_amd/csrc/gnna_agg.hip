@@ -919,7 +919,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         }
         // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
         // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
-        if (cnt && plan.handle && tune.pack_ids != 2 && mode != MODE_SDDMM) {
+        if (cnt && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && mode != MODE_SDDMM) {
             rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, &a.ids_packed, &a.item_off);
             if (rc != GNNA_OK) return rc;
             if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
@@ -1082,7 +1082,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
                                   t.nonlocal_ids == 1);
         }
         if (phases_out) phases_out[i] = std::max(1, B);
-        if (B >= 2 && t.pack_ids != 2 && plan.handle && t.sweep != 1) {
+        if (B >= 2 && t.pack_ids != 2 && plan.handle && t.sweep != 1) {   // (the plan is pinned here)
             const int32_t *ids = nullptr; const uint32_t *off = nullptr;
             rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, &ids, &off);
             if (rc != GNNA_OK) return rc;

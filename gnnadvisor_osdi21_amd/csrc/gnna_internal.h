@@ -79,7 +79,8 @@ struct SlicePlan {
     int S = 0;                       // fine slices of the plan
     uint32_t slice_rows = 0;         // source rows per fine slice
     SlicePlanStats stats;
-    void *handle = nullptr;          // the plan itself when it is pinned (get_packed_ids), else null
+    void *handle = nullptr;          // the plan itself (get_packed_ids)
+    bool pinned = false;             // made by gnna_prepare_graph (the caller promised not to change the graph)
 };
 // Fine slicing of `num_in_rows` source rows: S = kMaxSlices slices of ceil(num_in_rows / S) rows.
 inline uint32_t slice_rows_for(int64_t num_in_rows)
@@ -95,7 +96,8 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
                    const int32_t *part2Node, int64_t num_parts, int64_t num_in_rows, bool want_stats, bool pin,
                    SlicePlan *out);
 void drop_slice_plans();
-// Packed column ids of a pinned plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.
+// Packed column ids of a plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.  The
+// caller decides whether the plan may have them (pinned, or gnna_tuning.pack_ids = 1).
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build,
                    const int32_t **ids, const uint32_t **item_off);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.

@@ -848,6 +848,12 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
             pl->bytes = bytes;
         }
         if (!pl->ready) (void)hipEventCreateWithFlags(&pl->ready, hipEventDisableTiming);
+        // packed ids of the partition this plan described before (pack_ids = 1 on an automatic plan): gone with it
+        for (auto &pk : pl->packed) {
+            if (pk.ids) { (void)hipFree(pk.ids); count_event(CTR_LAUNCH_FREES); }
+            if (pk.ready) (void)hipEventDestroy(pk.ready);
+        }
+        pl->packed.clear();
         pl->col = column_index; pl->pp = part_pointers; pl->p2n = part2Node; pl->P = num_parts; pl->slice_rows = slice_rows;
         pl->device = dev; pl->have_stats = false; pl->made_on = stream; pl->last_stream = stream; pl->multi_stream = false;
         pl->uses = 0;
@@ -883,7 +889,8 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
     if (pin) hit->pinned = true;
     hit->stamp = ++g_plan_clock;
     out->cnt = hit->cnt;
-    out->handle = hit->pinned ? hit : nullptr;
+    out->handle = hit;
+    out->pinned = hit->pinned;
     out->S = S;
     out->slice_rows = slice_rows;
     out->stats.valid = hit->have_stats;
@@ -918,7 +925,7 @@ int release_slice_plans(const void *column_index)
 
 void drop_slice_plans() { (void)release_slice_plans(nullptr); }
 
-// Packed ids of a pinned plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
+// Packed ids of a plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
 // capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
 // plan that already holds kMaxPacked is replaced after a device synchronisation).  *ids stays null when there is none.
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build,
@@ -929,7 +936,7 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     Plan *pl = nullptr;
     for (Plan *q : g_plans) if (q == plan_handle) { pl = q; break; }
-    if (!pl || !pl->pinned || !pl->cnt) return GNNA_OK;
+    if (!pl || !pl->cnt) return GNNA_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
     for (auto &pk : pl->packed) {

@@ -149,6 +149,31 @@ def test_packed_non_canonical_rectangular_accumulate_and_deterministic():
         _lib.release_graph(ci2d)
 
 
+def test_pack_ids_1_packs_unprepared_graphs_too_and_evicted_plans_drop_their_copies():
+    """pack_ids = 1: the caller's promise covers every graph -- automatic plans get copies at first use; 40 graphs through
+    the 32 automatic plans: an evicted plan's copies go with it and every result stays right."""
+    _lib.reset_tuning()
+    _lib.release_graph(None)
+    _lib.set_tuning(column_phases=4, pack_ids=1)
+    keep = []
+    try:
+        for i in range(40):
+            g, X, pp, p2n = make_case(1200, 60000, 32, 8, seed=100 + i, kind="powerlaw")
+            Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+            keep.append((g, X, Xd, rp, ci, deg, ppd, p2nd))
+        for rep in range(2):
+            b0, l0 = counters()
+            for g, X, Xd, rp, ci, deg, ppd, p2nd in keep:
+                y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 8, 32, 4)
+                assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                                 what="pack_ids=1, unprepared")
+            b1, l1 = counters()
+            assert l1 - l0 == 40 and b1 - b0 == 40       # 40 graphs cycle through 32 plans: every call rebuilds
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(None)
+
+
 def test_packed_in_a_captured_graph():
     g, X, pp, p2n = make_case(6000, 700000, 64, 32, seed=21, kind="powerlaw")
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
