@@ -138,6 +138,8 @@ int gather_ceiling_launch(const float *X, const int32_t *ids, int64_t n, int dim
     else if (dim == 128 && U == 8) GO(32, 8);
     else if (dim == 32 && U == 4) GO(8, 4);
     else if (dim == 32 && U == 8) GO(8, 8);
+    else if (dim == 16 && U == 4) GO(4, 4);
+    else if (dim == 16 && U == 2) GO(4, 2);
     else return -2;
 #undef GO
     return hipGetLastError() == hipSuccess ? 0 : -3;

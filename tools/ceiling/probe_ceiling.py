@@ -94,7 +94,7 @@ for B in phases:
         for U in Us:
             row["floor_ms"][f"seg{seg}_U{U}"] = time_launch(ids, seg, U)
     row["persistent_16_waves_per_cu"] = {}
-    for cap in hub_caps:
+    for cap in (hub_caps if D == 64 else []):
         lds = max(cap * D * 4, 96 * 1024)                  # >= 96 KB: one workgroup per CU whatever the cache size
         if cap == 0:
             row["persistent_16_waves_per_cu"]["no_cache"] = {f"seg{seg}": time_hub(ids, seg, 4, 0, lds) for seg in segs}
