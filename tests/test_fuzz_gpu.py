@@ -44,17 +44,32 @@ def test_rect_accumulate_random():
             pp_l, p2n_l = _lib.build_part(ps, rp_l); pp_r, p2n_r = _lib.build_part(ps, rp_r)
             Xd = X.cuda(); degd = g.degrees.cuda()
             out = torch.full((hi - lo, D), float("nan"), device="cuda")
+            cil, ppl, p2nl = ci_l.cuda(), pp_l.cuda(), p2n_l.cuda()
+            cir, ppr, p2nr = ci_r.cuda(), pp_r.cuda(), p2n_r.cuda()
             _rand_tuning(rng)
-            _lib.agg_rect(mode, Xd[lo:hi].contiguous(), ci_l.cuda(), pp_l.cuda(), p2n_l.cuda(), hi - lo, ps,
+            # half of the cases go through the graph lifecycle (pinned plan, packed column ids where the schedule is sliced)
+            prepared = bool(rng.integers(0, 2))
+            if prepared:
+                _lib.set_tuning(pack_ids=int(rng.choice([0, 1, 2])))
+                if p2nl.numel():
+                    _lib.prepare_graph(cil, ppl, p2nl, hi - lo, hi - lo, ps, [D])
+                if p2nr.numel():
+                    _lib.prepare_graph(cir, ppr, p2nr, n, hi - lo, ps, [D] if rng.integers(0, 2) else [])
+            _lib.agg_rect(mode, Xd[lo:hi].contiguous(), cil, ppl, p2nl, hi - lo, ps,
                           degrees_out=degd[lo:hi].contiguous(), degrees_in=degd[lo:hi].contiguous(), epsilon=eps, out=out)
+            tune_keep = dict(pack_ids=_lib.get_tuning()["pack_ids"])
             _rand_tuning(rng)
+            _lib.set_tuning(**tune_keep)
             K = int(rng.choice([0, 0, 1, 2, 3, 5, 16]))       # 0: one call; else one call per source window
             for w in range(max(1, K)):
-                _lib.agg_rect(mode, Xd, ci_r.cuda(), pp_r.cuda(), p2n_r.cuda(), hi - lo, ps,
+                _lib.agg_rect(mode, Xd, cir, ppr, p2nr, hi - lo, ps,
                               degrees_out=degd[lo:hi].contiguous(), degrees_in=degd, epsilon=eps, out=out,
                               accumulate=True, windows=(K, w, w + 1) if K else None)
             assert_close_f64(out.cpu().numpy(), ref, scale=scale,
-                             what=f"case {k}: n={n} e={e} D={D} ps={ps} mode={mode} K={K} [{lo},{hi}) {_lib.get_tuning()}")
+                             what=f"case {k}: n={n} e={e} D={D} ps={ps} mode={mode} K={K} [{lo},{hi}) prepared={prepared} {_lib.get_tuning()}")
+            if prepared:
+                _lib.release_graph(cil)
+                _lib.release_graph(cir)
     finally:
         _lib.reset_tuning()
 
