@@ -950,12 +950,21 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     if (!may_build || cap != hipStreamCaptureStatusNone) return GNNA_OK;
     const int64_t num_chunks = (pl->P + G - 1) / G;
     const int64_t items = num_chunks * B;
-    // nnz: the last part pointer (one 4-byte read; builds are rare)
-    int32_t nnz = 0;
-    hipError_t e = hipMemcpyAsync(&nnz, static_cast<const int32_t *>(pl->pp) + pl->P, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids (edge count): %s", hipGetErrorString(e));
-    if (nnz <= 0) return GNNA_OK;
+    // nnz: from the counting pass's statistics (every prepared plan has them); a plan counted without statistics (forced
+    // phase count, pack_ids = 1) reads the last part pointer instead -- one 4-byte copy and a stream synchronisation
+    int64_t nnz = 0;
+    hipError_t e = hipSuccess;
+    if (pl->have_stats) {
+        nnz = (int64_t)pl->stats.edges;
+    } else {
+        int32_t last = 0;
+        e = hipMemcpyAsync(&last, static_cast<const int32_t *>(pl->pp) + pl->P, sizeof(int32_t), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        count_event(CTR_LAUNCH_SYNCS);
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids (edge count): %s", hipGetErrorString(e));
+        nnz = last;
+    }
+    if (nnz <= 0 || nnz > 0x7fffffffLL) return GNNA_OK;
     Plan::Packed *slot = nullptr;
     if ((int)pl->packed.size() < kMaxPacked) {
         pl->packed.emplace_back();
