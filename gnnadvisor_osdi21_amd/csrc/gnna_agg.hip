@@ -884,6 +884,11 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;
             w.dynamic = tune.xcd_remap != 0;      // (experiments: XCD=0 selects the fixed shares per wavefront)   // (experiments: BPC = 1 / 2 workgroups per CU)
             w.plain_ok = !accumulate_into_out; w.eps = p.eps;
+            if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && w.dynamic) {
+                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, &w.ids_packed, &w.item_off);
+                if (rc != GNNA_OK) return rc;
+                if (w.ids_packed) count_event(CTR_PACKED_LAUNCHES);
+            }
             t_last_phases = Bs;
             t_last_launches = 1;
             rc = launch_sweep(ds, w, stream);

@@ -145,6 +145,7 @@ struct SweepLaunch {
     bool dynamic = true;      // item pool with chunk locks (false: fixed share of the groups per wavefront)
     bool plain_ok;
     float eps;
+    const int32_t *ids_packed = nullptr; const uint32_t *item_off = nullptr;   // packed ids for (B, 64 groups per chunk)
 };
 bool sweep_supports(int mode, int dim, size_t x_bytes);
 int sweep_acc_rows(int dim, int wgs_per_cu);   // destination rows a workgroup's LDS accumulators hold at this width

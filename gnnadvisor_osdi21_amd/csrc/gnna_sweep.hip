@@ -99,6 +99,11 @@ struct SweepParams {
     int32_t slack;             // a workgroup starts step t once every workgroup of its XCD has finished step t - slack
                                // (1 = strict barrier); >= 1000: no synchronisation
     float eps;
+    // packed column ids of a prepared graph for (B, 64 groups per chunk) -- see gnna_stream.hip -- or null.  With them the
+    // sets start at multiples of 64 groups, so that a set's chunks are the global chunks the copy is laid out by.
+    const int32_t *ids_packed;
+    const uint32_t *item_off;
+    int64_t num_chunks;        // ceil(P / 64)
 };
 
 // First index g in [0, P] with pp[g] >= target (pp non-decreasing, pp[P] >= target), searched 64 ways per round
@@ -178,7 +183,8 @@ sweep_kernel(const SweepParams p)
             const int64_t i = set + wib;
             // (nnz < 2^31 and sets < 2^31: the product fits 64 bits)
             const int64_t target = i >= num_sets ? nnz : (nnz * i) / num_sets;
-            const int64_t g = i <= 0 ? 0 : (i >= num_sets ? p.P : lower_bound64(p.pp, p.P, target, lane));
+            int64_t g = i <= 0 ? 0 : (i >= num_sets ? p.P : lower_bound64(p.pp, p.P, target, lane));
+            if (p.ids_packed && g < p.P) g &= ~(int64_t)(kWave - 1);
             if (lane == 0) s_g[wib] = g;
         }
         if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
@@ -280,6 +286,9 @@ sweep_kernel(const SweepParams p)
                     if (f_lo > 0) cum_lo = __builtin_nontemporal_load(p.cnt + (size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane));
                     if (f_hi < p.S) cum_hi = __builtin_nontemporal_load(p.cnt + (size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane));
                 }
+                const bool packed = dyn && p.ids_packed != nullptr;
+                const uint32_t item_base = packed ? p.item_off[(size_t)t * (size_t)p.num_chunks + (size_t)(g0 >> 6)] : 0u;
+                const int32_t *__restrict__ ids = packed ? p.ids_packed : p.col;
                 const int len = pb > pa ? pb - pa : 0;
                 const int beg = cum_lo < len ? cum_lo : len;
                 int end = cum_hi < len ? cum_hi : len;
@@ -292,7 +301,7 @@ sweep_kernel(const SweepParams p)
                     const bool seg_start = gl && (lane == 0 || my_row != up_row || !canonical);
                     const unsigned long long SS = __ballot(seg_start);
                     const int up_end = __shfl_up(pa + end, 1), up_n = __shfl_up(n_own, 1);
-                    const bool cont = n_own > 0 && !seg_start && up_n > 0 && up_end == pa + beg;
+                    const bool cont = n_own > 0 && !seg_start && up_n > 0 && (packed || up_end == pa + beg);
                     const unsigned long long NE = __ballot(n_own > 0 && !cont);        // piece heads
                     const int n_cum = wave_inclusive_scan(n_own);
                     const unsigned long long heads_above = NE & above;
@@ -309,7 +318,7 @@ sweep_kernel(const SweepParams p)
                     const int rank = __popcll(NE & (upto >> 1));
                     const int Rn = __popcll(NE);
                     const int dstl = (n > 0 ? rank : 63) << 2;
-                    const int c_pbeg = __builtin_amdgcn_ds_permute(dstl, pa + beg);
+                    const int c_pbeg = __builtin_amdgcn_ds_permute(dstl, packed ? (int)item_base + (n_cum - n_own) : pa + beg);
                     const int t_n = __builtin_amdgcn_ds_permute(dstl, n);
                     const int c_n = lane < Rn ? t_n : 0;
                     const int c_meta = __builtin_amdgcn_ds_permute(dstl, ((over ? my_row : aslot) << 3) | edge | (last_in_seg ? 2 : 0) | over);
@@ -351,19 +360,19 @@ sweep_kernel(const SweepParams p)
                                     typedef i32x4 i32x4u __attribute__((aligned(4)));
 #pragma unroll
                                     for (int s4 = 0; s4 < RPI; s4 += 4) {
-                                        const i32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(p.col + e_j + s4));
+                                        const i32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(ids + e_j + s4));
                                         o[s4] = (uint32_t)tt[0]; o[s4 + 1] = (uint32_t)tt[1]; o[s4 + 2] = (uint32_t)tt[2]; o[s4 + 3] = (uint32_t)tt[3];
                                     }
                                 } else {
 #pragma unroll
-                                    for (int q = 0; q < RPI; q++) o[q] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + q);
+                                    for (int q = 0; q < RPI; q++) o[q] = (uint32_t)__builtin_nontemporal_load(ids + e_j + q);
                                 }
                             } else {
-                                const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(p.col + e_j) : 0u;
+                                const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(ids + e_j) : 0u;
 #pragma unroll
                                 for (int q = 0; q < RPI; q++) {
                                     o[q] = first;
-                                    if (q > 0 && q < v_j) o[q] = (uint32_t)__builtin_nontemporal_load(p.col + e_j + q);
+                                    if (q > 0 && q < v_j) o[q] = (uint32_t)__builtin_nontemporal_load(ids + e_j + q);
                                 }
                             }
 #pragma unroll
@@ -536,6 +545,7 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     p.flag = a.flag; p.seq = a.seq; p.trust = a.trust; p.sync = a.sync;
     p.P = a.P; p.D = a.D; p.ldx = a.ldx; p.S = a.S; p.B = a.B; p.plain_ok = a.plain_ok ? 1 : 0; p.eps = a.eps;
     p.slack = a.slack > 0 ? a.slack : 2;
+    p.ids_packed = a.ids_packed; p.item_off = a.item_off; p.num_chunks = (a.P + kWave - 1) / kWave;
     p.dynamic = a.dynamic ? 1 : 0;
     int lpr = 4;
     const int pieces = (a.D + 3) / 4;

@@ -101,6 +101,33 @@ def test_sweep_long_rows_crossing_the_chunks_of_a_wavefront_share_are_exact(dyna
             assert s.launches() == 4
 
 
+@pytest.mark.parametrize("dim,ps,phases", [(64, 32, 8), (16, 8, 3), (128, 64, 16), (41, 16, 32), (100, 3, 5)])
+def test_sweep_reads_the_packed_ids_of_a_prepared_graph(dim, ps, phases):
+    """A prepared graph's packed column ids (gnna_tuning.pack_ids) serve the sweep kernel too: its sets then start at
+    multiples of 64 groups, so that a set's chunks are the chunks the copy is laid out by."""
+    g, X, pp, p2n = make_case(4000, 400000, dim, ps, seed=dim + phases, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    try:
+        with sweep_forced(phases, gcn_prescale=1) as s:
+            _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, ps, [dim])
+            before = _lib.runtime_counters()["packed_launches"]
+            check_modes(g, X, pp, p2n, ps, what=f"sweep packed dim={dim} ps={ps} phases={phases}")
+            # check_modes moves its own copies of the index tensors to the device: run the prepared tensors as well
+            ys = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+            assert _lib.runtime_counters()["packed_launches"] == before + 1
+            assert s.launches() == 4
+        assert_close_f64(ys.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                         what="sweep packed sag")
+        ones = torch.ones_like(Xd)
+        with sweep_forced(phases):
+            y1 = _lib.sag(ones, rp, ci, deg, ppd, p2nd, ps, 32, 4).cpu()
+        want = (g.row_pointers[1:] - g.row_pointers[:-1]).to(torch.float32)[:, None].expand(-1, dim)
+        assert torch.equal(y1, want)
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
+
+
 def test_sweep_rows_beyond_the_accumulators_take_the_atomic_path():
     """Low-degree rows: a set (1/256 of the edges with one set per workgroup) spans more destination rows than the
     CU's LDS holds (256 rows of 128 floats, 512 of 64) -- the rows beyond are flushed per slice with atomics."""

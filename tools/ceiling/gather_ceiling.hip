@@ -105,6 +105,48 @@ __global__ void __launch_bounds__(1024) gather_ceiling_hub(const float *__restri
     reinterpret_cast<f32x4 *>(out)[((int64_t)blockIdx.x * 16 + wib) * 64 + lane] = acc;
 }
 
+// Which XCD does block b run on?  out[b] = XCC_ID hardware register of the block's first wavefront (the library's
+// "block b lands on XCD b % 8" is a locality assumption; this checks it on the device at hand).
+__global__ void xcc_of_block(int32_t *__restrict__ out)
+{
+    if (threadIdx.x == 0) {
+        uint32_t v;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+        out[blockIdx.x] = (int32_t)(v & 0xf);
+    }
+}
+
+extern "C" __attribute__((visibility("default")))
+int xcc_of_block_launch(int32_t *out, int blocks, int threads)
+{
+    hipLaunchKernelGGL(xcc_of_block, dim3(blocks), dim3(threads), 0, 0, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// How many 256-byte row flushes per second does the chip take?  Every wavefront makes `per_wave` flushes of one
+// 64-float row each to pseudo-random rows of Y[rows][64]; how: 0 float atomics (what the sliced schedule's flush does),
+// 1 plain stores, 2 plain read-add-write.
+__global__ void __launch_bounds__(256) flush_rate(float *__restrict__ Y, int64_t rows, int per_wave, int how)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t h = wave * 0x9E3779B97F4A7C15ull + 12345;
+    for (int k = 0; k < per_wave; k++) {
+        h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+        float *dst = Y + (h % (uint64_t)rows) * 64 + lane;
+        if (how == 0) unsafeAtomicAdd(dst, 1.0f);
+        else if (how == 1) *dst = 1.0f;
+        else *dst = *dst + 1.0f;
+    }
+}
+
+extern "C" __attribute__((visibility("default")))
+int flush_rate_launch(float *Y, int64_t rows, int64_t waves, int per_wave, int how)
+{
+    hipLaunchKernelGGL(flush_rate, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, Y, rows, per_wave, how);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" __attribute__((visibility("default")))
 int gather_ceiling_hub_launch(const float *X, const int32_t *ids, int64_t n, int dim, int seg, int U, float *out,
                               const float *hub, int hub_rows, int lds_bytes, int blocks)

@@ -40,9 +40,11 @@ def exact():
 
 for B in phases:
     row = dict(cfg=cfg, D=D, B=B)
+    sweep = int(os.environ.get("PROBE_SWEEP", "0"))      # 1: the sweep kernel instead of the streaming kernel
     for name, pk in (("ids_from_column_index", 2), ("packed_ids", 1)):
         _lib.reset_tuning()
-        _lib.set_tuning(column_phases=B, pack_ids=pk)
+        _lib.set_tuning(column_phases=B, pack_ids=pk, sweep=sweep, sweep_slack=int(os.environ.get("PROBE_SLACK", "0")),
+                        blocks_per_cu=int(os.environ.get("PROBE_WGS", "0")))
         _lib.prepare_graph(g.column_index, ppd, p2nd, g.num_nodes, g.num_nodes, ps, [D])
         before = _lib.runtime_counters()["packed_launches"]
         row[name] = timeit()
