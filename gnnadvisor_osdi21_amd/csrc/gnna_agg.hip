@@ -885,7 +885,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             w.dynamic = tune.xcd_remap != 0;      // (experiments: XCD=0 selects the fixed shares per wavefront)   // (experiments: BPC = 1 / 2 workgroups per CU)
             w.plain_ok = !accumulate_into_out; w.eps = p.eps;
             if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && w.dynamic) {
-                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, &w.ids_packed, &w.item_off);
+                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &w.ids_packed, &w.item_off);
                 if (rc != GNNA_OK) return rc;
                 if (w.ids_packed) count_event(CTR_PACKED_LAUNCHES);
             }
@@ -925,7 +925,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
         // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
         if (cnt && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && mode != MODE_SDDMM) {
-            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, &a.ids_packed, &a.item_off);
+            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off);
             if (rc != GNNA_OK) return rc;
             if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
         }
@@ -1089,7 +1089,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
         if (phases_out) phases_out[i] = std::max(1, B);
         if (B >= 2 && t.pack_ids != 2 && plan.handle && t.sweep != 1) {   // (the plan is pinned here)
             const int32_t *ids = nullptr; const uint32_t *off = nullptr;
-            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, &ids, &off);
+            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
             if (rc != GNNA_OK) return rc;
         }
         if (t.deterministic == 1 && dim >= 4) {   // the deterministic schedule parks partial rows in the stream's scratch (slot 2)

@@ -98,7 +98,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
 void drop_slice_plans();
 // Packed column ids of a plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.  The
 // caller decides whether the plan may have them (pinned, or gnna_tuning.pack_ids = 1).
-int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build,
+int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
                    const int32_t **ids, const uint32_t **item_off);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
 int release_slice_plans(const void *column_index);

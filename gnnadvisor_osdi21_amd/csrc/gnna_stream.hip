@@ -733,11 +733,14 @@ struct Plan {
         uint32_t *item_off = nullptr;
         hipEvent_t ready = nullptr;
         hipStream_t made_on = nullptr;
-        uint64_t stamp = 0;
+        uint64_t stamp = 0;              // value of the plan's lookup counter at the last use
     };
     std::vector<Packed> packed;
+    uint64_t pack_lookups = 0;
 };
-constexpr int kMaxPacked = 3;   // copies per plan (a GCN / GIN model aggregates at two or three widths)
+constexpr int kMaxPacked = 4;   // copies per plan (a GCN / GIN model aggregates at two or three widths)
+constexpr uint64_t kPackedKeep = 16;   // a copy looked up within the plan's last 16 lookups is not replaced at a launch (no build storms
+                                       // when more phase counts than copies are in use in turn: the extra ones read column_index)
 constexpr int kMaxPlans = 32;   // unpinned plans kept (31 bytes per neighbor-group each; Reddit-like: 59 MB): small next to
                                 // 288 GB, and a working set of graphs larger than the table would recount on every call
 std::vector<Plan *> g_plans;    // pinned plans are unbounded
@@ -927,8 +930,9 @@ void drop_slice_plans() { (void)release_slice_plans(nullptr); }
 
 // Packed ids of a plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
 // capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
-// plan that already holds kMaxPacked is replaced after a device synchronisation).  *ids stays null when there is none.
-int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build,
+// plan that already holds kMaxPacked is replaced after a device synchronisation -- at a launch only if it has not been
+// used for a while, in gnna_prepare_graph (force) always).  *ids stays null when there is none.
+int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
                    const int32_t **ids, const uint32_t **item_off)
 {
     *ids = nullptr; *item_off = nullptr;
@@ -939,10 +943,11 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     if (!pl || !pl->cnt) return GNNA_OK;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(stream, &cap);
+    pl->pack_lookups++;
     for (auto &pk : pl->packed) {
         if (pk.B == B && pk.G == G && pk.ids) {
             if (pk.made_on != stream && cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, pk.ready, 0);
-            pk.stamp = ++g_plan_clock;
+            pk.stamp = pl->pack_lookups;
             *ids = pk.ids; *item_off = pk.item_off;
             return GNNA_OK;
         }
@@ -971,6 +976,7 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         slot = &pl->packed.back();
     } else {
         for (auto &pk : pl->packed) if (!slot || pk.stamp < slot->stamp) slot = &pk;
+        if (!force && pl->pack_lookups - slot->stamp < kPackedKeep) return GNNA_OK;   // every copy is in recent use: none for this one
         (void)hipDeviceSynchronize();           // kernels of any stream may still read the copy that goes
         count_event(CTR_LAUNCH_SYNCS);
         if (slot->ids) { (void)hipFree(slot->ids); count_event(CTR_LAUNCH_FREES); }
@@ -986,7 +992,7 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         return GNNA_OK;                          // no memory for the copy: the ids are read from column_index
     }
     slot->item_off = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(slot->ids) + id_bytes);
-    slot->B = B; slot->G = G; slot->made_on = stream; slot->stamp = ++g_plan_clock;
+    slot->B = B; slot->G = G; slot->made_on = stream; slot->stamp = pl->pack_lookups;
     if (!slot->ready) (void)hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming);
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)ds->num_cus * 16));
     hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->pp),

@@ -75,8 +75,9 @@ def test_packed_ones_is_exact_and_off_switch():
 
 
 def test_more_phase_counts_than_copies_and_release():
-    """Three copies per graph: a fourth phase count replaces the least recently used one (built at first use, outside
-    captures); after the release the ids are read from column_index again."""
+    """Four copies per graph: a fifth phase count in turn with the others gets none (a copy in recent use is not replaced:
+    no build storm) and reads column_index; once the others have gone unused for a while it takes the oldest one's place;
+    after the release the ids are read from column_index again."""
     g, X, pp, p2n = make_case(4000, 300000, 64, 16, seed=9, kind="powerlaw")
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
@@ -90,7 +91,12 @@ def test_more_phase_counts_than_copies_and_release():
                 y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
                 assert_close_f64(y.cpu().numpy(), ref, what=f"phases {phases}")
         b1, l1 = counters()
-        assert l1 - l0 == 10 and b1 - b0 == 10          # five phase counts cycle through three slots
+        assert b1 - b0 == 4 and l1 - l0 == 8            # 32 phases ran without a copy, twice
+        for _ in range(20):                              # the other copies age ...
+            y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+        b2, l2 = counters()
+        assert b2 - b1 == 1 and l2 - l1 >= 8            # ... and 32 phases gets the oldest one's place
+        assert_close_f64(y.cpu().numpy(), ref, what="phases 32, packed")
         _lib.release_graph(ci)
         l0 = counters()[1]
         y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
