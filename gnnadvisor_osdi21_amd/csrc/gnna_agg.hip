@@ -83,9 +83,17 @@ struct AggParams {
 
 __global__ void __launch_bounds__(kBlock)
 prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restrict__ p2n,
-                const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate, int zero_fill)
+                const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate, int zero_fill,
+                const int32_t *__restrict__ chk_ids, int64_t chk_n, const unsigned long long *__restrict__ chk_sum,
+                int32_t *stale_flag)
 {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // packed ids of a prepared graph: does column_index still look like the array the copy was made from?  (1024 samples:
+    // catches a buffer that was rewritten, which is what happens when a promise of immutability is broken by accident)
+    if (chk_ids && blockIdx.x == 0 && threadIdx.x < kWave) {
+        const unsigned long long now = sample_checksum(chk_ids, chk_n, (int)threadIdx.x);
+        if (threadIdx.x == 0 && now != *chk_sum) *stale_flag = seq;
+    }
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (!zero_fill) {
@@ -749,6 +757,10 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     // prologue: zero-fill + validation.  `sparse_G` > 0: the streaming kernel is about to run a single pass with
     // `sparse_G` groups per work item and stores every row it owns, so only the other rows are cleared.
     const size_t n_floats = (size_t)num_nodes * (size_t)dim;
+    // set when the call reads packed ids: the (dense) prologue then compares a sample of column_index with the copy's
+    const unsigned long long *chk_sum = nullptr;
+    int64_t chk_n = 0;
+    int32_t *stale_flag = flag + kFlagSlots;          // the second ring, same slot
     auto run_prologue = [&](int sparse_G) -> int {
         const int validate = (num_parts > 0 && !tune.trust_canonical) ? 1 : 0;
         const int zero_fill = (accumulate_into_out || win_begin > 0) ? 0 : 1;
@@ -767,7 +779,8 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);
             blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
             hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
-                               part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill);
+                               part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill,
+                               chk_sum ? column_index : nullptr, chk_n, chk_sum, stale_flag);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
@@ -870,6 +883,12 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
                 Bs = 2;
                 while (Bs < S && x_bytes / Bs > ((size_t)2 << 20)) Bs <<= 1;
             }
+            const int32_t *sw_ids = nullptr; const uint32_t *sw_off = nullptr;
+            if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && tune.xcd_remap != 0) {
+                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &sw_ids, &sw_off, &chk_sum, &chk_n);
+                if (rc != GNNA_OK) return rc;
+                if (sw_ids) count_event(CTR_PACKED_LAUNCHES);
+            }
             rc = run_prologue(0);
             if (rc != GNNA_OK) return rc;
             uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * (kXcds * 16);
@@ -884,11 +903,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;
             w.dynamic = tune.xcd_remap != 0;      // (experiments: XCD=0 selects the fixed shares per wavefront)   // (experiments: BPC = 1 / 2 workgroups per CU)
             w.plain_ok = !accumulate_into_out; w.eps = p.eps;
-            if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && w.dynamic) {
-                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &w.ids_packed, &w.item_off);
-                if (rc != GNNA_OK) return rc;
-                if (w.ids_packed) count_event(CTR_PACKED_LAUNCHES);
-            }
+            w.ids_packed = sw_ids; w.item_off = sw_off; w.packed_stale = stale_flag;
             t_last_phases = Bs;
             t_last_launches = 1;
             rc = launch_sweep(ds, w, stream);
@@ -925,7 +940,9 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
         // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
         if (cnt && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && mode != MODE_SDDMM) {
-            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off);
+            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
+                                &chk_sum, &chk_n);
+            a.packed_stale = stale_flag;
             if (rc != GNNA_OK) return rc;
             if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
         }

@@ -151,6 +151,23 @@ __device__ __forceinline__ typename VecOf<4>::T fold_row(const typename VecOf<4>
     return r;
 }
 
+// Checksum of 1024 evenly spaced entries of an id array (one wavefront; every lane returns the sum): what a packed copy
+// of the ids remembers about the array it was made from, and what the prologue of a call compares again.
+__device__ __forceinline__ unsigned long long sample_checksum(const int32_t *__restrict__ ids, int64_t n, int lane)
+{
+    unsigned long long sum = 0;
+    if (n > 0) {
+#pragma unroll 4
+        for (int k = 0; k < 16; k++) {
+            const int i = k * 64 + lane;
+            const int64_t pos = (int64_t)(((unsigned long long)i * (unsigned long long)n) >> 10);
+            sum += (unsigned long long)(uint32_t)ids[pos] * (unsigned long long)(2 * i + 1);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    return sum;
+}
+
 }  // namespace gnna
 
 #endif  // GNNA_DEVICE_H_

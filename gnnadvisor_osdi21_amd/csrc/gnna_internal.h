@@ -41,7 +41,8 @@ struct CursorOwner {
 struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
-    int32_t *flags = nullptr;  // ring of kFlagSlots ints, zero-initialised
+    int32_t *flags = nullptr;  // two rings of kFlagSlots ints, zero-initialised: [slot] "partition is not canonical",
+                               // [kFlagSlots + slot] "the packed ids are stale" of the call with that sequence number
     unsigned long long *gap_lists = nullptr;   // ring of kGapSlots lists of kGapWords words
     uint32_t *sweep_sync = nullptr;  // ring of kSweepSyncSlots counter blocks for the sweep kernel's soft barrier
     std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
@@ -99,7 +100,8 @@ void drop_slice_plans();
 // Packed column ids of a plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.  The
 // caller decides whether the plan may have them (pinned, or gnna_tuning.pack_ids = 1).
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
-                   const int32_t **ids, const uint32_t **item_off);
+                   const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum = nullptr,
+                   int64_t *num_ids = nullptr);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
 int release_slice_plans(const void *column_index);
 // Number of phases of the sliced schedule from the statistics of the partition (gnna_agg.hip).
@@ -125,6 +127,7 @@ struct StreamLaunch {
     bool det = false;                              // deterministic schedule (ordered phase launches, no atomics)
     float *det_part = nullptr; int32_t *det_stamp = nullptr;   // [num_chunks][2][D] partial rows / [num_chunks][2] stamps
     const int32_t *ids_packed = nullptr; const uint32_t *item_off = nullptr;   // packed ids of a prepared graph for (B, G)
+    const int32_t *packed_stale = nullptr;   // *packed_stale == seq: column_index no longer matches the copy, read column_index
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
 
@@ -146,6 +149,7 @@ struct SweepLaunch {
     bool plain_ok;
     float eps;
     const int32_t *ids_packed = nullptr; const uint32_t *item_off = nullptr;   // packed ids for (B, 64 groups per chunk)
+    const int32_t *packed_stale = nullptr;
 };
 bool sweep_supports(int mode, int dim, size_t x_bytes);
 int sweep_acc_rows(int dim, int wgs_per_cu);   // destination rows a workgroup's LDS accumulators hold at this width

@@ -35,9 +35,9 @@ int get_device_state(DeviceState **out)
             if (e != hipSuccess)
                 return fail(GNNA_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
             s.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-            e = hipMalloc(reinterpret_cast<void **>(&s.flags), kFlagSlots * sizeof(int32_t));
+            e = hipMalloc(reinterpret_cast<void **>(&s.flags), 2 * kFlagSlots * sizeof(int32_t));
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(flags): %s", hipGetErrorString(e));
-            e = hipMemset(s.flags, 0, kFlagSlots * sizeof(int32_t));
+            e = hipMemset(s.flags, 0, 2 * kFlagSlots * sizeof(int32_t));
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMemset(flags): %s", hipGetErrorString(e));
             const size_t gap_bytes = (size_t)kGapSlots * kGapWords * sizeof(unsigned long long);
             e = hipMalloc(reinterpret_cast<void **>(&s.gap_lists), gap_bytes);

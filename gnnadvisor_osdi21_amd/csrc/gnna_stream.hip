@@ -102,6 +102,7 @@ struct StreamParams {
     // ids_packed[item_off[phase * num_chunks + chunk] ...], groups in order -- or null: ids are read from `col`
     const int32_t *ids_packed;
     const uint32_t *item_off;
+    const int32_t *packed_stale;   // *packed_stale == seq: the prologue found column_index changed since the copy was made
 };
 
 // ---- slice counts ---------------------------------------------------------------------------------
@@ -306,7 +307,7 @@ stream_kernel(const StreamParams p)
     int prev_row = -1, next_row = -1;
     if (g0 > 0) prev_row = p.p2n[g0 - 1];
     if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
-    const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr;
+    const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr && *p.packed_stale != p.seq;
     const uint32_t item_base = packed ? p.item_off[(size_t)phase * (size_t)p.num_chunks + (size_t)chunk] : 0u;
     const int32_t *__restrict__ ids = packed ? p.ids_packed : p.col;
 
@@ -709,6 +710,13 @@ item_pack_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp
     }
 }
 
+__global__ void __launch_bounds__(kWave)
+ids_checksum_kernel(const int32_t *__restrict__ col, int64_t n, unsigned long long *__restrict__ out)
+{
+    const unsigned long long v = sample_checksum(col, n, (int)threadIdx.x);
+    if (threadIdx.x == 0) *out = v;
+}
+
 // ---- plan cache -------------------------------------------------------------------------------------
 struct Plan {
     const void *col = nullptr, *pp = nullptr, *p2n = nullptr;
@@ -731,6 +739,8 @@ struct Plan {
         int B = 0, G = 0;
         int32_t *ids = nullptr;          // nnz ids, then (at item_off) B * num_chunks + 1 item starts
         uint32_t *item_off = nullptr;
+        unsigned long long *checksum = nullptr;   // sample_checksum of column_index when the copy was made
+        int64_t num_ids = 0;
         hipEvent_t ready = nullptr;
         hipStream_t made_on = nullptr;
         uint64_t stamp = 0;              // value of the plan's lookup counter at the last use
@@ -933,9 +943,11 @@ void drop_slice_plans() { (void)release_slice_plans(nullptr); }
 // plan that already holds kMaxPacked is replaced after a device synchronisation -- at a launch only if it has not been
 // used for a while, in gnna_prepare_graph (force) always).  *ids stays null when there is none.
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
-                   const int32_t **ids, const uint32_t **item_off)
+                   const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum, int64_t *num_ids)
 {
     *ids = nullptr; *item_off = nullptr;
+    if (checksum) *checksum = nullptr;
+    if (num_ids) *num_ids = 0;
     if (!plan_handle || B < 2 || G < 1) return GNNA_OK;
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     Plan *pl = nullptr;
@@ -949,6 +961,8 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
             if (pk.made_on != stream && cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, pk.ready, 0);
             pk.stamp = pl->pack_lookups;
             *ids = pk.ids; *item_off = pk.item_off;
+            if (checksum) *checksum = pk.checksum;
+            if (num_ids) *num_ids = pk.num_ids;
             return GNNA_OK;
         }
     }
@@ -983,7 +997,8 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         slot->ids = nullptr; slot->item_off = nullptr;
     }
     const size_t id_bytes = (((size_t)nnz * sizeof(int32_t)) + 255) & ~(size_t)255;
-    const size_t bytes = id_bytes + ((size_t)items + 1) * sizeof(uint32_t);
+    const size_t off_bytes = ((((size_t)items + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
+    const size_t bytes = id_bytes + off_bytes + 16;
     e = hipMalloc(reinterpret_cast<void **>(&slot->ids), bytes);
     count_event(CTR_LAUNCH_MALLOCS);
     if (e != hipSuccess) {
@@ -992,6 +1007,8 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         return GNNA_OK;                          // no memory for the copy: the ids are read from column_index
     }
     slot->item_off = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(slot->ids) + id_bytes);
+    slot->checksum = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(slot->ids) + id_bytes + off_bytes);
+    slot->num_ids = nnz;
     slot->B = B; slot->G = G; slot->made_on = stream; slot->stamp = pl->pack_lookups;
     if (!slot->ready) (void)hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming);
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)ds->num_cus * 16));
@@ -1000,11 +1017,14 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, stream, slot->item_off, items);
     hipLaunchKernelGGL(item_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col),
                        static_cast<const int32_t *>(pl->pp), pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off, slot->ids);
+    hipLaunchKernelGGL(ids_checksum_kernel, dim3(1), dim3(kWave), 0, stream, static_cast<const int32_t *>(pl->col), nnz, slot->checksum);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids launch: %s", hipGetErrorString(e));
     (void)hipEventRecord(slot->ready, stream);
     count_event(CTR_PACK_BUILDS);
     *ids = slot->ids; *item_off = slot->item_off;
+    if (checksum) *checksum = slot->checksum;
+    if (num_ids) *num_ids = slot->num_ids;
     return GNNA_OK;
 }
 
@@ -1032,7 +1052,8 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, 4) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
     p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
-    p.ids_packed = a.mode == MODE_SDDMM ? nullptr : a.ids_packed; p.item_off = a.item_off;
+    p.ids_packed = (a.mode == MODE_SDDMM || !a.packed_stale) ? nullptr : a.ids_packed; p.item_off = a.item_off;
+    p.packed_stale = a.packed_stale;
     if (a.det && a.mode != MODE_SDDMM) {
         // deterministic schedule: the phases are separate launches in order, each followed by the ordered sum of
         // the rows that chunks share

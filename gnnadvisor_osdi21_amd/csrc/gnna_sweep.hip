@@ -103,6 +103,7 @@ struct SweepParams {
     // sets start at multiples of 64 groups, so that a set's chunks are the global chunks the copy is laid out by.
     const int32_t *ids_packed;
     const uint32_t *item_off;
+    const int32_t *packed_stale;   // *packed_stale == seq: column_index changed since the copy was made, read column_index
     int64_t num_chunks;        // ceil(P / 64)
 };
 
@@ -147,6 +148,7 @@ sweep_kernel(const SweepParams p)
     const int c = lane % LPR;
     const int D = p.D;
     const bool canonical = p.trust || (*p.flag != p.seq);
+    const bool stale_ids = p.ids_packed != nullptr && *p.packed_stale == p.seq;
     const char *xbase = reinterpret_cast<const char *>(p.X);
     const uint32_t row_bytes32 = (uint32_t)p.ldx * 4u;
     uint32_t *offs = s_off[wib];
@@ -286,7 +288,7 @@ sweep_kernel(const SweepParams p)
                     if (f_lo > 0) cum_lo = __builtin_nontemporal_load(p.cnt + (size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane));
                     if (f_hi < p.S) cum_hi = __builtin_nontemporal_load(p.cnt + (size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane));
                 }
-                const bool packed = dyn && p.ids_packed != nullptr;
+                const bool packed = dyn && p.ids_packed != nullptr && !stale_ids;
                 const uint32_t item_base = packed ? p.item_off[(size_t)t * (size_t)p.num_chunks + (size_t)(g0 >> 6)] : 0u;
                 const int32_t *__restrict__ ids = packed ? p.ids_packed : p.col;
                 const int len = pb > pa ? pb - pa : 0;
@@ -545,7 +547,8 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     p.flag = a.flag; p.seq = a.seq; p.trust = a.trust; p.sync = a.sync;
     p.P = a.P; p.D = a.D; p.ldx = a.ldx; p.S = a.S; p.B = a.B; p.plain_ok = a.plain_ok ? 1 : 0; p.eps = a.eps;
     p.slack = a.slack > 0 ? a.slack : 2;
-    p.ids_packed = a.ids_packed; p.item_off = a.item_off; p.num_chunks = (a.P + kWave - 1) / kWave;
+    p.ids_packed = a.packed_stale ? a.ids_packed : nullptr; p.item_off = a.item_off; p.packed_stale = a.packed_stale;
+    p.num_chunks = (a.P + kWave - 1) / kWave;
     p.dynamic = a.dynamic ? 1 : 0;
     int lpr = 4;
     const int pieces = (a.D + 3) / 4;

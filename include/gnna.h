@@ -266,6 +266,8 @@ typedef struct gnna_tuning {
                              ids in the order the sliced schedule consumes them, so that a work item reads its ids once
                              and contiguously instead of one cache line per neighbor-group and phase (nnz x 4 bytes per
                              copy, up to 4 copies per graph).  0 = automatic (on for prepared graphs), 2 = off,
+                             (every call compares 1024 samples of column_index with the copy's checksum and reads
+                             column_index itself on a mismatch: a rewritten buffer is noticed, a few changed ids are not);
                              1 = on for EVERY graph, prepared or not: the caller promises that no column_index is
                              rewritten in place while the library holds a plan for it (the reference's own call sequence
                              never does; without the promise a stale copy would give wrong results, which is why it is

@@ -180,6 +180,38 @@ def test_pack_ids_1_packs_unprepared_graphs_too_and_evicted_plans_drop_their_cop
         _lib.release_graph(None)
 
 
+@pytest.mark.parametrize("sweep", [0, 1])
+def test_a_rewritten_column_index_is_noticed_and_the_copy_bypassed(sweep):
+    """The packed copy exists under the caller's promise not to change the graph; a broken promise is still caught when it
+    is wholesale: every call compares 1024 samples of column_index with what the copy was made from and reads
+    column_index itself when they differ (the slice counts may be stale then -- that costs locality, not correctness)."""
+    g, X, pp, p2n = make_case(4000, 300000, 64, 16, seed=31, kind="powerlaw")
+    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+    _lib.reset_tuning()
+    _lib.set_tuning(column_phases=8, sweep=sweep)
+    try:
+        _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 16, [64])
+        l0 = counters()[1]
+        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+        assert counters()[1] == l0 + 1
+        assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                         what="before the rewrite")
+        # same row lengths, other neighbours, written into the SAME device tensor
+        new_ci = (g.column_index.to(torch.int64) * 7 + 13).remainder(g.num_nodes).to(torch.int32)
+        ci.copy_(new_ci.to(ci.device))
+        for _ in range(2):
+            y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+            assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), new_ci.numpy()),
+                             what="after the rewrite")
+        ci.copy_(g.column_index.to(ci.device))          # and back: the copy is valid again
+        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
+        assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),
+                         what="restored")
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(ci)
+
+
 def test_packed_in_a_captured_graph():
     g, X, pp, p2n = make_case(6000, 700000, 64, 32, seed=21, kind="powerlaw")
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
