@@ -584,7 +584,11 @@ def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
     comp = compulsory_bytes(g.nnz, g.num_nodes, getattr(w, "unique_sources", g.num_nodes), w.dim)
     t = kern_ms * 1e-3
     fabric = traffic.get("bytes_per_step") if traffic else None
-    rec = {"bound": bound, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # the contract's `bound` is "hbm" | "mfma": this path is HBM-side (memory fabric) work; `bound_detail` says which part
+    # of that side binds -- features that fit the 256 MiB Infinity Cache are served by it, the traffic is L2 misses either way
+    detail = ("l2-fabric: the L2 <-> Infinity Cache / HBM fabric (source features are Infinity-Cache resident)"
+              if bound == "l2-fabric" else "hbm: source features exceed the Infinity Cache")
+    rec = {"bound": "hbm", "bound_detail": detail, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "kernel": kernel_label(w),
            "kernel_ms": kern_ms, "kernel_launches_per_step": w.launches, "column_phases": w.phases,
            "kernel_ms_per_launch": kern_ms / max(1, w.launches), "prologue_ms": prologue_ms,
@@ -1122,7 +1126,7 @@ def run_sharded(args, result_fd, world, rank, local_rank):
                        "values": {n: {"value": l["value"], "unit": "edges/s", "ms_per_step": l["ms_per_step"],
                                       "scaling": "weak" if n == "weak" else ("strong" if n == "strong" else "config5 (fixed total graph)")}
                                   for n, l in legs.items()}},
-            "roofline": {"bound": "l2-fabric", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "bound_detail": "l2-fabric: the L2 <-> Infinity Cache / HBM fabric", "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "achieved": k["compulsory_model"]["GBs"], "frac": k["compulsory_model"]["GBs"] / HBM_PEAK_GBS,
                          "achieved_source": "compulsory model per rank (no PMC passes in multi-rank runs); the gather-model rate "
                                             "is beside it",
