@@ -116,6 +116,68 @@ __global__ void xcc_of_block(int32_t *__restrict__ out)
     }
 }
 
+// Variant: an id with the top bit set marks a COLD row -- it is loaded with a non-temporal load (first to leave the L2),
+// so that the hot rows of the slice keep their lines.  Same walk as gather_ceiling.
+template <int LPR, int U>
+__global__ void __launch_bounds__(256) gather_ceiling_nt(const float *__restrict__ X, const int32_t *__restrict__ ids,
+                                                         int64_t n, int seg, float *__restrict__ out)
+{
+    constexpr int RPI = 64 / LPR;
+    constexpr int LOADS = 64 / RPI;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t base = wave * (int64_t)seg;
+    if (base + seg > n) return;
+    const int lslot = lane / LPR, c = lane % LPR;
+    const char *xb = reinterpret_cast<const char *>(X) + c * 16;
+    const uint32_t row_bytes = LPR * 16;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // buffer loads, so that the cache policy is an operand of the instruction the compiler cannot fold away (a plain and a
+    // __builtin_nontemporal_load in the two arms of a branch are merged into ONE plain load): aux 0 = default, 2 = nt
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X), (short)0, 0x7fffffff, 0x00020000);
+    auto load = [&](uint32_t id) -> f32x4 {
+        const int off = (int)((id & 0x7fffffffu) * row_bytes + (uint32_t)c * 16u);
+        i32x4_t r;
+        if (id >> 31) r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2);
+        else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        return __builtin_bit_cast(f32x4, r);
+    };
+    int idv = __builtin_nontemporal_load(ids + base + lane);
+    for (int t = 0; t < seg; t += 64) {
+        const int idn = (t + 64 < seg) ? __builtin_nontemporal_load(ids + base + t + 64 + lane) : 0;
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = load((uint32_t)__shfl(idv, u * RPI + lslot));
+#pragma unroll
+        for (int b = 1; b < LOADS / U; b++) {
+            uint32_t nn[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) nn[u] = (uint32_t)__shfl(idv, (b * U + u) * RPI + lslot);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                acc += v[u];
+                v[u] = load(nn[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc += v[u];
+        idv = idn;
+    }
+    reinterpret_cast<f32x4 *>(out)[wave * 64 + lane] = acc;
+}
+
+extern "C" __attribute__((visibility("default")))
+int gather_ceiling_nt_launch(const float *X, const int32_t *ids, int64_t n, int dim, int seg, float *out)
+{
+    if (seg % 64 != 0 || seg <= 0 || dim != 64) return -1;
+    const int64_t waves = n / seg;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL((gather_ceiling_nt<16, 4>), dim3(grid), dim3(256), 0, 0, X, ids, n, seg, out);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 extern "C" __attribute__((visibility("default")))
 int xcc_of_block_launch(int32_t *out, int blocks, int threads)
 {
