@@ -424,7 +424,9 @@ stream_kernel(const StreamParams p)
             const int nr = (L - r0) < RL ? (L - r0) : RL;
 
             // lane j fetches the RPI column ids of its load (one vector load when the load is full) and parks
-            // them in LDS as row offsets; a padded slot repeats slot 0, an unused load reads row 0
+            // them in LDS as row offsets; a padded slot repeats slot 0, an unused load reads row 0.  (Plain loads: a
+            // non-temporal load costs several times a normal one on this chip -- nt id loads were 3-6 % of the kernel --
+            // and the id lines other phases come back for now stay in the L2.)
             if (lane < RL) {
                 uint32_t o[RPI];
                 if (v_j == RPI) {
@@ -433,19 +435,19 @@ stream_kernel(const StreamParams p)
                         typedef i32x4 i32x4u __attribute__((aligned(4)));
 #pragma unroll
                         for (int s4 = 0; s4 < RPI; s4 += 4) {
-                            const i32x4 t = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(ids + e_j + s4));
+                            const i32x4 t = *reinterpret_cast<const i32x4u *>(ids + e_j + s4);
                             o[s4] = (uint32_t)t[0]; o[s4 + 1] = (uint32_t)t[1]; o[s4 + 2] = (uint32_t)t[2]; o[s4 + 3] = (uint32_t)t[3];
                         }
                     } else {
 #pragma unroll
-                        for (int s = 0; s < RPI; s++) o[s] = (uint32_t)__builtin_nontemporal_load(ids + e_j + s);
+                        for (int s = 0; s < RPI; s++) o[s] = (uint32_t)ids[e_j + s];
                     }
                 } else {
-                    const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(ids + e_j) : 0u;
+                    const uint32_t first = v_j > 0 ? (uint32_t)ids[e_j] : 0u;
 #pragma unroll
                     for (int s = 0; s < RPI; s++) {
                         o[s] = first;
-                        if (s > 0 && s < v_j) o[s] = (uint32_t)__builtin_nontemporal_load(ids + e_j + s);
+                        if (s > 0 && s < v_j) o[s] = (uint32_t)ids[e_j + s];
                     }
                 }
                 if constexpr (MODE == MODE_GCN) {

@@ -285,8 +285,8 @@ sweep_kernel(const SweepParams p)
                 const int pb = gl ? p.pp[g0 + lane + 1] : 0;
                 int cum_lo = 0, cum_hi = 0x7fffffff;
                 if (gl) {
-                    if (f_lo > 0) cum_lo = __builtin_nontemporal_load(p.cnt + (size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane));
-                    if (f_hi < p.S) cum_hi = __builtin_nontemporal_load(p.cnt + (size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane));
+                    if (f_lo > 0) cum_lo = p.cnt[(size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane)];
+                    if (f_hi < p.S) cum_hi = p.cnt[(size_t)(f_hi - 1) * (size_t)p.P + (size_t)(g0 + lane)];
                 }
                 const bool packed = dyn && p.ids_packed != nullptr && !stale_ids;
                 const uint32_t item_base = packed ? p.item_off[(size_t)t * (size_t)p.num_chunks + (size_t)(g0 >> 6)] : 0u;
@@ -362,19 +362,19 @@ sweep_kernel(const SweepParams p)
                                     typedef i32x4 i32x4u __attribute__((aligned(4)));
 #pragma unroll
                                     for (int s4 = 0; s4 < RPI; s4 += 4) {
-                                        const i32x4 tt = __builtin_nontemporal_load(reinterpret_cast<const i32x4u *>(ids + e_j + s4));
+                                        const i32x4 tt = *reinterpret_cast<const i32x4u *>(ids + e_j + s4);
                                         o[s4] = (uint32_t)tt[0]; o[s4 + 1] = (uint32_t)tt[1]; o[s4 + 2] = (uint32_t)tt[2]; o[s4 + 3] = (uint32_t)tt[3];
                                     }
                                 } else {
 #pragma unroll
-                                    for (int q = 0; q < RPI; q++) o[q] = (uint32_t)__builtin_nontemporal_load(ids + e_j + q);
+                                    for (int q = 0; q < RPI; q++) o[q] = (uint32_t)ids[e_j + q];
                                 }
                             } else {
-                                const uint32_t first = v_j > 0 ? (uint32_t)__builtin_nontemporal_load(ids + e_j) : 0u;
+                                const uint32_t first = v_j > 0 ? (uint32_t)ids[e_j] : 0u;
 #pragma unroll
                                 for (int q = 0; q < RPI; q++) {
                                     o[q] = first;
-                                    if (q > 0 && q < v_j) o[q] = (uint32_t)__builtin_nontemporal_load(ids + e_j + q);
+                                    if (q > 0 && q < v_j) o[q] = (uint32_t)ids[e_j + q];
                                 }
                             }
 #pragma unroll
