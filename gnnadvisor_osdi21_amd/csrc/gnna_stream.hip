@@ -429,6 +429,13 @@ stream_kernel(const StreamParams p)
             // and the id lines other phases come back for now stay in the L2.)
             if (lane < RL) {
                 uint32_t o[RPI];
+                // (plain loads up to 128-float rows; rows of 129-256 floats -- one id per wave-wide load, 1 KiB of L2
+                // per row -- do better when the ids leave the L2 first: D = 256: 7.13 ms with nt ids, 7.44 plain)
+                constexpr bool NT = LPR >= 64;
+                auto id_at = [&](int e) -> uint32_t {
+                    if constexpr (NT) return (uint32_t)__builtin_nontemporal_load(ids + e);
+                    else return (uint32_t)ids[e];
+                };
                 if (v_j == RPI) {
                     if constexpr (RPI >= 4) {
                         typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -440,14 +447,14 @@ stream_kernel(const StreamParams p)
                         }
                     } else {
 #pragma unroll
-                        for (int s = 0; s < RPI; s++) o[s] = (uint32_t)ids[e_j + s];
+                        for (int s = 0; s < RPI; s++) o[s] = id_at(e_j + s);
                     }
                 } else {
-                    const uint32_t first = v_j > 0 ? (uint32_t)ids[e_j] : 0u;
+                    const uint32_t first = v_j > 0 ? id_at(e_j) : 0u;
 #pragma unroll
                     for (int s = 0; s < RPI; s++) {
                         o[s] = first;
-                        if (s > 0 && s < v_j) o[s] = (uint32_t)ids[e_j + s];
+                        if (s > 0 && s < v_j) o[s] = id_at(e_j + s);
                     }
                 }
                 if constexpr (MODE == MODE_GCN) {
