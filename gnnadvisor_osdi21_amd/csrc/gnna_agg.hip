@@ -87,14 +87,20 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
                 const int32_t *__restrict__ chk_ids, int64_t chk_n, const unsigned long long *__restrict__ chk_sum,
                 int32_t *stale_flag)
 {
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // packed ids of a prepared graph: does column_index still look like the array the copy was made from?  (1024 samples:
-    // catches a buffer that was rewritten, which is what happens when a promise of immutability is broken by accident)
-    if (chk_ids && blockIdx.x == 0 && threadIdx.x < kWave) {
-        const unsigned long long now = sample_checksum(chk_ids, chk_n, (int)threadIdx.x);
-        if (threadIdx.x == 0 && now != *chk_sum) *stale_flag = seq;
+    // catches a buffer that was rewritten, which is what happens when a promise of immutability is broken by accident.)
+    // The launcher adds one block for it, so that the zero-fill does not wait behind the sampled loads.
+    const unsigned fill_blocks = chk_ids ? gridDim.x - 1 : gridDim.x;
+    if (blockIdx.x >= fill_blocks) {
+        if (threadIdx.x < kWave) {
+            const unsigned long long then = *chk_sum;
+            const unsigned long long now = sample_checksum(chk_ids, chk_n, (int)threadIdx.x);
+            if (threadIdx.x == 0 && now != then) *stale_flag = seq;
+        }
+        return;
     }
-    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nthreads = (size_t)fill_blocks * blockDim.x;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (!zero_fill) {
         // accumulate mode: Y keeps its contents
@@ -778,7 +784,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             size_t work = std::max(n_floats / 4, (size_t)num_parts);
             int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);
             blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
-            hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, n_floats,
+            hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks + (chk_sum ? 1u : 0u)), dim3(kBlock), 0, stream, out, n_floats,
                                part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill,
                                chk_sum ? column_index : nullptr, chk_n, chk_sum, stale_flag);
         }

@@ -157,12 +157,14 @@ __device__ __forceinline__ unsigned long long sample_checksum(const int32_t *__r
 {
     unsigned long long sum = 0;
     if (n > 0) {
-#pragma unroll 4
-        for (int k = 0; k < 16; k++) {
+        uint32_t v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {            // all 16 loads in flight together
             const int i = k * 64 + lane;
-            const int64_t pos = (int64_t)(((unsigned long long)i * (unsigned long long)n) >> 10);
-            sum += (unsigned long long)(uint32_t)ids[pos] * (unsigned long long)(2 * i + 1);
+            v[k] = (uint32_t)ids[(int64_t)(((unsigned long long)i * (unsigned long long)n) >> 10)];
         }
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += (unsigned long long)v[k] * (unsigned long long)(2 * (k * 64 + lane) + 1);
     }
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
     return sum;
