@@ -24,9 +24,9 @@ __global__ void __launch_bounds__(256) gather_ceiling(const float *__restrict__ 
     const char *xb = reinterpret_cast<const char *>(X) + c * 16;
     const uint32_t row_bytes = LPR * 16;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int idv = __builtin_nontemporal_load(ids + base + lane);
+    int idv = ids[base + lane];
     for (int t = 0; t < seg; t += 64) {
-        const int idn = (t + 64 < seg) ? __builtin_nontemporal_load(ids + base + t + 64 + lane) : 0;
+        const int idn = (t + 64 < seg) ? ids[base + t + 64 + lane] : 0;
         f32x4 v[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -76,9 +76,9 @@ __global__ void __launch_bounds__(1024) gather_ceiling_hub(const float *__restri
     // persistent: wavefront w takes segments w, w + W, ... (phase-major order is kept chip-wide)
     for (int64_t sgi = (int64_t)blockIdx.x * 16 + wib; sgi < nseg; sgi += waves_total) {
         const int64_t base = sgi * (int64_t)seg;
-        int idv = __builtin_nontemporal_load(ids + base + lane);
+        int idv = ids[base + lane];
         for (int t = 0; t < seg; t += 64) {
-            const int idn = (t + 64 < seg) ? __builtin_nontemporal_load(ids + base + t + 64 + lane) : 0;
+            const int idn = (t + 64 < seg) ? ids[base + t + 64 + lane] : 0;
             auto load = [&](uint32_t id) -> f32x4 {
                 if (id >> 31) return *reinterpret_cast<const f32x4 *>(hb + (id & 0x7fffffffu) * row_bytes);
                 return *reinterpret_cast<const f32x4 *>(xb + id * row_bytes);
@@ -143,9 +143,9 @@ __global__ void __launch_bounds__(256) gather_ceiling_nt(const float *__restrict
         else r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
         return __builtin_bit_cast(f32x4, r);
     };
-    int idv = __builtin_nontemporal_load(ids + base + lane);
+    int idv = ids[base + lane];
     for (int t = 0; t < seg; t += 64) {
-        const int idn = (t + 64 < seg) ? __builtin_nontemporal_load(ids + base + t + 64 + lane) : 0;
+        const int idn = (t + 64 < seg) ? ids[base + t + 64 + lane] : 0;
         f32x4 v[U];
 #pragma unroll
         for (int u = 0; u < U; u++) v[u] = load((uint32_t)__shfl(idv, u * RPI + lslot));
