@@ -207,6 +207,7 @@ class Workload:
         for _ in range(warmup):
             self.step()
         torch.cuda.synchronize()
+        swept0 = self._lib.runtime_counters()["sweep_launches"]
         self._lib.profile_begin(steps)
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -216,6 +217,7 @@ class Workload:
         prof = self._lib.profile_end()
         self.phases = self._lib.last_num_phases()
         self.launches = self._lib.last_num_launches()
+        self.swept = self._lib.runtime_counters()["sweep_launches"] - swept0 >= steps     # which kernel the library picked
         return elapsed, prof
 
     def verify(self, samples=256):
@@ -613,6 +615,16 @@ def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
             "l2_time_floor_ms": req * 128 / 34.5e12 * 1e3 if req else None,
             "l2_share_of_kernel_time": req * 128 / 34.5e12 / t if req else None,
             "l2_ceiling": "34.5 TB/s aggregate L2 (128-byte requests)"}
+        # which of the two the kernel is closer to: `frac` above is the FABRIC fraction (measured traffic / time / 8 TB/s) and
+        # falls when a schedule removes traffic (the sweep kernel moves half of what the streaming kernel does); the share of
+        # the kernel time each ceiling accounts for says which one binds
+        if req and req * 128 / 34.5e12 > fabric / 6.3e12:
+            rec["binding_ceiling"] = "l2: the L2 -> L1 gather path (%.1f TB/s of 34.5); the fabric carries %.2f GB per step, %.0f %% of its ceiling" % (
+                req * 128 / t / 1e12, fabric / 1e9, 100.0 * fabric / 6.3e12 / t)
+            rec["l2_gather"] = {"achieved": req * 128 / t / 1e9, "peak": 34500.0, "unit": "GB/s", "frac": req * 128 / t / 34.5e12}
+        else:
+            rec["binding_ceiling"] = "fabric: L2 misses (%.2f GB per step = %.0f %% of the 6.3 TB/s the fabric sustains); L2 -> L1 at %.0f %% of 34.5 TB/s" % (
+                fabric / 1e9, 100.0 * fabric / 6.3e12 / t, 100.0 * req * 128 / 34.5e12 / t if req else 0.0)
     else:
         rec.update({"achieved": comp / t / 1e9 if t > 0 else 0.0,
                     "frac": comp / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,

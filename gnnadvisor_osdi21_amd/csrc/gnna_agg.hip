@@ -585,6 +585,27 @@ int choose_row_stride(int dim)
 //  * at least ~16 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses -- ~8 are
 //    enough for the split that makes a slice fit the Infinity Cache (products-like, average degree 50, X = 627 MB: best
 //    4 phases; amazon0505-like, degree 12: none).
+// Phases for the sweep kernel when the library picks it by itself (gnna_tuning.sweep = 0), or 0: the streaming kernel
+// runs.  Measured (DESIGN 3.1b, round 3 end): with plain id loads and 8 row loads in flight the sweep beats the streaming
+// kernel by 3-4 % where (a) a destination row is 33-64 floats -- narrower rows flush cheaply, wider ones halve the rows
+// the LDS accumulators hold --, (b) the rows are long (>= 300 edges on average) and few enough that a workgroup's share
+// fits the accumulators in at most two sets (Reddit-like: 233 K rows of 492 edges; products-like needs 21 sets and loses
+// 15 %, the 65-edge rows of an 8-rank shard's local part lose 40 %), (c) sources and destinations are the same node set
+// and the source matrix is Infinity-Cache sized (the multi-GPU shapes -- 8 x the source rows, 32 phases -- lose 10 %),
+// and (d) the schedule is sliced anyway.  It takes twice the streaming kernel's phase count (no flush per piece), at most 16.
+int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
+                      double edges, int B, int num_cus, bool deterministic)
+{
+    if (t.sweep != 0 || deterministic || B < 2) return 0;
+    if (dim <= 32 || dim > 64 || !sweep_supports(mode, dim, x_bytes)) return 0;
+    if (num_in_rows != num_out_rows || x_bytes > ((size_t)160 << 20)) return 0;
+    if (edges < 300.0 * (double)std::max<int64_t>(1, num_out_rows)) return 0;
+    const double cap = (double)sweep_acc_rows(dim, 1) * 0.9 * (double)std::max(8, num_cus);
+    if ((double)num_out_rows > 2.0 * cap) return 0;
+    if (t.column_phases >= 2) return B;                 // a forced / measured phase count is taken as it is
+    return std::min(16, 2 * B);
+}
+
 int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
                   bool square, bool hinted_scattered)
 {
@@ -883,11 +904,14 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         if (!cnt || B < 2) { B = 1; cnt = nullptr; }
         // Destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
         // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
-        if (cnt && tune.sweep == 1 && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
+        const int auto_Bs = (cnt && plan.stats.valid) ? sweep_auto_phases(tune, mode, dim, x_bytes, num_nodes, num_in_rows, plan.stats.edges, B,
+                                                                          ds->num_cus, tune.deterministic == 1) : 0;
+        if (cnt && (tune.sweep == 1 || auto_Bs > 0) && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
             int Bs = B;
-            if (tune.column_phases < 2) {             // not forced: slices of about half an XCD's L2
-                Bs = 2;
-                while (Bs < S && x_bytes / Bs > ((size_t)2 << 20)) Bs <<= 1;
+            if (auto_Bs > 0) {
+                Bs = std::min(auto_Bs, S);
+            } else if (tune.column_phases < 2) {      // sweep forced, phases not: twice the streaming kernel's
+                Bs = std::min(std::min(16, 2 * B), S);
             }
             const int32_t *sw_ids = nullptr; const uint32_t *sw_off = nullptr;
             if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && tune.xcd_remap != 0) {
@@ -903,7 +927,8 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             SweepLaunch w;
             w.mode = mode; w.X = p.X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;
             w.cnt = cnt; w.row_scale = p.row_scale; w.flag = flag; w.seq = seq; w.trust = p.trust; w.sync = sync;
-            w.P = num_parts; w.D = dim; w.ldx = ldx; w.U = tune.loads_in_flight; w.S = S; w.B = Bs;
+            w.P = num_parts; w.D = dim; w.ldx = ldx; w.S = S; w.B = Bs;
+            w.U = std::max(tune.loads_in_flight, 8);      // 16 wavefronts per CU: more loads in flight per wavefront pay here
             w.rows_with_edges = plan.stats.valid ? (int64_t)std::min((double)num_nodes, plan.stats.groups) : num_nodes;
             if (tune.groups_per_chunk > 64) w.rounds = tune.groups_per_chunk / 64;   // experiments: G = 64 * (sets per workgroup)
             w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;
@@ -1110,10 +1135,21 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
                                   t.nonlocal_ids == 1);
         }
         if (phases_out) phases_out[i] = std::max(1, B);
-        if (B >= 2 && t.pack_ids != 2 && plan.handle && t.sweep != 1) {   // (the plan is pinned here)
+        if (B >= 2 && t.pack_ids != 2 && plan.handle) {   // (the plan is pinned here)
             const int32_t *ids = nullptr; const uint32_t *off = nullptr;
-            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
+            // the kernel that will run at this width: the sweep (its own phase count, 64 groups per chunk) or the streaming kernel
+            const int mode_guess = t.gcn_prescale == 2 ? MODE_GCN : MODE_SAG;
+            int Bs = sweep_auto_phases(t, mode_guess, dim, x_bytes, num_out_rows, num_in_rows, plan.stats.edges, B, ds->num_cus,
+                                       t.deterministic == 1);
+            if (t.sweep == 1 && t.deterministic != 1 && sweep_supports(mode_guess, dim, x_bytes))
+                Bs = t.column_phases >= 2 ? B : std::min(16, 2 * B);
+            Bs = std::min(Bs, plan.S);
+            if (Bs >= 2 && t.xcd_remap != 0)
+                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, true, &ids, &off);
+            else
+                rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
             if (rc != GNNA_OK) return rc;
+            if (phases_out && Bs >= 2) phases_out[i] = Bs;
         }
         if (t.deterministic == 1 && dim >= 4) {   // the deterministic schedule parks partial rows in the stream's scratch (slot 2)
             const int G_eff = std::max(1, std::min(kWave, t.groups_per_chunk * std::max(1, B)));

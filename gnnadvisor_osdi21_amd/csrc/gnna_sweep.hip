@@ -508,6 +508,9 @@ SweepKernel pick_sweep_u(int u)
 {
     constexpr int RPI = kWave / LPR;
     constexpr int RL = (kSweepIdSlots / RPI < kWave) ? kSweepIdSlots / RPI : kWave;
+    if constexpr (RL % 16 == 0 && WGS == 1) {
+        if (u >= 16) return sweep_kernel<LPR, MODE, 16, WGS>;
+    }
     if constexpr (RL % 8 == 0 && WGS == 1) {
         if (u >= 8) return sweep_kernel<LPR, MODE, 8, WGS>;
     }

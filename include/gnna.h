@@ -247,11 +247,12 @@ typedef struct gnna_tuning {
     int sweep;            /* destination-blocked sweep kernel (gnna_sweep.hip): persistent wavefronts keep the partial
                              rows of their groups in LDS while every XCD walks the source slices in step, and write
                              each row once.  1 = wherever it applies (sliced schedule, unweighted or pre-scaled gather,
-                             rows of >= 4 floats <= 128 wide, source matrix <= 4 GiB), 2 = never, 0 = automatic (today: never --
-                             it does not beat the streaming kernel).  While it is selected two other knobs
-                             are read in its terms: blocks_per_cu = workgroups per CU (1: one 16-wavefront workgroup with
-                             all of the CU's LDS, else two), groups_per_chunk > 64 = 64 x (sets per workgroup) instead of the
-                             automatic count */
+                             rows of >= 4 floats <= 128 wide, source matrix <= 4 GiB), 2 = never, 0 = automatic: where it
+                             measures faster than the streaming kernel -- rows of 33..64 floats, a sliced schedule over a
+                             square, Infinity-Cache-sized problem, long rows (>= 300 edges on average) and few enough of
+                             them that a workgroup's share fits its LDS accumulators in two sets.  While it is selected by 1 two other knobs are read in its terms:
+                             blocks_per_cu = workgroups per CU (1: one 16-wavefront workgroup with all of the CU's LDS,
+                             else two), groups_per_chunk > 64 = 64 x (sets per workgroup) instead of the automatic count */
     int sweep_slack;      /* sweep kernel: how many slice steps a wavefront may run ahead of the slowest wavefront of
                              its XCD (soft barrier on a per-XCD counter, bounded spin: only locality depends on it).
                              0 = built-in, n > 0 = n steps, >= 1000 = no synchronisation at all */

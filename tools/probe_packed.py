@@ -44,7 +44,8 @@ for B in phases:
     for name, pk in (("ids_from_column_index", 2), ("packed_ids", 1)):
         _lib.reset_tuning()
         _lib.set_tuning(column_phases=B, pack_ids=pk, sweep=sweep, sweep_slack=int(os.environ.get("PROBE_SLACK", "0")),
-                        blocks_per_cu=int(os.environ.get("PROBE_WGS", "0")))
+                        blocks_per_cu=int(os.environ.get("PROBE_WGS", "0")), loads_in_flight=int(os.environ.get("PROBE_U", "-1")),
+                        groups_per_chunk=(64 * int(os.environ["PROBE_ROUNDS"]) if "PROBE_ROUNDS" in os.environ else -1))
         _lib.prepare_graph(g.column_index, ppd, p2nd, g.num_nodes, g.num_nodes, ps, [D])
         before = _lib.runtime_counters()["packed_launches"]
         row[name] = timeit()
