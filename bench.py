@@ -596,8 +596,11 @@ def roofline_record(w, kern_ms, prologue_ms, traffic, bound):
            "kernel_ms_per_launch": kern_ms / max(1, w.launches), "prologue_ms": prologue_ms,
            "kernel_edges_per_s": g.nnz / t if t > 0 else 0.0,
            "gather_model": {"bytes_per_step": alg, "GBs": alg / t / 1e9 if t > 0 else 0.0,
-                            "formula": "nnz*(4D+4) + N*(4D+4) + P*8 (SURVEY 8d; counts L2 / Infinity-Cache hits, "
-                                       "so it is an effective gather rate, not an HBM fraction)"},
+                            "frac_of_hbm_peak": alg / t / 1e9 / HBM_PEAK_GBS if t > 0 else 0.0,
+                            "formula": "nnz*(4D+4) + N*(4D+4) + P*8 (SURVEY 8d; the ALGORITHMIC bytes; counts L2 / Infinity-Cache "
+                                       "hits, so it is an effective gather rate -- above 1 x the HBM peak when the features are "
+                                       "cache resident -- not an HBM fraction; `frac` below is measured fabric traffic / time / peak, "
+                                       "which FALLS when a schedule moves fewer bytes for the same edges)"},
            "compulsory_model": {"bytes_per_step": comp, "GBs": comp / t / 1e9 if t > 0 else 0.0}}
     if fabric:
         rec.update({"achieved": fabric / t / 1e9, "frac": fabric / t / 1e9 / HBM_PEAK_GBS,
