@@ -128,6 +128,53 @@ def test_sweep_reads_the_packed_ids_of_a_prepared_graph(dim, ps, phases):
         _lib.release_graph(ci)
 
 
+def test_the_library_picks_the_sweep_kernel_only_where_it_wins():
+    """gnna_tuning.sweep = 0: rows of 33-64 floats, a sliced schedule over a square problem with long rows (>= 300 edges)
+    that fit the accumulators in two sets -> sweep_kernel; wider / narrower rows, short rows, rectangular problems and
+    sweep = 2 -> stream_kernel.  Both give the oracle's result."""
+    g = graph.powerlaw_graph(80000, 32000000, 8000, seed=5, device="cuda")           # ~400 edges per row, X = 20 MB at D = 64
+    n = g.num_nodes
+    pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+    ppd, p2nd = pp.cuda(), p2n.cuda()
+    rpn, cin = g.row_pointers.cpu().numpy(), g.column_index.cpu().numpy()
+    _lib.reset_tuning()
+
+    def launches(fn):
+        before = _lib.runtime_counters()["sweep_launches"]
+        y = fn()
+        torch.cuda.synchronize()
+        return _lib.runtime_counters()["sweep_launches"] - before, y
+
+    try:
+        for dim, swept in ((64, 1), (41, 1), (32, 0), (128, 0)):
+            X = torch.randn(n, dim, generator=torch.Generator().manual_seed(dim))
+            Xd = X.cuda()
+            k, y = launches(lambda: _lib.sag(Xd, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4))
+            assert k == swept, (dim, k, _lib.last_num_phases())
+            assert _lib.last_num_phases() >= 2
+            assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, X.numpy(), rpn, cin), what=f"automatic choice, dim {dim}",
+                             scale=oracle.csr_f64(0, np.abs(X.numpy()), rpn, cin))
+        X = torch.randn(n, 64, generator=torch.Generator().manual_seed(1)).cuda()
+        _lib.set_tuning(sweep=2)
+        k, _ = launches(lambda: _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4))
+        assert k == 0
+        _lib.reset_tuning()
+        # a destination shard (rows != source rows) of the same graph keeps the streaming kernel
+        k, _ = launches(lambda: _lib.agg_rect(0, X, g.column_index[: int(g.row_pointers[n // 2])].contiguous(),
+                                              *[t.cuda() for t in _lib.build_part(64, g.row_pointers[: n // 2 + 1].cpu())], n // 2, 64))
+        assert k == 0
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(None)
+    # short rows (40 edges per row): streaming kernel
+    g2 = graph.powerlaw_graph(200000, 8000000, 2000, seed=6, device="cuda")
+    pp2, p2n2 = _lib.build_part(32, g2.row_pointers.cpu())
+    X2 = torch.randn(g2.num_nodes, 64, device="cuda")
+    k, _ = launches(lambda: _lib.sag(X2, g2.row_pointers, g2.column_index, g2.degrees, pp2.cuda(), p2n2.cuda(), 32, 32, 4))
+    assert k == 0
+    _lib.release_graph(None)
+
+
 def test_sweep_rows_beyond_the_accumulators_take_the_atomic_path():
     """Low-degree rows: a set (1/256 of the edges with one set per workgroup) spans more destination rows than the
     CU's LDS holds (256 rows of 128 floats, 512 of 64) -- the rows beyond are flushed per slice with atomics."""
