@@ -573,6 +573,25 @@ int choose_row_stride(int dim)
     return best;
 }
 
+// Row stride of the source rows the kernels gather from (== dim: X itself, no staged copy):
+//  (b) a padded stride for widths whose rows straddle 128-byte lines or are not 16-byte aligned (choose_row_stride);
+//  (c) a gap after every row: rows of at most two 128-byte lines that are re-read tens of times gather 3-5 % faster from
+//      a copy whose row stride is twice the lines a row covers (measured, Reddit-like, step incl. the copy: D = 16 / 32 /
+//      41 / 64 -> strides of 64 / 64 / 128 / 128 floats: 0.770 -> 0.757, 0.827 -> 0.810, 1.509 -> 1.466, 1.490 -> 1.443 ms;
+//      1.5 x or 4 x is slower, and so is any gap once the copy outgrows the Infinity Cache: D = 128 -> 256: 3.03 -> 3.30);
+//  pad_rows: 0 automatic (both, for hot rows), 1 rule (b) always, 2 never, > 2 an explicit stride (experiments).
+int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in_rows, bool whole_call)
+{
+    int ldx = dim;
+    if (t.pad_rows == 1 || (t.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);
+    if (t.pad_rows == 0 && hot_rows && dim >= 4 && dim <= 64 && whole_call) {
+        const int gapped = 2 * ((dim * 4 + 127) / 128) * 32;
+        if ((size_t)num_in_rows * (size_t)gapped * sizeof(float) <= ((size_t)160 << 20)) ldx = gapped;
+    }
+    if (t.pad_rows > 2 && t.pad_rows >= dim) ldx = t.pad_rows;
+    return ldx;
+}
+
 }  // namespace
 
 // Number of phases of the sliced schedule from the slice statistics of the partition (st.cells[l] =
@@ -592,9 +611,10 @@ int choose_row_stride(int dim)
 // fits the accumulators in at most two sets (Reddit-like: 233 K rows of 492 edges; products-like needs 21 sets and loses
 // 15 %, the 65-edge rows of an 8-rank shard's local part lose 40 %), (c) sources and destinations are the same node set
 // and the source matrix is Infinity-Cache sized (the multi-GPU shapes -- 8 x the source rows, 32 phases -- lose 10 %),
-// and (d) the schedule is sliced anyway.  It takes twice the streaming kernel's phase count (no flush per piece), at most 16.
+// and (d) the schedule is sliced anyway.  It takes twice the streaming kernel's phase count (no flush per piece), at most 16
+// and at most partSize / 4.
 int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
-                      double edges, int B, int num_cus, bool deterministic)
+                      double edges, int B, int num_cus, bool deterministic, int part_size)
 {
     if (t.sweep != 0 || deterministic || B < 2) return 0;
     if (dim <= 32 || dim > 64 || !sweep_supports(mode, dim, x_bytes)) return 0;
@@ -603,7 +623,8 @@ int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, i
     const double cap = (double)sweep_acc_rows(dim, 1) * 0.9 * (double)std::max(8, num_cus);
     if ((double)num_out_rows > 2.0 * cap) return 0;
     if (t.column_phases >= 2) return B;                 // a forced / measured phase count is taken as it is
-    return std::min(16, 2 * B);
+    // a work item is 64 groups of one phase: keep it at >= ~256 edges (partSize 32: 8 phases 1.45 ms, 16 phases 1.64)
+    return std::max(2, std::min(std::min(16, 2 * B), std::max(2, part_size / 4)));
 }
 
 int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
@@ -850,12 +871,13 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     // feature matrix would silently double the resident set -- the per-edge form runs on the same kernel)
     const bool hot_rows = est_edges >= 32 * num_in_rows && (size_t)num_in_rows * (size_t)dim * sizeof(float) <= ((size_t)1 << 30);
     const bool prescale = mode == MODE_GCN && (tune.gcn_prescale == 1 || (tune.gcn_prescale == 0 && hot_rows));
-    int ldx = dim;
-    if (tune.pad_rows == 1 || (tune.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);
-    if (tune.pad_rows > 2 && tune.pad_rows >= dim) ldx = tune.pad_rows;   // (experiments: an explicit row stride in floats)
+    const int ldx = pick_row_stride(tune, dim, hot_rows, num_in_rows, win_begin == 0 && num_windows == 1);
     p.ldx = ldx;
     p.row_scale = nullptr;
     const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);
+    // what the gather can touch of it (whole 128-byte lines of every row; a gapped copy's gaps never enter a cache):
+    // the size the slicing decisions go by
+    const size_t foot_bytes = (size_t)num_in_rows * (size_t)std::min(ldx, (dim * 4 + 127) / 128 * 32) * sizeof(float);
     const bool wide = x_bytes > 0xffffffffull;
     if (prescale || ldx != dim) {
         void *xs = nullptr;
@@ -887,16 +909,16 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         const uint8_t *cnt = nullptr;
         int S = kMaxSlices;
         SlicePlan plan;
-        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && x_bytes >= ((size_t)2 << 20);
+        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && foot_bytes >= ((size_t)2 << 20);
         if (tune.column_phases >= 2 && num_in_rows >= kMaxSlices) {
             B = std::min(tune.column_phases, kMaxSlices);
             rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, false, false, &plan);
             if (rc != GNNA_OK) return rc;
-        } else if (tune.column_phases == 0 && can_slice && x_bytes >= ((size_t)6 << 20)) {
+        } else if (tune.column_phases == 0 && can_slice && foot_bytes >= ((size_t)6 << 20)) {
             rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, false, &plan);
             if (rc != GNNA_OK) return rc;
             if (plan.cnt && plan.stats.valid)
-                B = choose_slices(plan.stats, x_bytes, plan.S, plan.slice_rows, num_nodes, num_in_rows == num_nodes,
+                B = choose_slices(plan.stats, foot_bytes, plan.S, plan.slice_rows, num_nodes, num_in_rows == num_nodes,
                                   tune.nonlocal_ids == 1);
         }
         cnt = plan.cnt;
@@ -904,14 +926,14 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         if (!cnt || B < 2) { B = 1; cnt = nullptr; }
         // Destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
         // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
-        const int auto_Bs = (cnt && plan.stats.valid) ? sweep_auto_phases(tune, mode, dim, x_bytes, num_nodes, num_in_rows, plan.stats.edges, B,
-                                                                          ds->num_cus, tune.deterministic == 1) : 0;
+        const int auto_Bs = (cnt && plan.stats.valid) ? sweep_auto_phases(tune, mode, dim, foot_bytes, num_nodes, num_in_rows, plan.stats.edges, B,
+                                                                          ds->num_cus, tune.deterministic == 1, partSize) : 0;
         if (cnt && (tune.sweep == 1 || auto_Bs > 0) && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
             int Bs = B;
             if (auto_Bs > 0) {
                 Bs = std::min(auto_Bs, S);
             } else if (tune.column_phases < 2) {      // sweep forced, phases not: twice the streaming kernel's
-                Bs = std::min(std::min(16, 2 * B), S);
+                Bs = std::max(2, std::min(std::min(std::min(16, 2 * B), std::max(2, partSize / 4)), S));
             }
             const int32_t *sw_ids = nullptr; const uint32_t *sw_off = nullptr;
             if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && tune.xcd_remap != 0) {
@@ -1122,16 +1144,16 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
         apply_graph_hints(column_index, dim, &t);
         const size_t raw = (size_t)num_in_rows * (size_t)dim * sizeof(float);
         const bool hot_rows = hot && raw <= ((size_t)1 << 30);
-        int ldx = dim;
-        if (t.pad_rows == 1 || (t.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);
+        const int ldx = pick_row_stride(t, dim, hot_rows, num_in_rows, true);
         const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);
+        const size_t foot_bytes = (size_t)num_in_rows * (size_t)std::min(ldx, (dim * 4 + 127) / 128 * 32) * sizeof(float);
         if (hot_rows || t.gcn_prescale == 1 || ldx != dim) staged = std::max(staged, x_bytes);   // (GCN pre-scaling stages too)
         int B = 1;
-        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && x_bytes >= ((size_t)2 << 20);
+        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && foot_bytes >= ((size_t)2 << 20);
         if (dim >= 4 && t.stream_kernel != 2) {
             if (t.column_phases >= 2 && num_in_rows >= kMaxSlices) B = std::min(t.column_phases, kMaxSlices);
-            else if (t.column_phases == 0 && can_slice && x_bytes >= ((size_t)6 << 20))
-                B = choose_slices(plan.stats, x_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,
+            else if (t.column_phases == 0 && can_slice && foot_bytes >= ((size_t)6 << 20))
+                B = choose_slices(plan.stats, foot_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,
                                   t.nonlocal_ids == 1);
         }
         if (phases_out) phases_out[i] = std::max(1, B);
@@ -1139,10 +1161,10 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
             const int32_t *ids = nullptr; const uint32_t *off = nullptr;
             // the kernel that will run at this width: the sweep (its own phase count, 64 groups per chunk) or the streaming kernel
             const int mode_guess = t.gcn_prescale == 2 ? MODE_GCN : MODE_SAG;
-            int Bs = sweep_auto_phases(t, mode_guess, dim, x_bytes, num_out_rows, num_in_rows, plan.stats.edges, B, ds->num_cus,
-                                       t.deterministic == 1);
+            int Bs = sweep_auto_phases(t, mode_guess, dim, foot_bytes, num_out_rows, num_in_rows, plan.stats.edges, B, ds->num_cus,
+                                       t.deterministic == 1, partSize);
             if (t.sweep == 1 && t.deterministic != 1 && sweep_supports(mode_guess, dim, x_bytes))
-                Bs = t.column_phases >= 2 ? B : std::min(16, 2 * B);
+                Bs = t.column_phases >= 2 ? B : std::max(2, std::min(std::min(16, 2 * B), std::max(2, partSize / 4)));
             Bs = std::min(Bs, plan.S);
             if (Bs >= 2 && t.xcd_remap != 0)
                 rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, true, &ids, &off);

@@ -156,7 +156,7 @@ int sweep_acc_rows(int dim, int wgs_per_cu);   // destination rows a workgroup's
 int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream);
 // Phases of the sweep kernel when the library picks it on its own (gnna_tuning.sweep = 0) for this call, else 0 (gnna_agg.hip).
 int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
-                      double edges, int B, int num_cus, bool deterministic);
+                      double edges, int B, int num_cus, bool deterministic, int part_size);
 constexpr int kSweepSyncSlots = 64;    // ring of per-call counter blocks (kXcds x 64 bytes each)
 
 // ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------------
