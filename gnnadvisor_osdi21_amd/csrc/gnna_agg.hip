@@ -575,16 +575,18 @@ int choose_row_stride(int dim)
 
 // Row stride of the source rows the kernels gather from (== dim: X itself, no staged copy):
 //  (b) a padded stride for widths whose rows straddle 128-byte lines or are not 16-byte aligned (choose_row_stride);
-//  (c) a gap after every row: rows of at most two 128-byte lines that are re-read tens of times gather 3-5 % faster from
-//      a copy whose row stride is twice the lines a row covers (measured, Reddit-like, step incl. the copy: D = 16 / 32 /
-//      41 / 64 -> strides of 64 / 64 / 128 / 128 floats: 0.770 -> 0.757, 0.827 -> 0.810, 1.509 -> 1.466, 1.490 -> 1.443 ms;
-//      1.5 x or 4 x is slower, and so is any gap once the copy outgrows the Infinity Cache: D = 128 -> 256: 3.03 -> 3.30);
+//  (c) a gap after every row: rows of one or two 128-byte lines that are re-read tens of times gather 2-6 % faster from a
+//      copy in which every row starts at a multiple of twice its lines (measured, Reddit-like, kernel ms at equal phase
+//      counts: D = 32 / 41 / 64 from strides of 64 / 128 / 128 floats: 0.805 -> 0.770, 1.480 -> 1.446, 1.508 -> 1.420; any
+//      multiple of that stride measures the same, anything else -- 1.5 x, a stride off the line grid -- the same as no gap
+//      or worse; rows of <= 64 bytes, D <= 16, share lines and lose by it: 0.701 -> 0.736; and so does any row once the
+//      copy outgrows the Infinity Cache: D = 128 -> 256: 3.03 -> 3.30);
 //  pad_rows: 0 automatic (both, for hot rows), 1 rule (b) always, 2 never, > 2 an explicit stride (experiments).
 int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in_rows, bool whole_call)
 {
     int ldx = dim;
     if (t.pad_rows == 1 || (t.pad_rows == 0 && hot_rows)) ldx = choose_row_stride(dim);
-    if (t.pad_rows == 0 && hot_rows && dim >= 4 && dim <= 64 && whole_call) {
+    if (t.pad_rows == 0 && hot_rows && dim > 16 && dim <= 64 && whole_call) {
         const int gapped = 2 * ((dim * 4 + 127) / 128) * 32;
         if ((size_t)num_in_rows * (size_t)gapped * sizeof(float) <= ((size_t)160 << 20)) ldx = gapped;
     }
@@ -651,7 +653,11 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
         if (st.cells[0] <= 1.15 * st.groups) return 1;       // every group inside one slice
     }
     int b = 1;
-    while (b < S && x_bytes / b > ((size_t)8 << 20)) b <<= 1;
+    // slices of at most 8 MiB; 4 MiB for rows of at most 64 bytes (D <= 16: a flush is one 64-byte memory-side request,
+    // a quarter of a 64-float row's, so finer slices pay: Reddit-like D = 16, 2 / 4 / 8 phases: 0.752 / 0.701 / 0.728 ms)
+    const double row_bytes_all = (double)x_bytes / ((double)slice_rows * S);
+    const size_t slice_target = row_bytes_all <= 64.0 ? ((size_t)4 << 20) : ((size_t)8 << 20);
+    while (b < S && x_bytes / b > slice_target) b <<= 1;
     int lvl = 0;
     for (int t = S; t > b; t >>= 1) lvl++;
     const double rows = std::min((double)num_out_rows, st.groups);

@@ -235,10 +235,10 @@ typedef struct gnna_tuning {
     int pad_rows;         /* 1 = gather from a staged copy of the source rows whose row stride is
                              padded to a 128-byte-line-friendly size when the width calls for
                              it (e.g. 41 -> 48, 56 -> 64 floats), 2 = never, 0 = automatic (when
-                             a source row is gathered >= ~32 times; rows of <= 64 floats then also get
-                             a gap of their own size after every row -- stride 64 / 64 / 128 / 128 floats
-                             for 16 / 32 / 41 / 64 -- while the copy stays Infinity-Cache sized: 3-5 %
-                             off the gather), > 2 = this stride in floats (experiments) */
+                             a source row is gathered >= ~32 times; rows of 17..64 floats then start at
+                             multiples of twice their 128-byte lines -- stride 64 / 128 / 128 floats for
+                             32 / 41 / 64 -- while the copy stays Infinity-Cache sized: 2-6 % off the
+                             gather), > 2 = this stride in floats (experiments) */
     int stream_kernel;    /* 0/1 = the streaming kernel with the sliced (single-launch, stateless) schedule
                              where it applies (rows of >= 4 floats, unweighted or pre-scaled gather, no
                              source windows), 2 = always the chunk-walk kernel with per-launch column
