@@ -247,6 +247,16 @@ scale_rows_kernel(const float *__restrict__ X, const float *__restrict__ deg, fl
             const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X) + i);
             reinterpret_cast<f32x4 *>(Xs)[i] = deg ? v * deg[i / d4] : v;
         }
+    } else if ((D & 3) == 0 && (ld_out & 3) == 0 &&
+               ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xs)) & 15) == 0) {
+        // padded / gapped layout of rows whose width is a whole number of 16-byte pieces: one vector per thread
+        const size_t n4 = ((size_t)rows * (size_t)D) >> 2;
+        const unsigned d4 = (unsigned)D >> 2, ld4 = (unsigned)ld_out >> 2;
+        for (size_t i = tid; i < n4; i += nthreads) {
+            const size_t r = i / d4;
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X) + i);
+            reinterpret_cast<f32x4 *>(Xs)[r * ld4 + (i - r * d4)] = deg ? v * deg[r] : v;
+        }
     } else {
         const size_t total = (size_t)rows * (size_t)D;
         for (size_t i = tid; i < total; i += nthreads) {
