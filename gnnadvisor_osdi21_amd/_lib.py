@@ -45,7 +45,8 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
-           "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32")
+           "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
+           "gnna_forget_graph")
 
 
 def load() -> ctypes.CDLL:
@@ -121,6 +122,8 @@ def load() -> ctypes.CDLL:
                                      ctypes.POINTER(ctypes.c_int), ctypes.c_void_p]
     L.gnna_release_graph.restype = ctypes.c_int
     L.gnna_release_graph.argtypes = [ctypes.c_void_p]
+    L.gnna_forget_graph.restype = ctypes.c_int
+    L.gnna_forget_graph.argtypes = [ctypes.c_void_p]
     L.gnna_runtime_counters.restype = None
     L.gnna_runtime_counters.argtypes = [ctypes.POINTER(ctypes.c_int64)]
     L.gnna_profile_begin.restype = ctypes.c_int
@@ -180,8 +183,9 @@ def _forget_when_freed(column_index) -> None:
         if _registered.get(ptr) is token:
             del _registered[ptr]
             if _lib is not None:
-                _lib.gnna_set_graph_hints(ptr, 0, 0)
-                _lib.gnna_release_graph(ptr)
+                # (a finalizer runs whenever and wherever the garbage collector does: unlink only, free later --
+                # gnna_release_graph would hipFree here, a device-wide synchronisation that breaks a capture in progress)
+                _lib.gnna_forget_graph(ptr)
     weakref.finalize(storage, drop)
 
 
@@ -405,7 +409,10 @@ def prepare_graph(column_index, part_pointers, part2Node, num_in_rows: int, num_
                   dims=()) -> dict:
     """gnna_prepare_graph: counting pass, statistics, phase choice per width and scratch sizing up front (one stream
     synchronisation here, none in any later aggregation on this graph); the plan stays until the column_index storage
-    is freed or `release_graph`.  -> {dim: phases the library will use}."""
+    is freed or `release_graph`.  CONTRACT: from here until the release, `column_index`, `part_pointers` and `part2Node`
+    must not be rewritten in place -- the plan keeps a copy of the ids in the order the kernels read them (a sample
+    checksum notices a rewritten buffer, not a few changed entries; `set_tuning(pack_ids=2)` turns the copy off).
+    -> {dim: phases the library will use}."""
     dims = [int(d) for d in dims]
     arr = (ctypes.c_int * max(1, len(dims)))(*dims)
     out = (ctypes.c_int * max(1, len(dims)))()

@@ -94,7 +94,7 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
     if (blockIdx.x >= fill_blocks) {
         if (threadIdx.x < kWave) {
             const unsigned long long then = *chk_sum;
-            const unsigned long long now = sample_checksum(chk_ids, chk_n, (int)threadIdx.x);
+            const unsigned long long now = graph_checksum(chk_ids, chk_n, pp, P, (int)threadIdx.x);
             if (threadIdx.x == 0 && now != then) *stale_flag = seq;
         }
         return;
@@ -808,6 +808,7 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     DeviceState *ds = nullptr;
     int rc = get_device_state(&ds);
     if (rc != GNNA_OK) return rc;
+    LaunchGuard in_flight;      // plans dropped by another thread stay allocated until this call has enqueued its kernels
 
     gnna_tuning tune;
     gnna_get_tuning(&tune);
@@ -1145,6 +1146,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
     DeviceState *ds = nullptr;
     int rc = get_device_state(&ds);
     if (rc != GNNA_OK) return rc;
+    drain_dead_buffers();       // (this call may synchronise and allocate: the place to free what finalizers left behind)
     SlicePlan plan;
     rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, true, &plan);
     if (rc != GNNA_OK) return rc;
@@ -1211,7 +1213,14 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
 
 int gnna_release_graph(const int32_t *column_index)
 {
-    (void)release_slice_plans(column_index);
+    (void)release_slice_plans(column_index, false);
+    return gnna_set_graph_hints(column_index, 0, 0);
+}
+
+int gnna_forget_graph(const int32_t *column_index)
+{
+    if (!column_index) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_forget_graph: null (gnna_release_graph(NULL) drops everything)");
+    (void)release_slice_plans(column_index, true);
     return gnna_set_graph_hints(column_index, 0, 0);
 }
 

@@ -170,6 +170,18 @@ __device__ __forceinline__ unsigned long long sample_checksum(const int32_t *__r
     return sum;
 }
 
+// What a packed copy of the ids remembers about the graph it was made from: samples of column_index AND of part_pointers
+// (the item starts of the copy are derived from the latter; its last entry -- the edge count -- is always among the
+// samples' end points) -- 1024 + 1024 entries, so a buffer that was rewritten is noticed, a few changed entries are not.
+__device__ __forceinline__ unsigned long long graph_checksum(const int32_t *__restrict__ ids, int64_t n,
+                                                             const int32_t *__restrict__ pp, int64_t P, int lane)
+{
+    const unsigned long long a = sample_checksum(ids, n, lane);
+    const unsigned long long b = sample_checksum(pp, P + 1, lane);
+    const unsigned long long last = (unsigned long long)(uint32_t)pp[P];
+    return a ^ ((b + last) * 0x9E3779B97F4A7C15ull);
+}
+
 }  // namespace gnna
 
 #endif  // GNNA_DEVICE_H_

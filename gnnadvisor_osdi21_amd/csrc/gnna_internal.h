@@ -103,7 +103,20 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
                    const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum = nullptr,
                    int64_t *num_ids = nullptr);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
-int release_slice_plans(const void *column_index);
+// deferred: the device buffers are not freed now (no synchronisation: safe from a finalizer on any thread, during a
+// stream capture) but at the next gnna_prepare_graph / gnna_release_graph / plan allocation with no launch in flight.
+int release_slice_plans(const void *column_index, bool deferred);
+void drain_dead_buffers();
+// An aggregation call holds plan buffers between looking them up and enqueueing its kernels: dropped plans are not freed
+// in between (RAII: LaunchGuard).
+void begin_launch();
+void end_launch();
+struct LaunchGuard {
+    LaunchGuard() { begin_launch(); }
+    ~LaunchGuard() { end_launch(); }
+    LaunchGuard(const LaunchGuard &) = delete;
+    LaunchGuard &operator=(const LaunchGuard &) = delete;
+};
 // Number of phases of the sliced schedule from the statistics of the partition (gnna_agg.hip).
 int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
                   bool square, bool hinted_scattered);

@@ -720,9 +720,10 @@ item_pack_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp
 }
 
 __global__ void __launch_bounds__(kWave)
-ids_checksum_kernel(const int32_t *__restrict__ col, int64_t n, unsigned long long *__restrict__ out)
+ids_checksum_kernel(const int32_t *__restrict__ col, int64_t n, const int32_t *__restrict__ pp, int64_t P,
+                    unsigned long long *__restrict__ out)
 {
-    const unsigned long long v = sample_checksum(col, n, (int)threadIdx.x);
+    const unsigned long long v = graph_checksum(col, n, pp, P, (int)threadIdx.x);
     if (threadIdx.x == 0) *out = v;
 }
 
@@ -756,7 +757,9 @@ struct Plan {
     };
     std::vector<Packed> packed;
     uint64_t pack_lookups = 0;
+    uint64_t pack_no_memory_until = 0;   // lookups below this do not try to build a copy (the last build's hipMalloc failed)
 };
+constexpr uint64_t kPackedNoMemoryBackoff = 1024;
 constexpr int kMaxPacked = 4;   // copies per plan (a GCN / GIN model aggregates at two or three widths)
 constexpr uint64_t kPackedKeep = 16;   // a copy looked up within the plan's last 16 lookups is not replaced at a launch (no build storms
                                        // when more phase counts than copies are in use in turn: the extra ones read column_index)
@@ -771,6 +774,20 @@ constexpr int kColdStreak = 8;
 int g_cold_evictions = 0;
 int g_skip_builds = 0;
 std::atomic<long long> g_counters[CTR_COUNT];
+
+// Device buffers of plans that were dropped while freeing them was not safe -- by gnna_forget_graph (a finalizer may run
+// on any thread at any time: hipFree synchronises the device and would invalidate a stream capture in progress), or
+// while another thread was between looking a plan up and enqueueing the kernel that reads it.  Freed at the next point
+// where the library may synchronise anyway and no aggregation call is in flight.
+std::vector<void *> g_dead;
+std::atomic<int> g_in_flight{0};
+
+void drain_dead_locked(int allowed_in_flight)
+{
+    if (g_dead.empty() || g_in_flight.load(std::memory_order_acquire) > allowed_in_flight) return;
+    for (void *ptr : g_dead) (void)hipFree(ptr);     // (hipFree waits for the device: kernels still reading it finish first)
+    g_dead.clear();
+}
 
 size_t stats_offset(int64_t P) { return (((size_t)P * (size_t)(kMaxSlices - 1)) + 255) & ~(size_t)255; }
 
@@ -859,6 +876,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
             count_event(CTR_LAUNCH_SYNCS);
         }
         if (pl->bytes < bytes) {
+            drain_dead_locked(1);                            // (about to allocate anyway; this call is the one in flight)
             if (pl->cnt) { (void)hipFree(pl->cnt); count_event(CTR_LAUNCH_FREES); }
             pl->cnt = nullptr; pl->bytes = 0;
             hipError_t e = hipMalloc(reinterpret_cast<void **>(&pl->cnt), bytes);
@@ -924,7 +942,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
     return GNNA_OK;
 }
 
-int release_slice_plans(const void *column_index)
+int release_slice_plans(const void *column_index, bool deferred)
 {
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     int dropped = 0;
@@ -932,20 +950,35 @@ int release_slice_plans(const void *column_index)
     for (size_t i = 0; i < g_plans.size();) {
         Plan *pl = g_plans[i];
         if (column_index && pl->col != column_index) { i++; continue; }
-        if (pl->cnt) (void)hipFree(pl->cnt);             // (hipFree waits for the device: kernels still reading it finish first)
+        if (pl->cnt) g_dead.push_back(pl->cnt);
         if (pl->ready) (void)hipEventDestroy(pl->ready);
         for (auto &pk : pl->packed) {
-            if (pk.ids) (void)hipFree(pk.ids);
+            if (pk.ids) g_dead.push_back(pk.ids);
             if (pk.ready) (void)hipEventDestroy(pk.ready);
         }
         delete pl;
         g_plans.erase(g_plans.begin() + (long)i);
         dropped++;
     }
+    if (!deferred) drain_dead_locked(0);
     return dropped;
 }
 
-void drop_slice_plans() { (void)release_slice_plans(nullptr); }
+void begin_launch()
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);     // (ordered against a drain's check of the counter)
+    g_in_flight.fetch_add(1, std::memory_order_acq_rel);
+}
+
+void end_launch() { g_in_flight.fetch_sub(1, std::memory_order_acq_rel); }
+
+void drain_dead_buffers()
+{
+    std::lock_guard<std::mutex> lock(g_plan_mutex);
+    drain_dead_locked(0);
+}
+
+void drop_slice_plans() { (void)release_slice_plans(nullptr, false); }
 
 // Packed ids of a plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
 // capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
@@ -976,6 +1009,7 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         }
     }
     if (!may_build || cap != hipStreamCaptureStatusNone) return GNNA_OK;
+    if (!force && pl->pack_lookups < pl->pack_no_memory_until) return GNNA_OK;   // a recent build ran out of memory
     const int64_t num_chunks = (pl->P + G - 1) / G;
     const int64_t items = num_chunks * B;
     // nnz: from the counting pass's statistics (every prepared plan has them); a plan counted without statistics (forced
@@ -998,11 +1032,13 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         pl->packed.emplace_back();
         slot = &pl->packed.back();
     } else {
-        for (auto &pk : pl->packed) if (!slot || pk.stamp < slot->stamp) slot = &pk;
-        if (!force && pl->pack_lookups - slot->stamp < kPackedKeep) return GNNA_OK;   // every copy is in recent use: none for this one
-        (void)hipDeviceSynchronize();           // kernels of any stream may still read the copy that goes
-        count_event(CTR_LAUNCH_SYNCS);
-        if (slot->ids) { (void)hipFree(slot->ids); count_event(CTR_LAUNCH_FREES); }
+        for (auto &pk : pl->packed) if (!slot || !pk.ids || (slot->ids && pk.stamp < slot->stamp)) slot = &pk;
+        if (slot->ids) {
+            if (!force && pl->pack_lookups - slot->stamp < kPackedKeep) return GNNA_OK;   // every copy is in recent use: none for this one
+            (void)hipDeviceSynchronize();           // kernels of any stream may still read the copy that goes
+            count_event(CTR_LAUNCH_SYNCS);
+            (void)hipFree(slot->ids); count_event(CTR_LAUNCH_FREES);
+        }
         slot->ids = nullptr; slot->item_off = nullptr;
     }
     const size_t id_bytes = (((size_t)nnz * sizeof(int32_t)) + 255) & ~(size_t)255;
@@ -1011,9 +1047,16 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     e = hipMalloc(reinterpret_cast<void **>(&slot->ids), bytes);
     count_event(CTR_LAUNCH_MALLOCS);
     if (e != hipSuccess) {
-        slot->ids = nullptr; slot->B = 0;
+        // no memory for the copy: the ids are read from column_index.  The slot does not stay behind as an empty entry (four
+        // of them would send every later launch through the replace-the-oldest branch: a device synchronisation and
+        // another failing hipMalloc each time), and this plan stops trying for a while
         (void)hipGetLastError();
-        return GNNA_OK;                          // no memory for the copy: the ids are read from column_index
+        slot->ids = nullptr; slot->item_off = nullptr; slot->B = 0; slot->G = 0;
+        if (slot->ready) { (void)hipEventDestroy(slot->ready); slot->ready = nullptr; }
+        if (slot == &pl->packed.back()) pl->packed.pop_back();
+        else slot->stamp = pl->pack_lookups;
+        pl->pack_no_memory_until = pl->pack_lookups + kPackedNoMemoryBackoff;
+        return GNNA_OK;
     }
     slot->item_off = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(slot->ids) + id_bytes);
     slot->checksum = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(slot->ids) + id_bytes + off_bytes);
@@ -1026,7 +1069,8 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, stream, slot->item_off, items);
     hipLaunchKernelGGL(item_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col),
                        static_cast<const int32_t *>(pl->pp), pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off, slot->ids);
-    hipLaunchKernelGGL(ids_checksum_kernel, dim3(1), dim3(kWave), 0, stream, static_cast<const int32_t *>(pl->col), nnz, slot->checksum);
+    hipLaunchKernelGGL(ids_checksum_kernel, dim3(1), dim3(kWave), 0, stream, static_cast<const int32_t *>(pl->col), nnz,
+                       static_cast<const int32_t *>(pl->pp), pl->P, slot->checksum);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids launch: %s", hipGetErrorString(e));
     (void)hipEventRecord(slot->ready, stream);

@@ -31,7 +31,8 @@
 //     from the fabric (sets per workgroup) x 8 times per aggregation.  Only locality depends on that barrier,
 //     never the result: a workgroup that waits too long stops waiting for the rest of the launch;
 //   * rows beyond the accumulators' capacity (a set of many low-degree rows), and every row of a partition that
-//     is not canonical, are flushed the old way (atomics per slice), which is correct for any partition.
+//     is not canonical, are flushed the old way (atomics per slice), which is correct for any partition (the sets of
+//     such a partition are equal shares of the groups, not found by a search in its part_pointers).
 //
 // The per-(chunk, slice) item is the streaming kernel's: descriptors -> pieces -> load list -> U row loads
 // always in flight -> fold at the last load of a row piece.
@@ -188,7 +189,10 @@ sweep_kernel(const SweepParams p)
             const int64_t i = set + wib;
             // (nnz < 2^31 and sets < 2^31: the product fits 64 bits)
             const int64_t target = i >= num_sets ? nnz : (nnz * i) / num_sets;
-            int64_t g = i <= 0 ? 0 : (i >= num_sets ? p.P : lower_bound64(p.pp, p.P, target, lane));
+            // (a partition that is not canonical may hold a part_pointers array no search can be trusted on: its sets
+            // are equal shares of the GROUPS -- every group then flushes per slice anyway; P < 2^31 groups x < 2^21 sets)
+            int64_t g = i <= 0 ? 0 : (i >= num_sets ? p.P : (canonical ? lower_bound64(p.pp, p.P, target, lane)
+                                                                        : (p.P * i) / num_sets));
             if (p.ids_packed && g < p.P) g &= ~(int64_t)(kWave - 1);
             if (lane == 0) s_g[wib] = g;
         }

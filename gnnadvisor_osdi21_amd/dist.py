@@ -176,10 +176,18 @@ class ShardedAggregator:
                  aggregate_fn: Optional[Callable] = None, build_part_fn: Optional[Callable] = None,
                  overlap: bool = True, force_overlap: bool = False,
                  hint_fn: Optional[Callable] = None, scattered_sources: bool = True,
-                 pipeline_chunks: int = 0, exchange: str = "allgather", emulate: Optional[tuple] = None):
+                 pipeline_chunks: int = 0, exchange: str = "allgather", emulate: Optional[tuple] = None,
+                 force_collectives: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # force_collectives (debug / bring-up): with ONE rank every collective of the N-rank step is still issued
+        # through the process group -- all_gather_into_tensor (whole and K pieces into adjacent views),
+        # all_to_all_single with split lists, the all-reduces of the set-up decisions and of dW -- so that the RCCL
+        # path can be executed, ordered against the library's launches and checked on a single GPU.  The rank's own
+        # block then plays both roles: sources in its first half are "local", sources in its second half are
+        # "remote" and travel through the collective (to the rank itself) before the remote part reads them.
+        self.force_collectives = bool(force_collectives) and dist.is_initialized() and self.world == 1 and emulate is None
         # emulate = (rank, world): this process plays ONE rank of a `world`-rank job without a process group -- the
         # shard, its local / remote split, the halo lists and the piece CSRs are built exactly as that rank would
         # build them; only the collectives are missing (the receive buffers are filled by `emulated_receive`).
@@ -193,12 +201,14 @@ class ShardedAggregator:
         self.n_local = self.bounds[self.rank + 1] - self.bounds[self.rank]
         assert local_row_pointers.numel() == self.n_local + 1
         self.rows_per_rank = max(1, max(self.bounds[i + 1] - self.bounds[i] for i in range(self.world)))
-        self.overlap = bool(overlap) and (self.world > 1 or force_overlap)
+        self.overlap = bool(overlap) and (self.world > 1 or force_overlap or self.force_collectives)
+        # collectives: does a step talk to the process group at all
+        self.collectives = (self.world > 1 and emulate is None) or self.force_collectives
         # pipelined exchange: K all-gathers of 1/K of every block, each aggregated on arrival
         # (0 = automatic: 4 pieces once the remote part is big enough to keep every piece busy)
         assert exchange in ("allgather", "halo", "auto")
         self.device = torch.device(device) if device is not None else column_index.device
-        if exchange != "allgather" and self.world > 1:
+        if exchange != "allgather" and (self.world > 1 or self.force_collectives):
             self.overlap = True                                  # the halo buffer holds remote rows only
         K = int(pipeline_chunks)
         if K <= 0:
@@ -220,6 +230,8 @@ class ShardedAggregator:
             exposed_us = self._agree_max(mine_us)
             largest = self._agree_max(remote_edges)
             K = 4 if (self.world > 1 and largest >= (16 << 20) and exposed_us > 0) else 1
+            if self.force_collectives:
+                K = 1      # (one rank: nothing to hide; ask for pieces explicitly with pipeline_chunks)
         self.chunks = max(1, min(K, 16, self.rows_per_rank)) if self.overlap else 1
         assert self._agree_max(self.chunks) == self.chunks == -self._agree_max(-self.chunks), \
             "ranks disagree on the number of exchange pieces"
@@ -246,6 +258,9 @@ class ShardedAggregator:
         # local-source / remote-source split for the overlapped schedule
         if self.overlap:
             lo, hi = self.bounds[self.rank], self.bounds[self.rank + 1]
+            if self.force_collectives:
+                hi = lo + (hi - lo) // 2                         # the second half of the own block is "remote"
+            self.local_rows = hi - lo                            # source rows the local part reads (of X_local)
             rp_l, ci_l, rp_r, ci_r = split_local_remote(local_row_pointers.to(self.device),
                                                         column_index.to(self.device), lo, hi)
             pp_l, p2n_l = build_part_fn(self.partSize, rp_l.cpu().contiguous())
@@ -305,7 +320,7 @@ class ShardedAggregator:
     # ---- collective set-up decisions ------------------------------------------------------------
     def _agree_max(self, value: int) -> int:
         """max of an integer over the ranks of the group (identity without a process group)."""
-        if self.emulated or not (dist.is_initialized() and self.world > 1):
+        if self.emulated or not (dist.is_initialized() and (self.world > 1 or self.force_collectives)):
             return int(value)
         on_gpu = dist.get_backend(self.group) == "nccl"
         t = torch.tensor([int(value)], dtype=torch.int64, device=self.device if on_gpu else "cpu")
@@ -321,11 +336,13 @@ class ShardedAggregator:
         ids of the remote-source edges of this shard."""
         self.halo_rows = 0
         self.remote_rows = self.world * self.rows_per_rank       # rows of the buffer the remote part reads
-        if exchange == "allgather" or self.world == 1:
+        if exchange == "allgather" or not (self.world > 1 or self.force_collectives):
             return "allgather"
         uniq = torch.unique(ci_remote_global.to(torch.int64))    # sorted => grouped by owner
         worst = self._agree_max(int(uniq.numel()))
-        if exchange == "auto" and worst > 0.7 * (self.world - 1) * self.rows_per_rank:
+        # rows a peer set could ask for at most (one forced rank: the "remote" half of its own block)
+        candidates = (self.world - 1) * self.rows_per_rank if self.world > 1 else self.n_local - self.n_local // 2
+        if exchange == "auto" and worst > 0.7 * candidates:
             return "allgather"                                   # nearly everything is referenced anyway
         K, world = self.chunks, self.world
         b = torch.as_tensor(self.bounds, dtype=torch.int64, device=uniq.device)
@@ -461,18 +478,21 @@ class ShardedAggregator:
         return [X_local.index_select(0, self._send_index[k]) for k in range(self.chunks)]
 
     def bytes_received_per_step(self, dim: int) -> int:
-        """Feature bytes this rank receives from its peers per aggregation."""
-        if self.world == 1:
+        """Feature bytes this rank receives from its peers per aggregation (forced one-rank collectives: the bytes the
+        rank sends to itself)."""
+        if not (self.world > 1 or self.force_collectives):
             return 0
         if self.exchange == "halo":
             return self.halo_rows * dim * 4
-        return (self.world - 1) * self.rows_per_rank * dim * 4
+        return max(1, self.world - 1) * self.rows_per_rank * dim * 4
 
     def allgather_bytes_per_step(self, dim: int) -> int:
+        if self.force_collectives:
+            return self.rows_per_rank * dim * 4
         return (self.world - 1) * self.rows_per_rank * dim * 4 if self.world > 1 else 0
 
     def describe_exchange(self) -> str:
-        if self.world == 1:
+        if not (self.world > 1 or self.force_collectives):
             return "no exchange (one rank)"
         how = ("halo rows only (all_to_all_single of %d of %d remote rows)" % (self.halo_rows, (self.world - 1) * self.rows_per_rank)
                if self.exchange == "halo" else "all-gather of the feature blocks")
@@ -483,7 +503,7 @@ class ShardedAggregator:
         With async_op the collective's work handle is returned as well: (buffer, work)."""
         assert X_local.shape[0] == self.n_local
         D = X_local.shape[1]
-        if self.world == 1:
+        if not self.collectives:
             return (X_local, None) if async_op else X_local
         shape = (self.world * self.rows_per_rank, D)
         if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != X_local.device:
@@ -509,7 +529,7 @@ class ShardedAggregator:
                 self._pad_buf = torch.zeros(self.rows_per_rank, D, dtype=X_local.dtype, device=X_local.device)
             self._pad_buf[: self.n_local].copy_(X_local)
             src = self._pad_buf
-        if self.world == 1:
+        if not self.collectives:
             return src, [None] * K
         shape = (self.world * self.rows_per_rank, D)
         if self._gather_buf is None or self._gather_buf.shape != shape or self._gather_buf.device != X_local.device:
@@ -531,9 +551,9 @@ class ShardedAggregator:
                 if w is not None:
                     w.wait()
             self._deg_all = buf
-        elif self.world == 1 and self.chunks == 1:
+        elif not self.collectives and self.chunks == 1:
             self._deg_all = degrees_local
-        elif self.world == 1:
+        elif not self.collectives:
             pad = torch.ones(self.rows_per_rank, dtype=degrees_local.dtype, device=degrees_local.device)
             pad[: self.n_local] = degrees_local
             self._deg_all = pad
@@ -605,7 +625,7 @@ class ShardedAggregator:
     # ---- the two halves of a step on their own (bench.py reports them beside the overlapped step) ----------------
     def exchange_only(self, X_local: torch.Tensor) -> None:
         """The source-feature exchange of one aggregation, waited for, without any aggregation."""
-        if self.world == 1:
+        if not self.collectives:
             return
         if self.exchange == "halo":
             _, works = self.exchange_halo(X_local.contiguous())
@@ -627,10 +647,10 @@ class ShardedAggregator:
         if mode == 1:
             assert degrees_local is not None and deg_in is not None
         if not self.overlap:
-            X_all = X_local if (self.world == 1 and not self.emulated) else self._gather_buf
+            X_all = X_local if not (self.collectives or self.emulated) else self._gather_buf
             return self.aggregate_fn(mode, X_all, self.column_index, self.part_pointers, self.part2Node, self.n_local,
                                      self.partSize, degrees_local, deg_in, epsilon, out)
-        X_all = self._halo_buf if self.exchange == "halo" else (self._gather_buf if (self.world > 1 or self.emulated) else
+        X_all = self._halo_buf if self.exchange == "halo" else (self._gather_buf if (self.collectives or self.emulated) else
                                                                 (self._pad_buf if self._pad_buf is not None else X_local))
         ci_l, pp_l, p2n_l = self.local_part
         out = self.aggregate_fn(mode, X_local, ci_l, pp_l, p2n_l, self.n_local, self.partSize, degrees_local,
@@ -657,7 +677,7 @@ class ShardedAggregator:
         n_all = self.remote_rows if self.overlap else self.world * self.rows_per_rank
         if not self.overlap:
             return [(self.column_index, self.part_pointers, self.part2Node, n_all if self.world > 1 else self.n_local)]
-        parts = [self.local_part + (self.n_local,)]
+        parts = [self.local_part + (self.n_local,)]                  # (reads X_local: n_local rows)
         if self.chunks == 1:
             parts.append(self.remote_part + (n_all,))
         else:
@@ -733,8 +753,8 @@ def _xtg(X: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
     return torch.mm(X.t(), G)
 
 
-def _all_reduce_sum(t: torch.Tensor, group) -> torch.Tensor:
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+def _all_reduce_sum(t: torch.Tensor, group, force: bool = False) -> torch.Tensor:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -753,7 +773,7 @@ class ShardedGCNFunction(torch.autograd.Function):
         X_local, weight = ctx.saved_tensors
         G = ctx.agg.gcn(d_output.contiguous(), ctx.deg)          # Â dY, rows of this rank
         d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
-        d_weight = _all_reduce_sum(_xtg(X_local, G), ctx.agg.group)
+        d_weight = _all_reduce_sum(_xtg(X_local, G), ctx.agg.group, ctx.agg.force_collectives)
         return d_input, d_weight, None, None
 
 
@@ -771,7 +791,7 @@ class ShardedGINFunction(torch.autograd.Function):
     def backward(ctx, d_output):
         T, weight = ctx.saved_tensors
         d_output = d_output.contiguous()
-        d_weight = _all_reduce_sum(_xtg(T, d_output), ctx.agg.group)
+        d_weight = _all_reduce_sum(_xtg(T, d_output), ctx.agg.group, ctx.agg.force_collectives)
         d_input = None
         if ctx.needs_input_grad[0]:
             d_input = ctx.agg.gin(torch.mm(d_output, weight.t()), ctx.epsilon)
@@ -786,7 +806,7 @@ class _ShardedConv(torch.nn.Module):
         self.agg = agg
         bound = 1.0 / (output_dim ** 0.5)
         w = torch.empty(input_dim, output_dim, device=device or agg.device).uniform_(-bound, bound)
-        if dist.is_initialized() and dist.get_world_size(agg.group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(agg.group) > 1 or agg.force_collectives):
             dist.broadcast(w, src=dist.get_global_rank(agg.group, 0) if agg.group is not None else 0,
                            group=agg.group)
         self.weights = torch.nn.Parameter(w)

@@ -184,6 +184,11 @@ def load_graph_shard(path, rank: int, world: int, load_from_txt: bool = False, r
     remote sources per shard is what the halo exchange lives on."""
     t0 = time.perf_counter()
     src, dst, n = _edges if _edges is not None else read_edge_list(path, load_from_txt)
+    # node ids are int32 in the CSR and in the kernels: refuse ids that the cast below would wrap silently
+    top = int(max(np.max(src), np.max(dst))) if len(src) else -1
+    low = int(min(np.min(src), np.min(dst))) if len(src) else 0
+    if int(n) > 2**31 - 1 or top >= 2**31 - 1 or low < 0 or top >= int(n):
+        raise ValueError(f"node ids must lie in [0, num_nodes) with num_nodes < 2^31 (got ids {low}..{top}, num_nodes {n})")
     src = np.ascontiguousarray(src, dtype=np.int32)
     dst = np.ascontiguousarray(dst, dtype=np.int32)
     num_edges = int(len(src))

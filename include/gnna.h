@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 301 /* 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
+#define GNNA_VERSION 400 /* 0.4.0: gnna_forget_graph; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -312,6 +312,12 @@ GNNA_API int gnna_prepare_graph(const int32_t *column_index, const int32_t *part
                                 int64_t num_parts, int64_t num_in_rows, int64_t num_out_rows, int partSize,
                                 const int *dims, int num_dims, int *phases_out, void *stream);
 GNNA_API int gnna_release_graph(const int32_t *column_index);
+/* The same for callers that cannot choose their moment -- finalizers, garbage collectors, another thread while a stream is
+ * being captured: the graph's plans, hints and schedules are unlinked at once (no later call finds them), but nothing is
+ * freed and nothing synchronises here; the device buffers go at the next gnna_prepare_graph / gnna_release_graph, or when
+ * the library next allocates a plan, and never while another thread's aggregation call is between looking a plan up
+ * and enqueueing its kernels. */
+GNNA_API int gnna_forget_graph(const int32_t *column_index);
 
 /* Events of the library's launch path since load (for tests and monitoring):
  *   [0] counting passes run, [1] stream / device synchronisations inside aggregation calls, [2] hipFree and

@@ -82,3 +82,43 @@ def test_counter_rows_are_split_by_workload_and_calibrated_on_the_last_copies():
     # a child whose dispatch count does not match the schedule is not trusted
     short, _ = bench.split_counters(manifest, rows[:-6], "FETCH_SIZE")
     assert short[1] is None
+
+
+def test_roofline_frac_is_the_share_of_the_binding_ceiling():
+    """`roofline.frac` = max(measured fabric bytes / t / 8 TB/s, L2 requests x 128 B / t / 34.5 TB/s).  It must rise when
+    the same schedule runs faster, must not fall because a schedule moves fewer fabric bytes for the same requests, and
+    round 3's record (sweep kernel: 1.3858 ms, 3.89 GB, 229.2 M requests) re-derives to 0.61, round 2's (1.586 ms, 7.9 GB,
+    241.5 M requests) to 0.62 with the fabric binding."""
+    r3 = bench.binding_shares(3890224405.36, 229.2e6, 1.3858e-3)
+    assert r3["binding"] == "l2" and abs(r3["frac"] - 0.6136) < 1e-3 and abs(r3["frac_hbm_measured"] - 0.3509) < 1e-3
+    assert r3["frac"] == r3["achieved_binding"] / r3["peak_binding"] == r3["frac_l2"]
+    r2 = bench.binding_shares(7.9e9, 241.5e6, 1.586e-3)
+    assert r2["binding"] == "fabric" and abs(r2["frac"] - 0.6226) < 1e-3
+    # faster on the same schedule (same counters) -> larger frac
+    assert bench.binding_shares(3890224405.36, 229.2e6, 1.25e-3)["frac"] > r3["frac"]
+    # fewer fabric bytes for the same requests and time -> not smaller
+    assert bench.binding_shares(2.0e9, 229.2e6, 1.3858e-3)["frac"] == r3["frac"]
+    # no request counter: the fabric share alone
+    only = bench.binding_shares(25.4e9, None, 3.45e-3)
+    assert only["binding"] == "fabric" and only["frac_l2"] is None and abs(only["frac"] - 25.4e9 / 3.45e-3 / 8e12) < 1e-9
+
+
+def test_roofline_record_carries_flat_keys_for_the_drivers_parser():
+    class G:
+        nnz, num_nodes = 114623790, 232965
+
+    class W:
+        g, P, dim, launches, phases, swept = G, 1901647, 64, 1, 16, True
+    traffic = {"bytes_per_step": 3890224405.36, "l2_requests_per_step": 229.2e6, "l2_hit_rate": 0.8646}
+    rec = bench.roofline_record(W, 1.3858, 0.042, traffic, "l2-fabric")
+    assert rec["bound"] == "hbm" and rec["peak"] == 8000.0 and rec["unit"] == "GB/s"
+    assert abs(rec["frac"] - 0.6136) < 1e-3 and rec["binding"] == "l2"
+    for key in ("frac_hbm_measured", "frac_l2", "frac_gather_model_of_hbm", "achieved_binding", "peak_binding",
+                "l2_requests_per_edge", "traffic", "achieved"):
+        assert isinstance(rec[key], float), key
+    assert abs(rec["frac_gather_model_of_hbm"] - 29877969476 / 1.3858e-3 / 8e12) < 1e-6      # 2.69: not a fraction of HBM
+    assert abs(rec["achieved"] - 3890224405.36 / 1.3858e-3 / 1e9) < 1e-6                      # the measured fabric rate stays
+    assert abs(rec["l2_requests_per_edge"] - 2.0) < 0.01
+    # without counters nothing is invented
+    rec0 = bench.roofline_record(W, 1.3858, 0.042, {"error": "rocprofv3 not found"}, "l2-fabric")
+    assert rec0["traffic"] is None and rec0["frac_l2"] is None and "compulsory" in rec0["achieved_source"]

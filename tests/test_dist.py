@@ -386,3 +386,72 @@ def test_two_ranks_ingest_a_graph_file_and_match_the_single_process_result(tmp_p
         assert np.allclose(Yg, want_g[old], rtol=1e-4, atol=1e-2), rank
         covered += hi - lo
     assert covered == n
+
+
+def _forced_worker(rank, world, port, chunks, exchange, q):
+    """ONE rank, every collective of the N-rank step still issued through the process group (the bring-up switch for
+    RCCL on a single GPU, here over gloo): the second half of the rank's own block travels through all_gather_into_tensor
+    / all_to_all_single to the rank itself before the remote part reads it."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, e, dim = 150, 2400, 9
+        g = graph.powerlaw_graph(n, e, 60, seed=31)
+        bounds = [0, n]
+        X = torch.randn(n, dim, generator=torch.Generator().manual_seed(32))
+        calls = {"all_gather": 0, "all_to_all": 0, "all_reduce": 0}
+        real = (dist.all_gather_into_tensor, dist.all_to_all_single, dist.all_reduce)
+
+        def counted(name, fn):
+            def f(*a, **k):
+                calls[name] += 1
+                return fn(*a, **k)
+            return f
+        dist.all_gather_into_tensor = counted("all_gather", real[0])
+        dist.all_to_all_single = counted("all_to_all", real[1])
+        dist.all_reduce = counted("all_reduce", real[2])
+        try:
+            agg = ShardedAggregator(g.row_pointers, g.column_index, bounds, 4, aggregate_fn=_oracle_aggregate,
+                                    build_part_fn=_oracle_build_part, pipeline_chunks=chunks, exchange=exchange,
+                                    force_collectives=True)
+            assert agg.force_collectives and agg.collectives and agg.overlap and agg.chunks == chunks
+            assert agg.exchange == exchange
+            # both halves carry edges, and together they are the shard
+            assert agg.local_part[0].numel() > 0 and agg.remote_part[0].numel() > 0
+            assert agg.local_part[0].numel() + agg.remote_part[0].numel() == g.column_index.numel()
+            assert int(agg.local_part[0].max()) < n // 2
+            rpn, cin = g.row_pointers.numpy(), g.column_index.numpy()
+            ok = True
+            for rep in range(3):                       # buffers are reused from step to step
+                Ys = agg.sag(X)
+                Yg = agg.aggregate(X, 1, degrees_local=g.degrees)
+                Yi = agg.aggregate(X, 2, epsilon=0.5)
+                ok &= np.allclose(Ys.numpy(), oracle.csr_f64(0, X.numpy(), rpn, cin), atol=1e-4)
+                ok &= np.allclose(Yg.numpy(), oracle.csr_f64(1, X.numpy(), rpn, cin, g.degrees.numpy()), rtol=1e-4, atol=1e-2)
+                ok &= np.allclose(Yi.numpy(), oracle.csr_f64(2, X.numpy(), rpn, cin, None, 0.5), atol=1e-4)
+            agg.exchange_only(X)
+            y2 = agg.aggregate_only(X)
+            ok &= np.allclose(y2.numpy(), oracle.csr_f64(0, X.numpy(), rpn, cin), atol=1e-4)
+            # the collectives really ran: per aggregation `chunks` exchanges of the step's kind
+            kind = "all_to_all" if exchange == "halo" else "all_gather"
+            ok &= calls[kind] >= 10 * chunks
+            ok &= calls["all_reduce"] >= 1                      # the set-up decisions
+            # sharded layers: dW all-reduced through the group even with one rank
+            from gnnadvisor_osdi21_amd.dist import ShardedGCNConv
+            before = calls["all_reduce"]
+            layer = ShardedGCNConv(dim, 4, agg, device="cpu")
+            Xg = X.clone().requires_grad_(True)
+            layer(Xg, g.degrees).sum().backward()
+            ok &= calls["all_reduce"] == before + 1 and bool(torch.isfinite(layer.weights.grad).all())
+        finally:
+            dist.all_gather_into_tensor, dist.all_to_all_single, dist.all_reduce = real
+        q.put((rank, bool(ok), dict(calls)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks,exchange", [(1, "allgather"), (3, "allgather"), (1, "halo"), (2, "halo")])
+def test_one_rank_with_forced_collectives_matches_the_whole_graph(chunks, exchange):
+    res = _run_ranks(_forced_worker, (chunks, exchange), world=1)
+    assert all(ok for _, ok, *_ in res), res
