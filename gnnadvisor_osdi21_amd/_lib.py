@@ -46,7 +46,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
            "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
-           "gnna_forget_graph")
+           "gnna_forget_graph", "gnna_agg_ld_f32")
 
 
 def load() -> ctypes.CDLL:
@@ -81,6 +81,11 @@ def load() -> ctypes.CDLL:
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                     ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.gnna_agg_ld_f32.restype = ctypes.c_int
+    L.gnna_agg_ld_f32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
+                                  ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
     L.gnna_agg_rect_windows_f32.restype = ctypes.c_int
     L.gnna_agg_rect_windows_f32.argtypes = (L.gnna_agg_rect_f32.argtypes[:-1]
                                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
@@ -402,6 +407,42 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
                                         part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
                                         int(num_out_rows), X.shape[1], part2Node.numel(), int(partSize),
                                         1 if accumulate else 0, _stream(X.device)))
+    return out
+
+
+ACCUMULATE, EPILOGUE_RELU = 1, 2
+
+
+def _rows_view(t: torch.Tensor, what: str):
+    """(data pointer, rows, dim, leading dimension) of a 2-D float32 device tensor whose rows are contiguous."""
+    assert t.dtype == torch.float32 and t.dim() == 2, f"{what} must be a 2-D float32 tensor"
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise GnnaError(f"{what}: the floats of a row must be contiguous (stride(1) == 1)")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+    if ld < t.shape[1]:
+        raise GnnaError(f"{what}: rows overlap (stride(0) = {t.stride(0)} < {t.shape[1]})")
+    return t.data_ptr(), t.shape[0], t.shape[1], ld
+
+
+def agg_ld(mode, X, column_index, part_pointers, part2Node, num_out_rows, partSize=32, degrees_out=None,
+           degrees_in=None, epsilon=1.0, out=None, accumulate=False, relu=False):
+    """gnna_agg_ld_f32: the rectangular aggregation with leading dimensions and the ReLU epilogue.  `X` and `out` may be
+    row-strided views (a column block ``M[:, a:b]``, a padded buffer ``P[:, :dim]``): stride(1) must be 1, stride(0) is
+    handed over as the leading dimension.  relu: out = max(out, 0) after the aggregation."""
+    if not X.is_cuda:
+        raise GnnaError("aggregation needs device tensors: there is no CPU path in libgnna")
+    xp, n_in, dim, ld_in = _rows_view(X, "X")
+    if out is None:
+        assert not accumulate, "accumulate needs an existing `out`"
+        out = _fresh_output((num_out_rows, dim), X.device)
+    yp, n_out, dim_o, ld_out = _rows_view(out, "out")
+    assert n_out == int(num_out_rows) and dim_o == dim and out.device == X.device
+    flags = (ACCUMULATE if accumulate else 0) | (EPILOGUE_RELU if relu else 0)
+    with torch.cuda.device(X.device):
+        _check(load().gnna_agg_ld_f32(int(mode), xp, ld_in, n_in, column_index.data_ptr(), _ptr(degrees_out),
+                                      _ptr(degrees_in), float(epsilon), part_pointers.data_ptr(), part2Node.data_ptr(),
+                                      yp, ld_out, int(num_out_rows), dim, part2Node.numel(), int(partSize), flags,
+                                      _stream(X.device)))
     return out
 
 

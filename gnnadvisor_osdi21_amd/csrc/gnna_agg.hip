@@ -1,40 +1,21 @@
-// gnna_agg.hip -- CDNA4 (gfx950) neighbor-group aggregation kernels + C-ABI launchers.
+// gnna_agg.hip -- the aggregation entry points of the C ABI (include/gnna.h) and what surrounds the two
+// aggregation kernels: prologue (zero-fill + partition validation), row staging / GCN pre-scaling, the choice of the
+// schedule (phases of the sliced schedule, streaming or sweep kernel), the graph lifecycle.  CDNA4 / gfx950 only.
 //
-// Replaces the five CUDA kernels of the reference (GNNAdvisor/GNNConv/GNNAdvisor_kernel.cu:
-// SAG :186-259, GCN fwd :324-415, GCN bwd :478-552, GIN fwd :620-689, GIN bwd :749-814) with
-// one templated HIP kernel.  Not a translation: see DESIGN.md "Kernel".
+// Replaces the host launchers of the reference (GNNAdvisor/GNNConv/GNNAdvisor_kernel.cu: SAG_cuda :110-184, the
+// aggregation halves of spmm_forward_cuda :282-322, spmm_backward_cuda :436-470, spmm_forward_cuda_gin :575-603,
+// spmm_backward_cuda_gin :712-744).  The kernels themselves: stream_kernel (gnna_stream.hip) and sweep_kernel
+// (gnna_sweep.hip); the chunk-walk kernel of round 1 that used to live here was retired in 0.4.0 (rows narrower than 4
+// floats and the windowed entry run on stream_kernel now).
 //
-// Shape of the computation (all three modes):
-//   out[part2Node[p], :] += sum_{e in [partPtr[p], partPtr[p+1])} coef * X[colidx[e], :]
-//
-// CDNA4 mapping
-//   * a 64-lane wavefront owns a *chunk* of G consecutive neighbor-groups.  Groups of one
-//     destination row are adjacent (build_part emits them consecutively), so a run of
-//     same-row groups is one contiguous edge segment that the wave reduces in registers;
-//     only a row that continues into a neighbouring chunk needs atomics.
-//   * lanes are laid out (slot, c): c = lane % LPR addresses a VEC-float piece of the
-//     feature row, slot = lane / LPR addresses one of RPI = 64/LPR neighbor rows, so one
-//     wave-wide global_load_dwordx4 fetches RPI complete, fully coalesced rows (D=64:
-//     4 rows = 1 KiB per instruction).  U such loads are issued back-to-back before the
-//     first add (memory-level parallelism; the kernel is gather-bandwidth bound).
-//   * column ids are fetched 64 at a time with one coalesced non-temporal load and
-//     handed to the slots with ds_bpermute; partial rows live in VGPRs (the reference's
-//     shared-memory read-modify-write chain, .cu:245-249, is what it is bound by).
-//   * slots are folded once per destination row as a reduce-scatter with v_permlane32_swap /
-//     v_permlane16_swap (3 swaps + 3 adds leave every lane with one float of the row) and DPP
-//     row rotations for narrow rows.
-//   * flush: plain (non-temporal) vector store when the row is wholly owned by the wave,
-//     hardware global_atomic_add_f32 only for rows shared with a neighbouring chunk.
-//   * a prologue kernel zero-fills `out` and checks that the partition is canonical
-//     (part2Node and partPtr non-decreasing); if it is not, every group is flushed with
-//     atomics, which is correct for any partition.
-//   * column phases (PHASED): the kernel is launched once per source-id range so that the slice of
-//     X being gathered is cache resident; every run keeps a cursor (next unconsumed edge) between
-//     the launches.  The windowed entry point runs a sub-range of those launches per call
-//     (pipelined multi-GPU exchange).
-//   * row staging: for widths whose rows straddle 128-byte lines (41, 47, 56 ...) and for the
-//     pre-scaled GCN form the source rows are first copied into scratch with a line-friendly
-//     row stride (and multiplied by their degree norm); the kernel takes the stride as `ldx`.
+// Shape of the computation (all modes):
+//   out[part2Node[p], :] (+)= coef * sum_{e in [partPtr[p], partPtr[p+1])} X[colidx[e], :]
+//   * a prologue kernel zero-fills `out` and checks that the partition is canonical (part2Node and partPtr
+//     non-decreasing); if it is not, every group is flushed with atomics, which is correct for any partition;
+//   * row staging: for widths whose rows straddle 128-byte lines (41, 47, 56 ...), for hot rows of one or two lines
+//     (every row on its own 256- / 512-byte boundary) and for the pre-scaled GCN form the source rows are first copied
+//     into library scratch with a line-friendly row stride (and multiplied by their degree norm); the kernels take the
+//     stride as `ldx`.  A caller that hands over such a layout itself (gnna_agg_ld_f32, ld_in) is gathered from directly.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -49,40 +30,10 @@
 namespace gnna {
 namespace {
 
-struct AggParams {
-    const float *X;
-    const int32_t *col;
-    const float *deg_row;  // per destination row (GCN)
-    const float *deg_col;  // per source row (GCN)
-    const int32_t *pp;
-    const int32_t *p2n;
-    float *Y;
-    int64_t P;           // number of neighbor-groups
-    int64_t num_chunks;  // ceil(P / G)
-    int64_t num_items;   // ceil(num_chunks / waves per block)
-    int64_t items_per_xcd;
-    const int32_t *flag; // *flag == seq  <=>  partition is NOT canonical
-    int32_t seq;
-    int32_t trust;
-    int32_t D;
-    int32_t ldx;  // row stride of X in floats (== D unless the rows were staged into a padded layout)
-    int32_t G;
-    int32_t xcd_remap;
-    float eps;
-    // column-phased schedule (num_phases > 1): this launch consumes, for every run, the
-    // edges from the run's cursor up to the first source id >= phase_hi
-    int32_t *cursor;   // [P] next unconsumed edge of the run starting at that group
-    int32_t phase;
-    int32_t num_phases;
-    int32_t phase_hi;
-    int32_t acc_in;  // 1: add to the existing contents of Y instead of overwriting (no zero-fill)
-    const float *row_scale;  // MODE_GIN only: optional per-destination-row factor on top of eps
-};
-
 // ---- prologue: zero-fill + partition validation ------------------------------------------
 
 __global__ void __launch_bounds__(kBlock)
-prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restrict__ p2n,
+prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, int ldy, const int32_t *__restrict__ p2n,
                 const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate, int zero_fill,
                 const int32_t *__restrict__ chk_ids, int64_t chk_n, const unsigned long long *__restrict__ chk_sum,
                 int32_t *stale_flag)
@@ -104,6 +55,22 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
     typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (!zero_fill) {
         // accumulate mode: Y keeps its contents
+    } else if (ldy != D) {
+        // rows `ldy` floats apart (the caller's leading dimension): only the D floats of every row are the library's
+        if ((D & 3) == 0 && (ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
+            const size_t n4 = n_floats >> 2;
+            const unsigned d4 = (unsigned)D >> 2, ld4 = (unsigned)ldy >> 2;
+            const f32x4 z = (f32x4)(0.f);
+            for (size_t i = tid; i < n4; i += nthreads) {
+                const size_t r = i / d4;
+                reinterpret_cast<f32x4 *>(Y)[r * ld4 + (i - r * d4)] = z;
+            }
+        } else {
+            for (size_t i = tid; i < n_floats; i += nthreads) {
+                const size_t r = i / (unsigned)D;
+                Y[r * (size_t)ldy + (i - r * (unsigned)D)] = 0.f;
+            }
+        }
     } else if ((reinterpret_cast<uintptr_t>(Y) & 15) == 0) {
         const size_t n4 = n_floats >> 2;
         f32x4 *Y4 = reinterpret_cast<f32x4 *>(Y);
@@ -136,7 +103,7 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, const int32_t *__restric
 // The result is only meaningful for a canonical partition: the validation raises the flag as before and
 // post_prologue_kernel, launched behind this kernel, then clears the whole output.
 __global__ void __launch_bounds__(kBlock)
-sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *__restrict__ p2n,
+sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const int32_t *__restrict__ p2n,
                        const int32_t *__restrict__ pp, int64_t P, int G, int32_t *flag, int32_t seq, int validate,
                        unsigned long long *gaps, int64_t big_rows)
 {
@@ -157,6 +124,13 @@ sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *_
                 if (lane == 0) { gaps[2 + 2 * idx] = (unsigned long long)lo; gaps[3 + 2 * idx] = (unsigned long long)cnt; }
                 return;
             }
+        }
+        if (ldy != D) {                                   // rows `ldy` floats apart: row by row
+            for (int64_t r = lo; r < lo + cnt; r++) {
+                float *row = Y + (size_t)r * (size_t)ldy;
+                for (int i = lane; i < D; i += kWave) row[i] = 0.f;
+            }
+            return;
         }
         float *base = Y + (size_t)lo * (size_t)D;
         const size_t n = (size_t)cnt * (size_t)D;
@@ -209,21 +183,27 @@ sparse_prologue_kernel(float *__restrict__ Y, int64_t N, int D, const int32_t *_
 // kernel then adds every row atomically), else the long gaps the prologue put on the call's list; returns at once
 // when there is neither
 __global__ void __launch_bounds__(kBlock)
-post_prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, const int32_t *flag, int32_t seq,
+post_prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, int ldy, const int32_t *flag, int32_t seq,
                      const unsigned long long *gaps)
 {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    // element i of a [rows, D] block whose rows lie `ldy` floats apart
+    auto at = [&](float *base, size_t i) -> float * {
+        if (ldy == D) return base + i;
+        const size_t r = i / (unsigned)D;
+        return base + r * (size_t)ldy + (i - r * (unsigned)D);
+    };
     if (*flag == seq) {
-        for (size_t i = tid; i < n_floats; i += nthreads) Y[i] = 0.f;
+        for (size_t i = tid; i < n_floats; i += nthreads) *at(Y, i) = 0.f;
         return;
     }
     if (!gaps) return;
     const unsigned long long n = gaps[0] < (unsigned long long)kGapEntries ? gaps[0] : (unsigned long long)kGapEntries;
     for (unsigned long long k = 0; k < n; k++) {
-        float *base = Y + (size_t)gaps[2 + 2 * k] * (size_t)D;
+        float *base = Y + (size_t)gaps[2 + 2 * k] * (size_t)ldy;
         const size_t cnt = (size_t)gaps[3 + 2 * k] * (size_t)D;
-        for (size_t i = tid; i < cnt; i += nthreads) base[i] = 0.f;
+        for (size_t i = tid; i < cnt; i += nthreads) *at(base, i) = 0.f;
     }
 }
 
@@ -232,320 +212,44 @@ post_prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, const int32_
 // deg[i] at the flush (deg_i * sum_j deg_j x_j), instead of one extra 4-byte gather plus a
 // broadcast and a multiply per edge.
 __global__ void __launch_bounds__(kBlock)
-scale_rows_kernel(const float *__restrict__ X, const float *__restrict__ deg, float *__restrict__ Xs,
+scale_rows_kernel(const float *__restrict__ X, int64_t ld_in, const float *__restrict__ deg, float *__restrict__ Xs,
                   int64_t rows, int D, int ld_out)
 {
-    // Xs[r, 0:D] = (deg ? deg[r] : 1) * X[r, 0:D], rows of Xs `ld_out` floats apart (pad never read)
+    // Xs[r, 0:D] = (deg ? deg[r] : 1) * X[r, 0:D]; rows of X `ld_in`, rows of Xs `ld_out` floats apart (pads never read,
+    // except by the 4-float loads of rows narrower than 4 floats, whose padding lanes are never stored)
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nthreads = (size_t)gridDim.x * blockDim.x;
     typedef float f32x4 __attribute__((ext_vector_type(4)));
-    if (ld_out == D && (D & 3) == 0 &&
-        ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xs)) & 15) == 0) {
+    const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xs)) & 15) == 0;
+    if (ld_out == D && ld_in == D && (D & 3) == 0 && aligned) {
         const size_t n4 = ((size_t)rows * (size_t)D) >> 2;
         const int d4 = D >> 2;
         for (size_t i = tid; i < n4; i += nthreads) {
             const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X) + i);
             reinterpret_cast<f32x4 *>(Xs)[i] = deg ? v * deg[i / d4] : v;
         }
-    } else if ((D & 3) == 0 && (ld_out & 3) == 0 &&
-               ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Xs)) & 15) == 0) {
-        // padded / gapped layout of rows whose width is a whole number of 16-byte pieces: one vector per thread
+    } else if ((D & 3) == 0 && (ld_out & 3) == 0 && (ld_in & 3) == 0 && aligned) {
+        // padded / gapped layouts of rows whose width is a whole number of 16-byte pieces: one vector per thread
         const size_t n4 = ((size_t)rows * (size_t)D) >> 2;
-        const unsigned d4 = (unsigned)D >> 2, ld4 = (unsigned)ld_out >> 2;
+        const unsigned d4 = (unsigned)D >> 2;
+        const size_t ldo4 = (size_t)ld_out >> 2, ldi4 = (size_t)ld_in >> 2;
         for (size_t i = tid; i < n4; i += nthreads) {
-            const size_t r = i / d4;
-            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X) + i);
-            reinterpret_cast<f32x4 *>(Xs)[r * ld4 + (i - r * d4)] = deg ? v * deg[r] : v;
+            const size_t r = i / d4, c4 = i - r * d4;
+            const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(X) + r * ldi4 + c4);
+            reinterpret_cast<f32x4 *>(Xs)[r * ldo4 + c4] = deg ? v * deg[r] : v;
         }
     } else {
         const size_t total = (size_t)rows * (size_t)D;
         for (size_t i = tid; i < total; i += nthreads) {
-            const size_t r = i / D;
-            const float v = __builtin_nontemporal_load(X + i);
-            Xs[r * (size_t)ld_out + (i - r * D)] = deg ? v * deg[r] : v;
-        }
-    }
-}
-
-// ---- main kernel --------------------------------------------------------------------------
-
-template <int VEC, int LPR, int MODE, int U, bool WIDE, bool PHASED>
-__global__ void __launch_bounds__(kBlock)
-agg_kernel(const AggParams p)
-{
-    typedef typename VecOf<VEC>::T VT;
-    typedef typename VecOf<VEC>::M MT;
-    // byte offsets into X: 32-bit (SGPR base + VGPR offset addressing) unless X exceeds 4 GiB
-    typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
-    constexpr int RPI = kWave / LPR;  // neighbor rows per wave-wide load
-    static_assert(U * RPI <= kWave, "a batch must fit one 64-edge id tile");
-
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int slot = lane / LPR;
-    const int c = lane % LPR;
-    const int D = p.D;
-    const int G = p.G;
-    const bool canonical = p.trust || (*p.flag != p.seq);
-    const char *xbase = reinterpret_cast<const char *>(p.X);
-    const OffT row_bytes = (OffT)p.ldx * (OffT)sizeof(float);
-
-    // item = 4 consecutive chunks handled by the 4 waves of one block.
-    const int64_t item_span = p.xcd_remap ? p.items_per_xcd * kXcds : p.num_items;
-    for (int64_t it = blockIdx.x; it < item_span; it += gridDim.x) {
-        int64_t item = it;
-        if (p.xcd_remap) {
-            // blocks land on XCD (blockIdx % 8): give each XCD one contiguous range of items
-            item = (it % kXcds) * p.items_per_xcd + it / kXcds;
-            if (item >= p.num_items) continue;
-        }
-        const int64_t chunk = item * kWavesPerBlock + wib;
-        if (chunk >= p.num_chunks) continue;
-        const int64_t g0 = chunk * G;
-        const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
-
-        // chunk metadata: one coalesced load each (G <= 63)
-        const int my_row = lane < ng ? p.p2n[g0 + lane] : -1;
-        const int my_pp = lane <= ng ? p.pp[g0 + lane] : 0;
-        int prev_row = -1, next_row = -1;
-        if (g0 > 0) prev_row = p.p2n[g0 - 1];
-        if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
-
-        int up_row = __shfl_up(my_row, 1);
-        bool is_start = lane < ng && (lane == 0 || my_row != up_row || !canonical);
-        unsigned long long starts = __ballot(is_start);
-
-        // column-phased schedule: every run keeps a cursor (next unconsumed edge) between the
-        // phase launches, stored at the index of the run's first group
-        int my_cur = 0, new_cur = 0;
-        if constexpr (PHASED) {
-            if (p.phase > 0 && lane < ng) my_cur = p.cursor[g0 + lane];
-        }
-
-        while (starts) {
-            const int js = __builtin_ctzll(starts);
-            starts &= starts - 1;
-            const int je = starts ? __builtin_ctzll(starts) : ng;
-            const int row = __builtin_amdgcn_readlane(my_row, js);
-            int sb = __builtin_amdgcn_readlane(my_pp, js);
-            const int se = __builtin_amdgcn_readlane(my_pp, je);
-            const bool shared = (js == 0 && prev_row == row) || (je == ng && next_row == row);
-            const bool use_atomic = shared || !canonical;
-            if constexpr (PHASED) {
-                if (p.phase > 0) sb = __builtin_amdgcn_readlane(my_cur, js);
-                if (lane == js) new_cur = sb;
-                if (sb >= se) continue;  // run already fully consumed by earlier phases
-            }
-            const bool accumulate = p.acc_in || (PHASED && p.phase > 0);
-
-            float row_deg = 1.f;
-            if constexpr (MODE == MODE_GCN) row_deg = p.deg_row[row];
-            float row_scale = p.eps;
-            if constexpr (MODE == MODE_GIN) {
-                if (p.row_scale) row_scale *= p.row_scale[row];
-            }
-
-            int consumed_end = sb;
-            for (int d0 = 0; d0 < D; d0 += VEC * LPR) {
-                // lane c owns the VEC floats starting at `dcol`.  When D is not a multiple of VEC the
-                // last piece is shifted back to end exactly at D: it overlaps its predecessor by
-                // `shift` floats, which both lanes compute identically (so plain stores may
-                // overlap) and which only the predecessor adds atomically.
-                const int piece = d0 + c * VEC;
-                const bool cvalid = piece < D;
-                int dcol = piece, shift = 0;
-                if (VEC > 1 && piece + VEC > D && cvalid) { dcol = D - VEC; shift = piece - dcol; }
-                // lanes past the end of the row re-read this sweep's first piece (same cache lines, never
-                // stored); min() keeps that read inside the row when the first piece is the shifted one
-                const OffT col_off = (OffT)(cvalid ? dcol : (d0 + VEC <= D ? d0 : D - VEC)) * (OffT)sizeof(float);
-                VT acc = vzero<VEC>();
-
-                // gathers `nv` neighbor rows whose ids sit in lanes 0..nv-1 of `id`
-                auto gather_tile = [&](const int id, const float dgn, const int nv) {
-                    if (nv <= RPI) {
-                        // short run (low-degree rows): one wave-wide load covers it
-                        const int nid = __shfl(id, slot);
-                        VT v0 = vzero<VEC>();
-                        if (slot < nv) v0 = *reinterpret_cast<const MT *>(xbase + (OffT)((OffT)nid * row_bytes + col_off));
-                        if constexpr (MODE == MODE_GCN) {
-                            VT tmp = v0 * (row_deg * __shfl(dgn, slot));
-                            acc += tmp;
-                        } else {
-                            acc += v0;
-                        }
-                        return;
-                    }
-#pragma unroll 1
-                    for (int b = 0; b < nv; b += U * RPI) {
-                        VT v[U];
-                        int nid[U];
-                        float cf[U];
-#pragma unroll
-                        for (int u = 0; u < U; u++) nid[u] = __shfl(id, b + u * RPI + slot);
-                        if (b + U * RPI <= nv) {
-                            // full batch: U unpredicated wave-wide row loads back to back
-#pragma unroll
-                            for (int u = 0; u < U; u++)
-                                v[u] = *reinterpret_cast<const MT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < U; u++) {
-                                v[u] = vzero<VEC>();
-                                if (b + u * RPI + slot < nv)
-                                    v[u] = *reinterpret_cast<const MT *>(xbase + (OffT)((OffT)nid[u] * row_bytes + col_off));
-                            }
-                        }
-                        if constexpr (MODE == MODE_GCN) {
-#pragma unroll
-                            for (int u = 0; u < U; u++) cf[u] = row_deg * __shfl(dgn, b + u * RPI + slot);
-                        }
-#pragma unroll
-                        for (int u = 0; u < U; u++) {
-                            if constexpr (MODE == MODE_GCN) {
-                                // reference rounds coef*x and the accumulate separately
-                                // (__fmaf_rn(c, x, 0) then +=, .cu:405); built with -ffp-contract=off
-                                VT tmp = v[u] * cf[u];
-                                acc += tmp;
-                            } else {
-                                acc += v[u];
-                            }
-                        }
-                    }
-                };
-
-                if constexpr (PHASED) {
-                    // consume the run from its cursor while the ids stay below this phase's bound
-                    // (ids of a CSR row are sorted, so that is one contiguous piece; if they are not,
-                    // every edge is still consumed exactly once, only in a less local phase)
-                    const bool last_phase = p.phase + 1 >= p.num_phases;
-                    int t = sb;
-                    while (t < se) {
-                        const int nvalid = se - t < kWave ? se - t : kWave;
-                        int id = 0x7fffffff;
-                        if (lane < nvalid) id = __builtin_nontemporal_load(p.col + t + lane);
-                        int take = nvalid;
-                        if (!last_phase) {
-                            const unsigned long long below = __ballot(lane < nvalid && id < p.phase_hi);
-                            take = below == ~0ull ? kWave : __builtin_ctzll(~below);
-                        }
-                        float dgn = 0.f;
-                        if constexpr (MODE == MODE_GCN) {
-                            if (lane < take) dgn = p.deg_col[id];
-                        }
-                        gather_tile(id, dgn, take);
-                        t += take;
-                        if (take < nvalid) break;  // reached the phase boundary inside this tile
-                    }
-                    consumed_end = t;
-                    if (consumed_end == sb) break;  // nothing of this run in this phase: no flush
-                } else {
-                    int id_next = 0;
-                    if (sb + lane < se) id_next = __builtin_nontemporal_load(p.col + sb + lane);
-                    for (int t = sb; t < se; t += kWave) {
-                        const int nv = se - t < kWave ? se - t : kWave;
-                        const int id = id_next;
-                        // software prefetch of the next 64 column ids
-                        if (t + kWave + lane < se) id_next = __builtin_nontemporal_load(p.col + t + kWave + lane);
-                        float dgn = 0.f;
-                        if constexpr (MODE == MODE_GCN) {
-                            if (lane < nv) dgn = p.deg_col[id];
-                        }
-                        gather_tile(id, dgn, nv);
-                    }
-                }
-
-                if constexpr (VEC == 4 && LPR <= 16) {
-                    // Fold the RPI slots as a reduce-scatter: instead of summing all four components
-                    // across the slots (8 lane swaps), the halves / rows exchange the components they
-                    // do not keep.  permlane32_swap(x, z) leaves {x_lo, z_lo} | {x_hi, z_hi}: their
-                    // sum holds x (lanes 0-31) and z (lanes 32-63) folded over lane, lane+32; the
-                    // same for (y, w); permlane16_swap of the two results then leaves row r of the
-                    // wave with component r.  3 swaps + 3 adds, and every lane ends with ONE float:
-                    // component lane>>4 of piece lane%LPR (narrow rows: the slots sharing a 16-lane
-                    // row are folded with DPP rotations afterwards).
-                    float px, qy;
-                    {
-                        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[0]), __float_as_uint(acc[2]), false, false);
-                        px = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                        r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[1]), __float_as_uint(acc[3]), false, false);
-                        qy = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                    }
-                    float val;
-                    {
-                        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(px), __float_as_uint(qy), false, false);
-                        val = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-                    }
-                    if constexpr (LPR <= 8) val += row_ror<8>(val);
-                    if constexpr (LPR <= 4) val += row_ror<4>(val);
-                    if constexpr (MODE == MODE_GIN) val *= row_scale;
-                    const int k = lane >> 4;  // component held by this lane
-                    if ((lane & 15) < LPR && cvalid) {
-                        float *dst = p.Y + (size_t)row * D + dcol + k;
-                        if (!use_atomic) {
-                            if (accumulate) {
-                                // earlier phases' partial (streamed: keep the X slice resident in L2); a shifted
-                                // first piece of a later dimension sweep overlaps floats that the previous sweep
-                                // has already read-modify-written: keep those as they are
-                                const float prev = __builtin_nontemporal_load(dst);
-                                val = (c == 0 && k < shift) ? prev : val + prev;
-                            }
-                            __builtin_nontemporal_store(val, dst);
-                        } else if (k >= shift) {
-                            unsafeAtomicAdd(dst, val);
-                        }
-                    }
-                } else {
-                    // fold the RPI slots; every slot then holds the row's partial sum
-#pragma unroll
-                    for (int k = 0; k < VEC; k++) {
-                        float s = slot_reduce<LPR>(vget<VEC>(acc, k));
-                        if constexpr (MODE == MODE_GIN) s *= row_scale;
-                        vset<VEC>(acc, k, s);
-                    }
-
-                    if (slot == 0 && cvalid) {
-                        float *dst = p.Y + (size_t)row * D + dcol;
-                        if (!use_atomic) {
-                            if (accumulate) {
-                                const VT prev = __builtin_nontemporal_load(reinterpret_cast<const MT *>(dst));
-#pragma unroll
-                                for (int k = 0; k < VEC; k++) {
-                                    const bool done = VEC > 1 && c == 0 && k < shift;
-                                    vset<VEC>(acc, k, done ? vget<VEC>(prev, k) : vget<VEC>(acc, k) + vget<VEC>(prev, k));
-                                }
-                            }
-                            __builtin_nontemporal_store(acc, reinterpret_cast<MT *>(dst));
-                        } else {
-#pragma unroll
-                            for (int k = 0; k < VEC; k++)
-                                if (k >= shift) unsafeAtomicAdd(dst + k, vget<VEC>(acc, k));
-                        }
-                    }
-                }
-            }
-            if constexpr (PHASED) {
-                if (lane == js) new_cur = consumed_end;
-            }
-        }
-        if constexpr (PHASED) {
-            if (is_start && p.phase + 1 < p.num_phases) p.cursor[g0 + lane] = new_cur;
+            const size_t r = i / (unsigned)D, cc = i - r * (unsigned)D;
+            const float v = __builtin_nontemporal_load(X + r * (size_t)ld_in + cc);
+            Xs[r * (size_t)ld_out + cc] = deg ? v * deg[r] : v;
         }
     }
 }
 
 // ---- host side ------------------------------------------------------------------------------
 
-// Number of column phases.  The gather is bound by the L2-miss path once X is larger than the
-// caches; restricting a launch to a slice of X makes the slice cache resident (MI355X, Reddit-like
-// D=64, ids folded into one slice: 59.6 MB slice 2.81 ms, 7.45 MB 1.58 ms, 3.7 MB 1.34 ms per full
-// pass).  Each extra phase costs a launch, a pass over the chunk descriptors and a
-// read-modify-write of the touched output rows, so the measured optimum is about one phase per
-// 14 MB of X (tools/sweep.py --phases, Reddit-like: D=16/32/64/128/256 -> 2/2/4/8/16 phases,
-// +12/+17/+49/+64/+60 %), capped by the work per row and phase (products-like, average degree 50:
-// 2 phases +6 %, 4 phases -12 %) and useless -- harmful -- when the ids of a row are already
-// local (community-ordered variant: 1.38 ms single pass, 2.5 ms in 2 phases).  Locality and degree
-// cannot be seen from here without a device round trip, so the automatic mode acts only on the
-// hints the Decider supplies (gnna_tuning.avg_degree / nonlocal_ids); without hints: one pass.
 thread_local int t_last_phases = 1;
 thread_local int t_last_launches = 1;   // aggregation kernel launches of the calling thread's last call
 
@@ -695,93 +399,20 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     return std::max(b, 1);
 }
 
-int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size)
-{
-    int b = 1;
-    if (tune.column_phases >= 1) {
-        b = std::min(tune.column_phases, 16);   // (chunk-walk kernel: one launch per phase)
-    } else if (tune.nonlocal_ids == 1 && tune.avg_degree > 0) {
-        // measured optimum on the Reddit-like graph, D = 16 / 32 / 40 / 48 / 64 / 96 / 128:
-        // 2 / 2 / 3 / 3-4 / 4 / 5 / 8 phases, i.e. one phase per ~14 MB of X, two from 12 MB on
-        const size_t per_phase = 14000000;
-        b = (int)std::min<size_t>(8, (x_bytes + per_phase / 2) / per_phase);
-        if (b < 2 && x_bytes >= 12000000) b = 2;
-        // per-row work bounds the phase count: ~50 edges per row and phase; two phases already pay from an
-        // average degree of ~40 (products-like, 50.5: 3.76 -> 3.55 ms; a 61-edge local part: 0.38 -> 0.36 ms)
-        b = std::min(b, std::max(tune.avg_degree / 50, tune.avg_degree >= 40 ? 2 : 1));
-        const int64_t est_edges = std::min<int64_t>(num_parts * (int64_t)part_size, num_parts * (int64_t)tune.avg_degree);
-        while (b > 1 && est_edges / b < ((int64_t)4 << 20)) b--;
-    }
-    while (b > 1 && num_parts / b < 64) b--;
-    return std::max(b, 1);
-}
-
 namespace {
-typedef void (*AggKernel)(const AggParams);
 
-template <int VEC, int LPR, int MODE, int U>
-AggKernel pick_wide(bool wide, bool phased)
-{
-    if (phased) {
-        if (wide) return agg_kernel<VEC, LPR, MODE, U, true, true>;
-        return agg_kernel<VEC, LPR, MODE, U, false, true>;
-    }
-    if (wide) return agg_kernel<VEC, LPR, MODE, U, true, false>;
-    return agg_kernel<VEC, LPR, MODE, U, false, false>;
-}
-
-template <int VEC, int LPR, int MODE>
-AggKernel pick_u(int u, bool wide, bool phased)
-{
-    constexpr int RPI = kWave / LPR;
-    constexpr int UMAX = kWave / RPI;  // == LPR
-    if constexpr (VEC == 4 && UMAX >= 16) {
-        if (u >= 16) return pick_wide<VEC, LPR, MODE, 16>(wide, phased);
-    }
-    if constexpr (UMAX >= 8) {
-        if (u >= 8) return pick_wide<VEC, LPR, MODE, 8>(wide, phased);
-    }
-    if constexpr (VEC == 4 || UMAX < 8) {
-        return pick_wide<VEC, LPR, MODE, 4>(wide, phased);
-    } else {
-        return pick_wide<VEC, LPR, MODE, 8>(wide, phased);
-    }
-}
-
-template <int VEC, int MODE>
-AggKernel pick_lpr(int lpr, int u, bool wide, bool phased)
-{
-    switch (lpr) {
-    case 4: return pick_u<VEC, 4, MODE>(u, wide, phased);
-    case 8: return pick_u<VEC, 8, MODE>(u, wide, phased);
-    case 16: return pick_u<VEC, 16, MODE>(u, wide, phased);
-    case 32: return pick_u<VEC, 32, MODE>(u, wide, phased);
-    default: return pick_u<VEC, 64, MODE>(u, wide, phased);
-    }
-}
-
-template <int MODE>
-AggKernel pick_vec(int vec, int lpr, int u, bool wide, bool phased)
-{
-    if (vec == 4) return pick_lpr<4, MODE>(lpr, u, wide, phased);
-    return pick_u<1, 4, MODE>(u, wide, phased);  // rows narrower than 4 floats: one lane per float
-}
-
-AggKernel pick_kernel(int mode, int vec, int lpr, int u, bool wide, bool phased)
-{
-    switch (mode) {
-    case MODE_GCN: return pick_vec<MODE_GCN>(vec, lpr, u, wide, phased);
-    case MODE_GIN: return pick_vec<MODE_GIN>(vec, lpr, u, wide, phased);
-    default: return pick_vec<MODE_SAG>(vec, lpr, u, wide, phased);
-    }
-}
-
-int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
+// One aggregation call.  ld_in / ld_out: row strides of `input` / `out` in floats (>= dim).  flags: GNNA_ACCUMULATE,
+// GNNA_EPILOGUE_RELU.  num_windows > 1: the call is one of a windowed sequence and covers source windows [win_begin, win_end).
+int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows, const int32_t *column_index,
                const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
-               const int32_t *part2Node, float *out, int64_t num_nodes, int dim, int64_t num_parts,
-               int partSize, int dimWorker, int warpPerBlock, void *stream_v, bool accumulate_into_out = false,
+               const int32_t *part2Node, float *out, int64_t ld_out, int64_t num_nodes, int dim, int64_t num_parts,
+               int partSize, int dimWorker, int warpPerBlock, void *stream_v, unsigned flags,
                int num_windows = 1, int win_begin = 0, int win_end = 1)
 {
+    const bool accumulate_into_out = (flags & GNNA_ACCUMULATE) != 0;
+    const bool relu = (flags & GNNA_EPILOGUE_RELU) != 0;
+    if (flags & ~(unsigned)(GNNA_ACCUMULATE | GNNA_EPILOGUE_RELU))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "unknown flag bits 0x%x", flags);
     if (num_nodes < 0 || dim < 0 || num_parts < 0 || num_in_rows < 0)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size (num_nodes=%lld dim=%d num_parts=%lld)",
                           (long long)num_nodes, dim, (long long)num_parts);
@@ -797,6 +428,9 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         return fail(GNNA_ERR_UNSUPPORTED, "%lld destination rows in one call (at most 536870911): shard the rows",
                     (long long)num_nodes);
     if (num_nodes == 0 || dim == 0) return GNNA_OK;
+    if (ld_in < dim || ld_out < dim || ld_in >= ((int64_t)1 << 29) || ld_out >= ((int64_t)1 << 29))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "row strides must be >= dim and < 2^29 floats (ld_in=%lld ld_out=%lld dim=%d)",
+                    (long long)ld_in, (long long)ld_out, dim);
     if (!out || !input) return fail(GNNA_ERR_INVALID_ARGUMENT, "null feature pointer");
     if (num_parts > 0 && (!column_index || !part_pointers || !part2Node))
         return fail(GNNA_ERR_INVALID_ARGUMENT, "null index pointer");
@@ -818,11 +452,13 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
     const int32_t seq = next_call_seq(ds, &flag);
     const int prof_call = profile_acquire_call(num_parts > 0);
     profile_record(prof_call, 0, stream);
+    const bool windowed = num_windows > 1;
+    const int ldy = (int)ld_out;
 
     // prologue: zero-fill + validation.  `sparse_G` > 0: the streaming kernel is about to run a single pass with
     // `sparse_G` groups per work item and stores every row it owns, so only the other rows are cleared.
     const size_t n_floats = (size_t)num_nodes * (size_t)dim;
-    // set when the call reads packed ids: the (dense) prologue then compares a sample of column_index with the copy's
+    // set when the call reads packed ids: the (dense) prologue then compares a sample of the graph with the copy's
     const unsigned long long *chk_sum = nullptr;
     int64_t chk_n = 0;
     int32_t *stale_flag = flag + kFlagSlots;          // the second ring, same slot
@@ -835,16 +471,16 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
             unsigned long long *gaps = ds->gap_lists + (size_t)((uint32_t)seq % kGapSlots) * kGapWords;
             (void)hipMemsetAsync(gaps, 0, sizeof(unsigned long long), stream);
             const int64_t big_rows = std::max<int64_t>(64, ((int64_t)1 << 20) / std::max(1, dim * 4));   // >= 1 MiB of zeros
-            hipLaunchKernelGGL(sparse_prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, num_nodes, dim,
+            hipLaunchKernelGGL(sparse_prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, num_nodes, dim, ldy,
                                part2Node, part_pointers, num_parts, sparse_G, flag, seq, validate, gaps, big_rows);
             hipLaunchKernelGGL(post_prologue_kernel, dim3((unsigned)(ds->num_cus * 8)), dim3(kBlock), 0, stream, out,
-                               n_floats, dim, flag, seq, gaps);
+                               n_floats, dim, ldy, flag, seq, gaps);
         } else {
             size_t work = std::max(n_floats / 4, (size_t)num_parts);
             int64_t blocks = (int64_t)((work + kBlock - 1) / kBlock);
             blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
             hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks + (chk_sum ? 1u : 0u)), dim3(kBlock), 0, stream, out, n_floats,
-                               part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill,
+                               dim, ldy, part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill,
                                chk_sum ? column_index : nullptr, chk_n, chk_sum, stale_flag);
         }
         hipError_t e = hipGetLastError();
@@ -852,51 +488,51 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         profile_record(prof_call, 1, stream);
         return GNNA_OK;
     };
-    if (num_parts == 0) return run_prologue(0);
-
-    // vector width / lane layout: one lane per 4 consecutive floats of a row (dword-aligned
-    // dwordx4 accesses, ragged tail handled by the shifted last piece), LPR lanes per row
-    const int vec = dim >= 4 ? 4 : 1;
-    const int pieces = (dim + vec - 1) / vec;
-    int lpr = 4;
-    while (lpr < 64 && lpr < pieces) lpr <<= 1;
-
-    AggParams p;
-    p.X = input; p.col = column_index; p.deg_row = degrees; p.deg_col = degrees_in; p.pp = part_pointers; p.p2n = part2Node;
-    p.Y = out; p.P = num_parts; p.D = dim; p.eps = epsilon;
-    p.G = std::max(1, std::min(tune.groups_per_chunk, 63));
-    p.num_chunks = (num_parts + p.G - 1) / p.G;
-    p.num_items = (p.num_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-    p.items_per_xcd = (p.num_items + kXcds - 1) / kXcds;
-    p.xcd_remap = tune.xcd_remap ? 1 : 0;
-    p.flag = flag; p.seq = seq; p.trust = tune.trust_canonical ? 1 : 0;
-
-    int64_t span = p.xcd_remap ? p.items_per_xcd * kXcds : p.num_items;
-    int64_t grid = span;
-    if (tune.blocks_per_cu > 0) grid = std::min<int64_t>(grid, (int64_t)tune.blocks_per_cu * ds->num_cus);
-    grid = std::max<int64_t>(1, std::min<int64_t>(grid, 0x7fffffff));
-    if (p.xcd_remap && grid < span) grid = std::max<int64_t>(kXcds, grid / kXcds * kXcds);  // keep it % 8 stable
+    if (num_parts == 0) {
+        rc = run_prologue(0);
+        if (rc != GNNA_OK || !relu || !accumulate_into_out) return rc;
+        // (nothing to add, but the epilogue still applies to what `out` holds)
+        StreamLaunch e0;
+        e0.mode = mode; e0.Y = out; e0.p2n = part2Node; e0.P = 0; e0.D = dim; e0.ldy = ldy; e0.relu = true; e0.num_out_rows = num_nodes;
+        e0.flag = flag; e0.seq = seq; e0.cnt = nullptr; e0.B = 1; e0.plain_ok = false; e0.G = 1;
+        return launch_stream_epilogue_only(e0, stream);
+    }
 
     const int64_t window_rows = (num_in_rows + num_windows - 1) / num_windows;
 
-    // Staged copy of the source rows in library scratch, made when every source row is gathered many
-    // times: (a) GCN pre-scaling -- Xs_j = deg_j X_j, so that the gather is unweighted and deg_i is
-    // applied at the flush; (b) a padded row stride for widths whose rows straddle 128-byte lines or
-    // are not 16-byte aligned (the class counts of GCN output layers: 41, 47, 22, 7 ...).
+    // ---- where the rows are gathered from -------------------------------------------------------------------------
+    // Either `input` itself (row stride ld_in) or a staged copy in library scratch, made when every source row is gathered
+    // many times: (a) GCN pre-scaling -- Xs_j = deg_j X_j, so that the gather is unweighted and deg_i is applied at the
+    // flush; (b) a padded row stride for widths whose rows straddle 128-byte lines or are not 16-byte aligned (the
+    // class counts of GCN output layers: 41, 47, 22, 7 ...); (c) every row on its own 256- / 512-byte boundary; (d) rows
+    // narrower than 4 floats, which the kernels gather as 4-float rows.  A caller whose own layout (ld_in) is already
+    // what (b) / (c) would produce is gathered from directly: no copy per call.
     const int64_t est_edges = num_parts * (int64_t)(tune.avg_degree > 0 ? std::min(partSize, tune.avg_degree) : partSize / 2 + 1);
     // (automatic staging only while the copy stays small next to the 288 GB of HBM: a staged copy of a multi-GB
     // feature matrix would silently double the resident set -- the per-edge form runs on the same kernel)
     const bool hot_rows = est_edges >= 32 * num_in_rows && (size_t)num_in_rows * (size_t)dim * sizeof(float) <= ((size_t)1 << 30);
     const bool prescale = mode == MODE_GCN && (tune.gcn_prescale == 1 || (tune.gcn_prescale == 0 && hot_rows));
-    const int ldx = pick_row_stride(tune, dim, hot_rows, num_in_rows, win_begin == 0 && num_windows == 1);
-    p.ldx = ldx;
-    p.row_scale = nullptr;
+    const int want = dim < 4 ? 4 : pick_row_stride(tune, dim, hot_rows, num_in_rows, !windowed);
+    bool direct = !prescale && dim >= 4;
+    if (direct && want != dim && ld_in != want) {
+        // is the caller's layout as good as the staged one would be?
+        const bool aligned16 = (reinterpret_cast<uintptr_t>(input) & 15) == 0 && (ld_in & 3) == 0;
+        const int gapped = 2 * ((dim * 4 + 127) / 128) * 32;
+        if (want == gapped && dim > 16 && dim <= 64)
+            direct = (ld_in % gapped) == 0 && (reinterpret_cast<uintptr_t>(input) % ((size_t)gapped * 4)) == 0;
+        else
+            direct = aligned16 && avg_lines_per_row((int64_t)dim * 4, ld_in * 4) <= avg_lines_per_row((int64_t)dim * 4, (int64_t)want * 4) + 1e-9;
+    }
+    const int ldx = direct ? (int)ld_in : want;
+    const float *X = input;
+    const float *row_scale = nullptr;
+    float eps = epsilon;
     const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);
     // what the gather can touch of it (whole 128-byte lines of every row; a gapped copy's gaps never enter a cache):
     // the size the slicing decisions go by
-    const size_t foot_bytes = (size_t)num_in_rows * (size_t)std::min(ldx, (dim * 4 + 127) / 128 * 32) * sizeof(float);
+    const size_t foot_bytes = (size_t)num_in_rows * (size_t)std::min(ldx, (std::max(dim, 4) * 4 + 127) / 128 * 32) * sizeof(float);
     const bool wide = x_bytes > 0xffffffffull;
-    if (prescale || ldx != dim) {
+    if (!direct) {
         void *xs = nullptr;
         rc = get_workspace(ds, stream, 1, x_bytes, &xs);
         if (rc != GNNA_OK) return rc;
@@ -907,26 +543,43 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         int64_t sblocks = (int64_t)((s_bytes / 16 + kBlock - 1) / kBlock);
         sblocks = std::max<int64_t>(1, std::min<int64_t>(sblocks, (int64_t)ds->num_cus * 8));
         hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)sblocks), dim3(kBlock), 0, stream,
-                           input + (size_t)r0 * dim, prescale ? degrees_in + r0 : nullptr,
+                           input + (size_t)r0 * (size_t)ld_in, ld_in, prescale ? degrees_in + r0 : nullptr,
                            static_cast<float *>(xs) + (size_t)r0 * ldx, r1 - r0, dim, ldx);
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) return fail(GNNA_ERR_HIP, "staging launch: %s", hipGetErrorString(es));
-        p.X = static_cast<const float *>(xs);
+        X = static_cast<const float *>(xs);
         if (prescale) {
-            p.row_scale = degrees;
-            p.eps = 1.f;
+            row_scale = degrees;
+            eps = 1.f;
             mode = MODE_GIN;  // unweighted gather + per-row factor at the flush
         }
     }
-    // Streaming kernel (gnna_stream.hip): rows of >= 4 floats that are not part of a windowed sequence.  Its sliced schedule is stateless and a single launch; the number of phases is
-    // tune.column_phases when set (process-wide or measured per graph), otherwise chosen from the slice
-    // statistics of the partition (first sight of a graph: one counting pass + one stream synchronisation).
-    if (vec == 4 && num_windows == 1 && tune.stream_kernel != 2) {
-        int B = 1;
-        const uint8_t *cnt = nullptr;
-        int S = kMaxSlices;
-        SlicePlan plan;
-        const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && foot_bytes >= ((size_t)2 << 20);
+
+    // ---- the schedule: phases of the sliced schedule ------------------------------------------------------------
+    // tune.column_phases when set (process-wide or measured per graph), otherwise chosen from the slice statistics of
+    // the partition (first sight of a graph: one counting pass + one stream synchronisation).
+    int B = 1;
+    const uint8_t *cnt = nullptr;
+    int S = kMaxSlices;
+    int win_lo = 0, win_hi = 0;
+    SlicePlan plan;
+    const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && foot_bytes >= ((size_t)2 << 20);
+    if (windowed) {
+        // the fine slices of this plan ARE the caller's source windows: the call takes, of every group, the ids of its
+        // windows -- positions [cum[win_begin], cum[win_end]) -- which are exactly those ids when the group's ids are
+        // sorted (checked by the counting pass: a window call must not read rows that have not arrived)
+        rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, false, &plan,
+                            (uint32_t)std::max<int64_t>(1, window_rows));
+        if (rc != GNNA_OK) return rc;
+        if (!plan.cnt || !plan.stats.valid)
+            return fail(GNNA_ERR_UNSUPPORTED, "the windowed aggregation needs its window counts, which cannot be built inside a "
+                                              "stream capture: run the sequence once before capturing it");
+        if (plan.stats.unsorted > 0)
+            return fail(GNNA_ERR_UNSUPPORTED, "windowed aggregation: the column ids of %.0f neighbor-groups are not in increasing "
+                                              "order (sort the ids of every row, as the loader's CSR has them)", plan.stats.unsorted);
+        cnt = plan.cnt; S = plan.S; B = 1;
+        win_lo = win_begin; win_hi = win_end == num_windows ? S : win_end;
+    } else {
         if (tune.column_phases >= 2 && num_in_rows >= kMaxSlices) {
             B = std::min(tune.column_phases, kMaxSlices);
             rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, false, false, &plan);
@@ -941,126 +594,97 @@ int launch_agg(int mode, const float *input, int64_t num_in_rows, const int32_t 
         cnt = plan.cnt;
         if (cnt) S = plan.S;
         if (!cnt || B < 2) { B = 1; cnt = nullptr; }
-        // Destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
-        // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
-        const int auto_Bs = (cnt && plan.stats.valid) ? sweep_auto_phases(tune, mode, dim, foot_bytes, num_nodes, num_in_rows, plan.stats.edges, B,
-                                                                          ds->num_cus, tune.deterministic == 1, partSize) : 0;
-        if (cnt && (tune.sweep == 1 || auto_Bs > 0) && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
-            int Bs = B;
-            if (auto_Bs > 0) {
-                Bs = std::min(auto_Bs, S);
-            } else if (tune.column_phases < 2) {      // sweep forced, phases not: twice the streaming kernel's
-                Bs = std::max(2, std::min(std::min(std::min(16, 2 * B), std::max(2, partSize / 4)), S));
-            }
-            const int32_t *sw_ids = nullptr; const uint32_t *sw_off = nullptr;
-            if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && tune.xcd_remap != 0) {
-                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &sw_ids, &sw_off, &chk_sum, &chk_n);
-                if (rc != GNNA_OK) return rc;
-                if (sw_ids) count_event(CTR_PACKED_LAUNCHES);
-            }
-            rc = run_prologue(0);
-            if (rc != GNNA_OK) return rc;
-            uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * (kXcds * 16);
-            hipError_t em = hipMemsetAsync(sync, 0, kXcds * 16 * sizeof(uint32_t), stream);
-            if (em != hipSuccess) return fail(GNNA_ERR_HIP, "sweep counters: %s", hipGetErrorString(em));
-            SweepLaunch w;
-            w.mode = mode; w.X = p.X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;
-            w.cnt = cnt; w.row_scale = p.row_scale; w.flag = flag; w.seq = seq; w.trust = p.trust; w.sync = sync;
-            w.P = num_parts; w.D = dim; w.ldx = ldx; w.S = S; w.B = Bs;
-            w.U = std::max(tune.loads_in_flight, 8);      // 16 wavefronts per CU: more loads in flight per wavefront pay here
-            w.rows_with_edges = plan.stats.valid ? (int64_t)std::min((double)num_nodes, plan.stats.groups) : num_nodes;
-            if (tune.groups_per_chunk > 64) w.rounds = tune.groups_per_chunk / 64;   // experiments: G = 64 * (sets per workgroup)
-            w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;
-            w.dynamic = tune.xcd_remap != 0;      // (experiments: XCD=0 selects the fixed shares per wavefront)   // (experiments: BPC = 1 / 2 workgroups per CU)
-            w.plain_ok = !accumulate_into_out; w.eps = p.eps;
-            w.ids_packed = sw_ids; w.item_off = sw_off; w.packed_stale = stale_flag;
-            t_last_phases = Bs;
-            t_last_launches = 1;
-            rc = launch_sweep(ds, w, stream);
-            if (rc != GNNA_OK) return rc;
-            profile_record(prof_call, 2, stream);
-            return GNNA_OK;
+    }
+
+    // ---- destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
+    // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
+    const int auto_Bs = (cnt && !windowed && plan.stats.valid)
+                            ? sweep_auto_phases(tune, mode, dim, foot_bytes, num_nodes, num_in_rows, plan.stats.edges, B, ds->num_cus,
+                                                tune.deterministic == 1, partSize) : 0;
+    if (cnt && !windowed && dim >= 4 && (tune.sweep == 1 || auto_Bs > 0) && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
+        int Bs = B;
+        if (auto_Bs > 0) {
+            Bs = std::min(auto_Bs, S);
+        } else if (tune.column_phases < 2) {      // sweep forced, phases not: twice the streaming kernel's
+            Bs = std::max(2, std::min(std::min(std::min(16, 2 * B), std::max(2, partSize / 4)), S));
         }
-        t_last_phases = B;
-        StreamLaunch a;
-        a.mode = mode; a.X = p.X; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node; a.Y = out;
-        a.cnt = cnt; a.row_scale = p.row_scale; a.deg_row = p.deg_row; a.deg_col = p.deg_col; a.flag = flag; a.seq = seq; a.trust = p.trust; a.P = num_parts;
-        // a work item is (chunk, slice): keep its edge count about what `groups_per_chunk` groups are in one pass
-        a.D = dim; a.ldx = ldx; a.G = std::min(64, tune.groups_per_chunk * B); a.U = tune.loads_in_flight; a.S = S; a.B = B;
-        t_last_launches = 1;
-        a.wide = wide; a.plain_ok = (B == 1 && !accumulate_into_out); a.xcd_remap = tune.xcd_remap != 0;
-        a.eps = p.eps;
-        if (tune.deterministic == 1) {
-            // ordered phase launches, owned rows read-modify-written, rows shared between chunks summed in chunk order
-            // from partials parked in the stream's scratch (slot 2): bit-reproducible for a canonical partition
-            const int G_eff = std::max(1, std::min(a.G, kWave));
-            const size_t chunks = (size_t)((num_parts + G_eff - 1) / G_eff);
-            const size_t part_bytes = ((chunks * 2 * (size_t)dim * sizeof(float)) + 255) & ~(size_t)255;
-            const size_t stamp_bytes = chunks * 2 * sizeof(int32_t);
-            void *ws = nullptr;
-            rc = get_workspace(ds, stream, 2, part_bytes + stamp_bytes, &ws);
+        const int32_t *sw_ids = nullptr; const uint32_t *sw_off = nullptr;
+        if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && tune.xcd_remap != 0) {
+            rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &sw_ids, &sw_off, &chk_sum, &chk_n);
             if (rc != GNNA_OK) return rc;
-            a.det = true;
-            a.det_part = static_cast<float *>(ws);
-            a.det_stamp = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + part_bytes);
-            hipError_t em = hipMemsetAsync(a.det_stamp, 0, stamp_bytes, stream);
-            if (em != hipSuccess) return fail(GNNA_ERR_HIP, "deterministic schedule scratch: %s", hipGetErrorString(em));
-            t_last_launches = B;
+            if (sw_ids) count_event(CTR_PACKED_LAUNCHES);
         }
-        // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
-        // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
-        if (cnt && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && mode != MODE_SDDMM) {
-            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
-                                &chk_sum, &chk_n);
-            a.packed_stale = stale_flag;
-            if (rc != GNNA_OK) return rc;
-            if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
-        }
-        // single pass, nothing to add to: only the rows the kernel does not store need clearing -- worth a second
-        // (empty) launch once the output is tens of MB
-        const bool sparse = !a.det && a.plain_ok && tune.zero_fill != 2 &&
-                            (tune.zero_fill == 1 || n_floats * sizeof(float) >= ((size_t)32 << 20));
-        rc = run_prologue(sparse ? std::max(1, std::min(a.G, kWave)) : 0);
+        rc = run_prologue(0);
         if (rc != GNNA_OK) return rc;
-        rc = launch_stream(a, stream);
+        uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * (kXcds * 16);
+        hipError_t em = hipMemsetAsync(sync, 0, kXcds * 16 * sizeof(uint32_t), stream);
+        if (em != hipSuccess) return fail(GNNA_ERR_HIP, "sweep counters: %s", hipGetErrorString(em));
+        SweepLaunch w;
+        w.mode = mode; w.X = X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;
+        w.cnt = cnt; w.row_scale = row_scale; w.flag = flag; w.seq = seq; w.trust = tune.trust_canonical ? 1 : 0; w.sync = sync;
+        w.P = num_parts; w.D = dim; w.ldx = ldx; w.ldy = ldy; w.S = S; w.B = Bs;
+        w.relu = relu; w.num_out_rows = num_nodes;
+        w.U = std::max(tune.loads_in_flight, 8);      // 16 wavefronts per CU: more loads in flight per wavefront pay here
+        w.rows_with_edges = plan.stats.valid ? (int64_t)std::min((double)num_nodes, plan.stats.groups) : num_nodes;
+        if (tune.groups_per_chunk > 64) w.rounds = tune.groups_per_chunk / 64;   // experiments: G = 64 * (sets per workgroup)
+        w.slack = tune.sweep_slack; w.wgs_per_cu = tune.blocks_per_cu;          // (experiments: BPC = 1 / 2 workgroups per CU)
+        w.dynamic = tune.xcd_remap != 0;                                          // (experiments: XCD=0 selects the fixed shares per wavefront)
+        w.plain_ok = !accumulate_into_out; w.eps = eps;
+        w.ids_packed = sw_ids; w.item_off = sw_off; w.packed_stale = stale_flag;
+        t_last_phases = Bs;
+        t_last_launches = 1;
+        rc = launch_sweep(ds, w, stream);
         if (rc != GNNA_OK) return rc;
         profile_record(prof_call, 2, stream);
         return GNNA_OK;
     }
-    rc = run_prologue(0);
-    if (rc != GNNA_OK) return rc;
 
-    // phases: `sub` launches per source window (one window == the whole source range unless the caller
-    // pipelines a chunked feature exchange); this call runs the launches of windows [win_begin, win_end)
-    const int total = choose_phases(tune, x_bytes, num_parts, partSize);
-    const int sub = std::max(1, (total + num_windows / 2) / num_windows);
-    const int phases = sub * num_windows;
-    t_last_phases = phases;
-    t_last_launches = sub * (win_end - win_begin);
-    AggKernel k = pick_kernel(mode, vec, lpr, tune.loads_in_flight, wide, phases > 1);
-    p.cursor = nullptr; p.phase = 0; p.num_phases = 1; p.phase_hi = 0x7fffffff;
-    p.acc_in = accumulate_into_out ? 1 : 0;
-    if (phases > 1) {
-        rc = claim_cursors(ds, stream, column_index, part_pointers, num_windows, win_begin, win_end);
-        if (rc != GNNA_OK) return rc;
+    // ---- streaming kernel (gnna_stream.hip) -----------------------------------------------------------------------
+    t_last_phases = B;
+    StreamLaunch a;
+    a.mode = mode; a.X = X; a.col = column_index; a.pp = part_pointers; a.p2n = part2Node; a.Y = out;
+    a.cnt = cnt; a.row_scale = row_scale; a.deg_row = degrees; a.deg_col = degrees_in; a.flag = flag; a.seq = seq;
+    a.trust = tune.trust_canonical ? 1 : 0; a.P = num_parts;
+    // a work item is (chunk, slice): keep its edge count about what `groups_per_chunk` groups are in one pass
+    a.D = dim; a.ldx = ldx; a.ldy = ldy; a.G = std::min(64, tune.groups_per_chunk * B); a.U = tune.loads_in_flight; a.S = S; a.B = B;
+    a.win_lo = win_lo; a.win_hi = win_hi; a.relu = relu; a.num_out_rows = num_nodes;
+    t_last_launches = 1;
+    a.wide = wide; a.plain_ok = (B == 1 && !accumulate_into_out && !windowed); a.xcd_remap = tune.xcd_remap != 0;
+    a.eps = eps;
+    if (tune.deterministic == 1 && !windowed) {
+        // ordered phase launches, owned rows read-modify-written, rows shared between chunks summed in chunk order
+        // from partials parked in the stream's scratch (slot 2): bit-reproducible for a canonical partition
+        const int G_eff = std::max(1, std::min(a.G, kWave));
+        const size_t chunks = (size_t)((num_parts + G_eff - 1) / G_eff);
+        const size_t part_bytes = ((chunks * 2 * (size_t)dim * sizeof(float)) + 255) & ~(size_t)255;
+        const size_t stamp_bytes = chunks * 2 * sizeof(int32_t);
         void *ws = nullptr;
-        rc = get_workspace(ds, stream, 0, (size_t)num_parts * sizeof(int32_t), &ws);
+        rc = get_workspace(ds, stream, 2, part_bytes + stamp_bytes, &ws);
         if (rc != GNNA_OK) return rc;
-        p.cursor = static_cast<int32_t *>(ws);
-        p.num_phases = phases;
+        a.det = true;
+        a.det_part = static_cast<float *>(ws);
+        a.det_stamp = reinterpret_cast<int32_t *>(static_cast<char *>(ws) + part_bytes);
+        hipError_t em = hipMemsetAsync(a.det_stamp, 0, stamp_bytes, stream);
+        if (em != hipSuccess) return fail(GNNA_ERR_HIP, "deterministic schedule scratch: %s", hipGetErrorString(em));
+        t_last_launches = B;
     }
-    const int64_t sub_rows = (window_rows + sub - 1) / sub;
-    for (int w = win_begin; w < win_end; w++) {
-        for (int j = 0; j < sub; j++) {
-            p.phase = w * sub + j;
-            const int64_t hi = std::min<int64_t>((int64_t)w * window_rows + (int64_t)(j + 1) * sub_rows,
-                                                 (int64_t)(w + 1) * window_rows);
-            p.phase_hi = (int32_t)std::min<int64_t>(hi, 0x7fffffff);
-            hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kBlock), 0, stream, p);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
-        }
+    // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
+    // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
+    if (cnt && !windowed && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned))) {
+        rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
+                            &chk_sum, &chk_n);
+        a.packed_stale = stale_flag;
+        if (rc != GNNA_OK) return rc;
+        if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
     }
+    // single pass, nothing to add to: only the rows the kernel does not store need clearing -- worth a second
+    // (empty) launch once the output is tens of MB
+    const bool sparse = !a.det && a.plain_ok && tune.zero_fill != 2 &&
+                        (tune.zero_fill == 1 || n_floats * sizeof(float) >= ((size_t)32 << 20));
+    rc = run_prologue(sparse ? std::max(1, std::min(a.G, kWave)) : 0);
+    if (rc != GNNA_OK) return rc;
+    rc = launch_stream(a, stream);
+    if (rc != GNNA_OK) return rc;
     profile_record(prof_call, 2, stream);
     return GNNA_OK;
 }
@@ -1079,8 +703,8 @@ int gnna_sag_f32(const float *input, const int32_t *row_pointers, const int32_t 
                  int partSize, int dimWorker, int warpPerBlock, void *stream)
 {
     (void)row_pointers; (void)degrees;  // unused by the reference kernel as well (.cu:186-259)
-    return launch_agg(MODE_SAG, input, num_nodes, column_index, nullptr, nullptr, 1.f, part_pointers,
-                      part2Node, out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream);
+    return launch_agg(MODE_SAG, input, dim, num_nodes, column_index, nullptr, nullptr, 1.f, part_pointers,
+                      part2Node, out, dim, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream, 0u);
 }
 
 int gnna_agg_gcn_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
@@ -1089,8 +713,8 @@ int gnna_agg_gcn_f32(const float *input, const int32_t *row_pointers, const int3
                      int partSize, int dimWorker, int warpPerBlock, void *stream)
 {
     (void)row_pointers;
-    return launch_agg(MODE_GCN, input, num_nodes, column_index, degrees, degrees, 1.f, part_pointers,
-                      part2Node, out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream);
+    return launch_agg(MODE_GCN, input, dim, num_nodes, column_index, degrees, degrees, 1.f, part_pointers,
+                      part2Node, out, dim, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream, 0u);
 }
 
 int gnna_agg_gin_f32(const float *input, const int32_t *row_pointers, const int32_t *column_index,
@@ -1099,8 +723,8 @@ int gnna_agg_gin_f32(const float *input, const int32_t *row_pointers, const int3
                      int partSize, int dimWorker, int warpPerBlock, void *stream)
 {
     (void)row_pointers;
-    return launch_agg(MODE_GIN, input, num_nodes, column_index, nullptr, nullptr, epsilon, part_pointers,
-                      part2Node, out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream);
+    return launch_agg(MODE_GIN, input, dim, num_nodes, column_index, nullptr, nullptr, epsilon, part_pointers,
+                      part2Node, out, dim, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream, 0u);
 }
 
 int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
@@ -1111,8 +735,20 @@ int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows, const i
 {
     if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
-    return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
-                      part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0);
+    return launch_agg(mode, input, dim, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
+                      part2Node, out, dim, num_out_rows, dim, num_parts, partSize, 32, 4, stream,
+                      accumulate != 0 ? GNNA_ACCUMULATE : 0u);
+}
+
+int gnna_agg_ld_f32(int mode, const float *input, int64_t ld_in, int64_t num_in_rows, const int32_t *column_index,
+                    const float *degrees_out, const float *degrees_in, float epsilon,
+                    const int32_t *part_pointers, const int32_t *part2Node, float *out, int64_t ld_out,
+                    int64_t num_out_rows, int dim, int64_t num_parts, int partSize, unsigned flags, void *stream)
+{
+    if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
+    return launch_agg(mode, input, ld_in, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
+                      part2Node, out, ld_out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, flags);
 }
 
 int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows, const int32_t *column_index,
@@ -1123,9 +759,9 @@ int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows,
 {
     if (mode != MODE_SAG && mode != MODE_GCN && mode != MODE_GIN)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "unknown mode %d", mode);
-    return launch_agg(mode, input, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
-                      part2Node, out, num_out_rows, dim, num_parts, partSize, 32, 4, stream, accumulate != 0,
-                      num_windows, window_begin, window_end);
+    return launch_agg(mode, input, dim, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
+                      part2Node, out, dim, num_out_rows, dim, num_parts, partSize, 32, 4, stream,
+                      accumulate != 0 ? GNNA_ACCUMULATE : 0u, num_windows, window_begin, window_end);
 }
 
 int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers, const int32_t *part2Node,
@@ -1168,7 +804,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
         if (hot_rows || t.gcn_prescale == 1 || ldx != dim) staged = std::max(staged, x_bytes);   // (GCN pre-scaling stages too)
         int B = 1;
         const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && foot_bytes >= ((size_t)2 << 20);
-        if (dim >= 4 && t.stream_kernel != 2) {
+        {
             if (t.column_phases >= 2 && num_in_rows >= kMaxSlices) B = std::min(t.column_phases, kMaxSlices);
             else if (t.column_phases == 0 && can_slice && foot_bytes >= ((size_t)6 << 20))
                 B = choose_slices(plan.stats, foot_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,

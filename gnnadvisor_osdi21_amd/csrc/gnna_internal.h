@@ -22,21 +22,10 @@ int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // measured schedule for this feature width was registered with gnna_set_graph_phases().  (gnna_host.cpp)
 void apply_graph_hints(const void *column_index, int dim, gnna_tuning *tune);
 
-// Number of column phases for a gather from `x_bytes` of source rows (gnna_agg.hip): tune.column_phases
-// when forced, else from the size of X and the two graph hints; 1 = single pass.
-int choose_phases(const gnna_tuning &tune, size_t x_bytes, int64_t num_parts, int part_size);
-
 // ---- per-device runtime state (gnna_runtime.hip) -------------------------------------------------
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
-};
-// Who owns the run cursors (scratch slot 0) of a stream: the multi-launch schedules of the chunk-walk kernel keep
-// per-run state there between launches -- and, for a windowed aggregation, between library CALLS.
-struct CursorOwner {
-    const void *col = nullptr, *pp = nullptr;
-    int windows = 0;       // number of source windows of the sequence (1 = a whole aggregation in one call)
-    int next_window = 0;   // the window the next call has to start at (== windows: sequence complete)
 };
 struct DeviceState {
     std::atomic<bool> init{false};
@@ -45,8 +34,8 @@ struct DeviceState {
                                // [kFlagSlots + slot] "the packed ids are stale" of the call with that sequence number
     unsigned long long *gap_lists = nullptr;   // ring of kGapSlots lists of kGapWords words
     uint32_t *sweep_sync = nullptr;  // ring of kSweepSyncSlots counter blocks for the sweep kernel's soft barrier
-    std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 0 run cursors, slot 1 pre-scaled X
-    std::map<hipStream_t, CursorOwner> cursor_owner;
+    std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 1 staged / pre-scaled X, slot 2 partial rows of the
+                                                          // deterministic schedule / slabs of the weight-gradient kernel
 };
 constexpr int kFlagSlots = 1024;
 // per-call lists of long runs of rows without edges that the sparse prologue leaves to a grid-wide pass
@@ -56,12 +45,6 @@ constexpr int kGapSlots = 64, kGapEntries = 63, kGapWords = 2 + 2 * kGapEntries;
 int get_device_state(DeviceState **out);
 // Grow-only scratch buffer `slot` of `stream`.
 int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out);
-// Claims the stream's run cursors for the windows [win_begin, win_end) of a `num_windows`-window sequence on the
-// partition (column_index, part_pointers).  A sequence starts at window 0; a later window is accepted only as the
-// continuation of the sequence that is in progress on this stream -- if anything else used the cursors in between
-// (another phased aggregation, an SDDMM, a different graph's windows) the call fails instead of summing wrongly.
-int claim_cursors(DeviceState *ds, hipStream_t stream, const void *column_index, const void *part_pointers,
-                  int num_windows, int win_begin, int win_end);
 // Fresh non-zero sequence number of an aggregation call and its slot in the flag ring.
 int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
 
@@ -73,6 +56,7 @@ struct SlicePlanStats {
     double cells[kSliceLevels] = {0, 0, 0, 0, 0};
     double edges = 0, groups = 0;
     double span = 0;                 // sum over the edges of |column id - destination row|
+    double unsorted = 0;             // neighbor-groups whose column ids are not in non-decreasing order
     double near[24] = {0};           // near[k]: edges with |column id - destination row| < 256 * 2^(k / 2)
 };
 struct SlicePlan {
@@ -95,7 +79,7 @@ inline uint32_t slice_rows_for(int64_t num_in_rows)
 // back-off for partitions that are never seen twice).  A plan made by gnna_prepare_graph is never evicted.
 int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_index, const int32_t *part_pointers,
                    const int32_t *part2Node, int64_t num_parts, int64_t num_in_rows, bool want_stats, bool pin,
-                   SlicePlan *out);
+                   SlicePlan *out, uint32_t window_rows = 0);
 void drop_slice_plans();
 // Packed column ids of a plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.  The
 // caller decides whether the plan may have them (pinned, or gnna_tuning.pack_ids = 1).
@@ -135,6 +119,10 @@ struct StreamLaunch {
     const int32_t *flag; int32_t seq; int32_t trust;
     int64_t P;
     int D, ldx, G, U, S, B;
+    int ldy = 0;                                   // row stride of Y in floats (0: D)
+    int win_lo = 0, win_hi = 0;                    // windowed call: the fine slices (= source windows) it covers; win_hi == S: the rest
+    bool relu = false;                             // epilogue: out = max(out, 0)
+    int64_t num_out_rows = 0;                      // rows of Y (the epilogue's whole-output pass)
     bool wide, plain_ok, xcd_remap;
     float eps;
     bool det = false;                              // deterministic schedule (ordered phase launches, no atomics)
@@ -143,6 +131,8 @@ struct StreamLaunch {
     const int32_t *packed_stale = nullptr;   // *packed_stale == seq: column_index no longer matches the copy, read column_index
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
+// The ReLU epilogue over the whole output on its own (a call that has nothing to aggregate but accumulates into `out`).
+int launch_stream_epilogue_only(const StreamLaunch &a, hipStream_t stream);
 
 // ---- destination-blocked sweep kernel (gnna_sweep.hip) ------------------------------------------------------
 struct SweepLaunch {
@@ -154,6 +144,9 @@ struct SweepLaunch {
     uint32_t *sync;           // kXcds counters, 64 bytes apart, zero when the kernel starts
     int64_t P;
     int D, ldx, U, S, B;
+    int ldy = 0;              // row stride of Y in floats (0: D)
+    bool relu = false;        // epilogue: out = max(out, 0)
+    int64_t num_out_rows = 0;
     int rounds = 0;           // sets per workgroup (0: from rows_with_edges and the accumulator capacity)
     int64_t rows_with_edges = 0;
     int slack = 0;            // soft-barrier slack in steps (0: built-in, >= 1000: none)

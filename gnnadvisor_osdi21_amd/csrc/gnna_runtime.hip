@@ -83,24 +83,6 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
     return GNNA_OK;
 }
 
-int claim_cursors(DeviceState *ds, hipStream_t stream, const void *column_index, const void *part_pointers,
-                  int num_windows, int win_begin, int win_end)
-{
-    std::lock_guard<std::mutex> lock(g_dev_mutex);
-    CursorOwner &o = ds->cursor_owner[stream];
-    if (win_begin > 0) {
-        if (o.col != column_index || o.pp != part_pointers || o.windows != num_windows || o.next_window != win_begin)
-            return fail(GNNA_ERR_INVALID_ARGUMENT,
-                        "source window %d of %d does not continue the windowed aggregation in progress on this stream "
-                        "(expected window %d of %d of %s partition): the windows of one aggregation must be issued in "
-                        "order, with no other phased aggregation or SDDMM on the stream in between",
-                        win_begin, num_windows, o.next_window, o.windows,
-                        (o.col == column_index && o.pp == part_pointers) ? "this" : "another");
-    }
-    o.col = column_index; o.pp = part_pointers; o.windows = num_windows; o.next_window = win_end;
-    return GNNA_OK;
-}
-
 int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot)
 {
     const uint32_t seq_u = g_seq.fetch_add(1) + 1;

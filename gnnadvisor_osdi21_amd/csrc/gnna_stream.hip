@@ -81,12 +81,18 @@ struct StreamParams {
     int64_t blocks_per_phase;  // multiple of kXcds when xcd_remap
     int32_t seq;
     int32_t trust;
-    int32_t D;
-    int32_t ldx;
+    int32_t D;                 // floats per destination row (what is stored)
+    int32_t DL;                // floats per gathered row (>= 4: rows narrower than 4 floats are gathered from a staged,
+                               // 4-float-strided copy and only their first D floats are stored)
+    int32_t ldx;               // row stride of X in floats
+    int32_t ldy;               // row stride of Y in floats
     int32_t G;
-    int32_t S;                 // fine slices (1..16)
-    int32_t B;                 // phases: phase p covers fine slices [p*S/B, (p+1)*S/B)
+    int32_t S;                 // fine slices of the plan
+    int32_t B;                 // phases: phase p covers fine slices [win_lo + p*W/B, win_lo + (p+1)*W/B), W = win_hi - win_lo
+    int32_t win_lo, win_hi;    // the fine slices this launch covers: [0, S) unless the call is one of a windowed sequence
+                               // (win_hi == S: "and everything that is left")
     int32_t phase_lo;          // first phase of this launch
+    int32_t relu;              // 1: rows this work item stores (plain, once) are stored as max(x, 0)
     int32_t plain_ok;          // 1: rows owned by one work item may be written with plain stores
     int32_t xcd_remap;
     // deterministic schedule (gnna_tuning.deterministic): one launch per phase, in order; a row owned by the work item is
@@ -116,6 +122,7 @@ struct SliceStats {
     unsigned long long groups;     // non-empty groups
     unsigned long long span;       // sum over the edges of |column id - destination row|
     unsigned long long near[24];   // near[k]: edges with |column id - destination row| < 256 * 2^(k / 2)
+    unsigned long long unsorted;   // neighbor-groups whose column ids are not in non-decreasing order
 };
 
 __global__ void __launch_bounds__(kBlock)
@@ -125,17 +132,21 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    unsigned long long cells[kSliceLevels] = {0, 0, 0, 0, 0}, edges = 0, groups = 0, span = 0;
+    unsigned long long cells[kSliceLevels] = {0, 0, 0, 0, 0}, edges = 0, groups = 0, span = 0, unsorted = 0;
     unsigned long long near_l = 0;   // lane k < 24 accumulates near[k]
     for (int64_t g = wave; g < P; g += nwaves) {
         const int beg = pp[g], end = pp[g + 1];
         const int row = p2n[g];
         int mine = 0;  // lane f < S accumulates the count of slice f
+        uint32_t last_id = 0;          // the previous tile's last id (wave-uniform)
+        bool descending = false;
         for (int t = beg; t < end; t += kWave) {
             const bool valid = t + lane < end;
             int f = -1, bucket = 99;
+            uint32_t my_id = 0xffffffffu;
             if (valid) {
                 const uint32_t id = (uint32_t)__builtin_nontemporal_load(col + t + lane);
+                my_id = id;
                 f = (int)min(id / slice_rows, (uint32_t)(S - 1));
                 const int dist = (int)id - row;
                 const unsigned ad = (unsigned)(dist < 0 ? -dist : dist);
@@ -146,6 +157,13 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
                     const int m = 31 - __builtin_clz(ad);
                     bucket = 2 * (m - 8) + (ad < (((1u << m) * 181u) >> 7) ? 1 : 2);
                 }
+            }
+            {
+                // sortedness of the group's ids (the windowed entry depends on it): every id against its predecessor
+                const uint32_t prev = lane == 0 ? last_id : (uint32_t)__shfl_up((int)my_id, 1);
+                if (__ballot(valid && (t + lane > beg) && my_id < prev) != 0) descending = true;
+                const int nv = end - t < kWave ? end - t : kWave;
+                last_id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, nv - 1);
             }
 #pragma unroll
             for (int b = 0; b < 24; b++) {
@@ -179,6 +197,7 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
             }
             edges += (unsigned long long)(end - beg);
             groups += 1;
+            if (descending) unsorted += 1;
         }
     }
     // span was accumulated per lane: reduce over the wavefront
@@ -190,6 +209,7 @@ slice_count_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ 
             if (cells[i]) atomicAdd(&stats->cells[i], cells[i]);
         if (edges) atomicAdd(&stats->edges, edges);
         if (groups) atomicAdd(&stats->groups, groups);
+        if (unsorted) atomicAdd(&stats->unsorted, unsorted);
     }
 }
 
@@ -220,13 +240,16 @@ __device__ __forceinline__ void park_row(const typename VecOf<4>::T r, float *__
 // (a partial row parked in library scratch).
 enum { EMIT_STORE = 0, EMIT_ATOMIC = 1, EMIT_RMW = 2, EMIT_PART = 3 };
 template <int LPR>
-__device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *__restrict__ dst, int width, int how, int lane)
+__device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *__restrict__ dst, int width, int how, int lane,
+                                         bool relu)
 {
 #pragma unroll
     for (int i = 0; i < (4 * LPR + kWave - 1) / kWave; i++) {
         const int idx = i * kWave + lane;
         if (idx < width) {
-            if (how == EMIT_STORE) __builtin_nontemporal_store(buf[idx], dst + idx);
+            // (the fused ReLU epilogue applies where the row is complete when it is written: the plain store of a row one
+            // work item owns; rows that are added to are left to the fix-up pass behind the kernel)
+            if (how == EMIT_STORE) __builtin_nontemporal_store(relu ? fmaxf(buf[idx], 0.f) : buf[idx], dst + idx);
             else if (how == EMIT_ATOMIC) unsafeAtomicAdd(dst + idx, buf[idx]);
             else if (how == EMIT_RMW) dst[idx] = dst[idx] + buf[idx];
             else dst[idx] = buf[idx];
@@ -271,6 +294,7 @@ stream_kernel(const StreamParams p)
     const int slot = lane / LPR;
     const int c = lane % LPR;
     const int D = p.D;
+    const int DL = p.DL;
     const bool canonical = p.trust || (*p.flag != p.seq);
     const char *xbase = reinterpret_cast<const char *>(p.X);
     const uint32_t row_bytes32 = (uint32_t)p.ldx * 4u;
@@ -298,7 +322,8 @@ stream_kernel(const StreamParams p)
     const int pa = gl ? p.pp[g0 + lane] : 0;
     const int pb = gl ? p.pp[g0 + lane + 1] : 0;
     // cumulative slice counts of the group at the phase's two slice boundaries (phase-major byte arrays)
-    const int f_lo = p.cnt ? phase * p.S / p.B : 0, f_hi = p.cnt ? (phase + 1) * p.S / p.B : 1;
+    const int W = p.win_hi - p.win_lo;
+    const int f_lo = p.cnt ? p.win_lo + phase * W / p.B : 0, f_hi = p.cnt ? p.win_lo + (phase + 1) * W / p.B : 1;
     int cum_lo = 0, cum_hi = 0x7fffffff;
     if (p.cnt && gl) {
         if (f_lo > 0) cum_lo = p.cnt[(size_t)(f_lo - 1) * (size_t)p.P + (size_t)(g0 + lane)];
@@ -364,21 +389,21 @@ stream_kernel(const StreamParams p)
     const int c_offX = c_offI - c_nl;
     const int L = __builtin_amdgcn_readlane(c_offI, kWave - 1);
 
-    for (int d0 = 0; d0 < D; d0 += 4 * LPR) {
-        // lane c owns the 4 floats starting at dcol; a ragged last piece is shifted back to end at D
+    for (int d0 = 0; d0 < DL; d0 += 4 * LPR) {
+        // lane c owns the 4 floats starting at dcol; a ragged last piece is shifted back to end at DL
         const int piece = d0 + c * 4;
-        const bool cvalid = piece < D;
+        const bool cvalid = piece < DL;
         int dcol = piece, shift = 0;
-        if (piece + 4 > D && cvalid) { dcol = D - 4; shift = piece - dcol; }
+        if (piece + 4 > DL && cvalid) { dcol = DL - 4; shift = piece - dcol; }
         (void)shift;
-        const uint32_t col_off = (uint32_t)(cvalid ? dcol : (d0 + 4 <= D ? d0 : D - 4)) * 4u;
+        const uint32_t col_off = (uint32_t)(cvalid ? dcol : (d0 + 4 <= DL ? d0 : DL - 4)) * 4u;
         VT acc = vzero<4>();
-        const int sweep_width = D - d0 < 4 * LPR ? D - d0 : 4 * LPR;
+        const int sweep_width = D - d0 < 4 * LPR ? D - d0 : 4 * LPR;      // (D < DL only for rows narrower than 4 floats)
         auto drain = [&]() {
             for (int q = 0; q < npend; q++) {
                 const int meta = __builtin_amdgcn_readlane(pend_meta, q);
                 const int64_t row = meta >> 2;
-                float *dst = p.Y + (size_t)row * D + d0;
+                float *dst = p.Y + (size_t)row * (size_t)p.ldy + d0;
                 int how = (meta & 1) ? EMIT_ATOMIC : EMIT_STORE;
                 if (p.det && canonical) {
                     how = EMIT_RMW;
@@ -390,7 +415,7 @@ stream_kernel(const StreamParams p)
                         if (lane == 0) p.det_stamp[chunk * 2 + slot_p] = p.stamp;
                     }
                 }
-                emit_row<LPR>(pend + q * PEND_FLOATS, dst, sweep_width, how, lane);
+                emit_row<LPR>(pend + q * PEND_FLOATS, dst, sweep_width, how, lane, p.relu != 0);
             }
             npend = 0;
         };
@@ -482,7 +507,7 @@ stream_kernel(const StreamParams p)
                 // every edge is written once, in the one phase that owns it
                 // (lanes past the row end read the sweep's first piece instead of running past A's last row: their
                 // value is zeroed in dot_of, the address must still be inside the tensor)
-                const float *abase = p.A + (cvalid ? dcol : (d0 + 4 <= D ? d0 : D - 4));
+                const float *abase = p.A + (cvalid ? dcol : (d0 + 4 <= DL ? d0 : DL - 4));
                 auto a_ptr = [&](int j) -> const MT * {
                     return reinterpret_cast<const MT *>(abase + (size_t)__builtin_amdgcn_readlane(row_j, j) * (size_t)D);
                 };
@@ -593,7 +618,7 @@ stream_kernel(const StreamParams p)
 // row -- in chunk order, and adds the sum to the output with a plain read-modify-write.  Only partials stamped by
 // this phase's launch count (a chunk without edges of the row in this phase wrote none); consumed stamps are cleared.
 __global__ void __launch_bounds__(kBlock)
-det_fixup_kernel(const int32_t *__restrict__ p2n, int64_t P, int G, int64_t num_chunks, float *__restrict__ Y, int D,
+det_fixup_kernel(const int32_t *__restrict__ p2n, int64_t P, int G, int64_t num_chunks, float *__restrict__ Y, int D, int ldy,
                  const float *__restrict__ part, int32_t *__restrict__ stamps, int32_t stamp)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -618,7 +643,7 @@ det_fixup_kernel(const int32_t *__restrict__ p2n, int64_t P, int G, int64_t num_
                 if (stamps[j * 2] == stamp && i < D) acc += part[((size_t)j * 2) * (size_t)D + i];
                 if (!(p2n[h1 - 1] == rl && h1 < P && p2n[h1] == rl)) break;      // the row ends inside chunk j
             }
-            if (i < D) Y[(size_t)rl * (size_t)D + i] += acc;
+            if (i < D) Y[(size_t)rl * (size_t)ldy + i] += acc;
         }
         // clear what was consumed (a stale stamp must never match a later launch)
         if (lane == 0) {
@@ -631,6 +656,36 @@ det_fixup_kernel(const int32_t *__restrict__ p2n, int64_t P, int G, int64_t num_
                 if (!(p2n[h1 - 1] == rl && h1 < P && p2n[h1] == rl)) break;
             }
         }
+    }
+}
+
+// ---- fused ReLU epilogue: the rows the kernel could not finish -------------------------------------------
+// stream_kernel applies max(x, 0) where it stores a row it owns (single pass, plain stores).  Behind it:
+//   whole == 0: the rows that two or more work items added to -- a row that continues across a chunk boundary
+//               (groups g0 - 1 and g0 of one row, g0 a multiple of G) -- are clamped here, one wavefront per boundary
+//               (a hub row spanning many chunks is clamped once per boundary: idempotent);
+//   whole != 0, or the partition turned out not to be canonical (every row was added atomically): the whole output.
+__global__ void __launch_bounds__(kBlock)
+relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const int32_t *__restrict__ p2n, int64_t P, int G,
+                  const int32_t *flag, int32_t seq, int whole)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    if (whole || *flag == seq) {
+        for (int64_t r = wave; r < N; r += nwaves) {
+            float *row = Y + (size_t)r * (size_t)ldy;
+            for (int i = lane; i < D; i += kWave) row[i] = fmaxf(row[i], 0.f);
+        }
+        return;
+    }
+    const int64_t num_chunks = (P + G - 1) / G;
+    for (int64_t c = 1 + wave; c < num_chunks; c += nwaves) {
+        const int64_t g0 = c * G;
+        const int r = p2n[g0];
+        if (p2n[g0 - 1] != r || r < 0 || r >= N) continue;
+        float *row = Y + (size_t)r * (size_t)ldy;
+        for (int i = lane; i < D; i += kWave) row[i] = fmaxf(row[i], 0.f);
     }
 }
 
@@ -826,11 +881,12 @@ void count_event(int which) { g_counters[which].fetch_add(1, std::memory_order_r
 // single-pass schedule).  `pin` (gnna_prepare_graph) keeps the plan until gnna_release_graph.
 int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_index, const int32_t *part_pointers,
                    const int32_t *part2Node, int64_t num_parts, int64_t num_in_rows, bool want_stats, bool pin,
-                   SlicePlan *out)
+                   SlicePlan *out, uint32_t window_rows)
 {
     *out = SlicePlan();
     const int S = kMaxSlices;
-    const uint32_t slice_rows = slice_rows_for(num_in_rows);
+    // (window_rows > 0: the fine slices are the caller's source windows -- the windowed entry -- instead of 1/32 of the rows)
+    const uint32_t slice_rows = window_rows ? window_rows : slice_rows_for(num_in_rows);
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_plan_mutex);
@@ -938,6 +994,7 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
     out->stats.edges = (double)hit->stats.edges;
     out->stats.groups = (double)hit->stats.groups;
     out->stats.span = (double)hit->stats.span;
+    out->stats.unsorted = (double)hit->stats.unsorted;
     for (int i = 0; i < 24; i++) out->stats.near[i] = (double)hit->stats.near[i];
     return GNNA_OK;
 }
@@ -1081,12 +1138,31 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     return GNNA_OK;
 }
 
+// The part of the ReLU epilogue the aggregation kernel leaves behind (nothing when the call has no epilogue).
+static int launch_relu_fixup(const StreamLaunch &a, int G, bool whole, hipStream_t stream)
+{
+    if (!a.relu || a.mode == MODE_SDDMM) return GNNA_OK;
+    const int64_t units = whole ? a.num_out_rows : (a.P + G - 1) / G;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((units + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16));
+    hipLaunchKernelGGL(relu_fixup_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a.Y, a.num_out_rows, a.D,
+                       a.ldy > 0 ? a.ldy : a.D, a.p2n, a.P, G, a.flag, a.seq, whole ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GNNA_ERR_HIP, "epilogue launch: %s", hipGetErrorString(e));
+    return GNNA_OK;
+}
+
+int launch_stream_epilogue_only(const StreamLaunch &a, hipStream_t stream)
+{
+    return launch_relu_fixup(a, 1, /*whole=*/true, stream);
+}
+
 int launch_stream(const StreamLaunch &a, hipStream_t stream)
 {
     StreamParams p;
     p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
     p.deg_row = a.deg_row; p.deg_col = a.deg_col; p.A = a.A;
     p.flag = a.flag; p.P = a.P; p.seq = a.seq; p.trust = a.trust; p.D = a.D; p.ldx = a.ldx;
+    p.DL = std::max(a.D, 4); p.ldy = a.ldy > 0 ? a.ldy : a.D;
     p.G = std::max(1, std::min(a.G, kWave));
     p.num_chunks = (a.P + p.G - 1) / p.G;
     int64_t items = (p.num_chunks + kSWaves - 1) / kSWaves;
@@ -1094,12 +1170,18 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     if (p.xcd_remap) items = (items + kXcds - 1) / kXcds * kXcds;
     p.blocks_per_phase = items;
     p.S = a.cnt ? a.S : 1; p.B = a.cnt ? a.B : 1; p.phase_lo = 0;
+    p.win_lo = 0; p.win_hi = p.S;
+    if (a.cnt && a.win_hi > a.win_lo) { p.win_lo = a.win_lo; p.win_hi = std::min(a.win_hi, p.S); }
     p.plain_ok = a.plain_ok ? 1 : 0;
+    // fused ReLU: in the kernel where a row is stored once (single pass over a canonical partition, plain stores), by
+    // the fix-up pass for everything else
+    const bool relu_in_kernel = a.relu && a.mode != MODE_SDDMM && p.B == 1 && a.plain_ok && !a.det;
+    p.relu = relu_in_kernel ? 1 : 0;
     p.eps = a.eps;
     const int64_t grid = items * (int64_t)p.B;
     if (grid > 0x7fffffffLL) return fail(GNNA_ERR_UNSUPPORTED, "aggregation grid too large (%lld blocks)", (long long)grid);
     int lpr = 4;
-    const int pieces = (a.D + 3) / 4;
+    const int pieces = (p.DL + 3) / 4;
     while (lpr < 64 && lpr < pieces) lpr <<= 1;
     StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
@@ -1117,16 +1199,16 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
             p.stamp = (int32_t)((((uint32_t)a.seq & 0x1ffffffu) << 6) | (uint32_t)ph);
             hipLaunchKernelGGL(k, dim3((unsigned)items), dim3(kSBlock), 0, stream, p);
             hipLaunchKernelGGL(det_fixup_kernel, dim3((unsigned)fblocks), dim3(kBlock), 0, stream, a.p2n, a.P, p.G, p.num_chunks,
-                               a.Y, a.D, a.det_part, a.det_stamp, p.stamp);
+                               a.Y, a.D, p.ldy, a.det_part, a.det_stamp, p.stamp);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
-        return GNNA_OK;
+        return launch_relu_fixup(a, p.G, /*whole=*/true, stream);
     }
     hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(kSBlock), 0, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(e));
-    return GNNA_OK;
+    return launch_relu_fixup(a, p.G, /*whole=*/!relu_in_kernel, stream);
 }
 
 }  // namespace gnna

@@ -94,6 +94,8 @@ struct SweepParams {
     int32_t trust;
     int32_t D;
     int32_t ldx;
+    int32_t ldy;               // row stride of Y in floats
+    int32_t relu;              // 1: a row the set owns (written once, plain store) is written as max(x, 0)
     int32_t S;
     int32_t B;
     int32_t rounds;            // sets per workgroup
@@ -128,6 +130,58 @@ __device__ __forceinline__ int64_t lower_bound64(const int32_t *__restrict__ pp,
         hi = new_hi > new_lo ? new_hi : new_lo;
     }
     return lo;
+}
+
+// First group of set i of num_sets (one wavefront; every lane returns it): an equal share of the EDGES, found by a search
+// in part_pointers -- for a partition that is not canonical (no search can be trusted on its part_pointers; every group
+// then flushes per slice anyway) an equal share of the GROUPS.  With packed ids the sets start at multiples of 64 groups,
+// so that a set's chunks are the global chunks the copy is laid out by.
+__device__ __forceinline__ int64_t sweep_set_start(int64_t i, int64_t num_sets, int64_t nnz, const int32_t *__restrict__ pp,
+                                                   int64_t P, bool canonical, bool align64, int lane)
+{
+    // (nnz < 2^31 and sets < 2^31: the products fit 64 bits; P < 2^31 groups)
+    const int64_t target = i >= num_sets ? nnz : (nnz * i) / num_sets;
+    int64_t g = i <= 0 ? 0 : (i >= num_sets ? P : (canonical ? lower_bound64(pp, P, target, lane) : (P * i) / num_sets));
+    if (align64 && g < P) g &= ~(int64_t)(kWave - 1);
+    return g;
+}
+
+// The ReLU epilogue's second half: a row two sets share was ADDED to the output by both (float atomics), so it is clamped
+// here, behind the kernel -- one wavefront per set boundary; everything when the partition is not canonical (every row was
+// added per slice) or `whole` is set (the call accumulates into an existing output).
+__global__ void __launch_bounds__(kBlock)
+sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const int32_t *__restrict__ pp,
+                        const int32_t *__restrict__ p2n, int64_t P, int64_t num_sets, int align64, int cap_rows,
+                        const int32_t *flag, int32_t seq, int32_t trust, int whole)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const bool canonical = trust || (*flag != seq);
+    if (whole || !canonical) {
+        for (int64_t r = wave; r < N; r += nwaves) {
+            float *row = Y + (size_t)r * (size_t)ldy;
+            for (int i = lane; i < D; i += kWave) row[i] = fmaxf(row[i], 0.f);
+        }
+        return;
+    }
+    const int64_t nnz = (int64_t)pp[P];
+    for (int64_t i = wave; i < num_sets; i += nwaves) {
+        const int64_t g_lo = sweep_set_start(i, num_sets, nnz, pp, P, true, align64 != 0, lane);
+        const int64_t g_hi = sweep_set_start(i + 1, num_sets, nnz, pp, P, true, align64 != 0, lane);
+        if (g_hi <= g_lo) continue;
+        const int row_first = p2n[g_lo], row_last = p2n[g_hi - 1];
+        // the row the set shares with its predecessor (the row it shares with its successor is that set's first row) ...
+        if (g_lo > 0 && p2n[g_lo - 1] == row_first && row_first >= 0 && row_first < N) {
+            float *row = Y + (size_t)row_first * (size_t)ldy;
+            for (int k = lane; k < D; k += kWave) row[k] = fmaxf(row[k], 0.f);
+        }
+        // ... and the rows beyond the set's accumulators: flushed per slice with atomics, never stored
+        for (int64_t r = (int64_t)row_first + cap_rows; r <= row_last && r < N; r++) {
+            float *row = Y + (size_t)r * (size_t)ldy;
+            for (int k = lane; k < D; k += kWave) row[k] = fmaxf(row[k], 0.f);
+        }
+    }
 }
 
 template <int LPR, int MODE, int U, int WGS>
@@ -186,14 +240,7 @@ sweep_kernel(const SweepParams p)
         // ---- the set: an equal share of the edges, XCD-major, then workgroup, then round -------------------
         const int64_t set = ((int64_t)xcd * nbx + bx) * R + r;
         if (wib < 2) {
-            const int64_t i = set + wib;
-            // (nnz < 2^31 and sets < 2^31: the product fits 64 bits)
-            const int64_t target = i >= num_sets ? nnz : (nnz * i) / num_sets;
-            // (a partition that is not canonical may hold a part_pointers array no search can be trusted on: its sets
-            // are equal shares of the GROUPS -- every group then flushes per slice anyway; P < 2^31 groups x < 2^21 sets)
-            int64_t g = i <= 0 ? 0 : (i >= num_sets ? p.P : (canonical ? lower_bound64(p.pp, p.P, target, lane)
-                                                                        : (p.P * i) / num_sets));
-            if (p.ids_packed && g < p.P) g &= ~(int64_t)(kWave - 1);
+            const int64_t g = sweep_set_start(set + wib, num_sets, nnz, p.pp, p.P, canonical, p.ids_packed != nullptr, lane);
             if (lane == 0) s_g[wib] = g;
         }
         if (threadIdx.x == 0) { s_ctl[0] = 0; s_ctl[1] = 0; }
@@ -438,7 +485,7 @@ sweep_kernel(const SweepParams p)
                                         scale = p.eps;
                                         if (p.row_scale) scale *= p.row_scale[row];
                                     }
-                                    float *dst = p.Y + (size_t)row * (size_t)D + dcol;
+                                    float *dst = p.Y + (size_t)row * (size_t)p.ldy + dcol;
                                     if constexpr (LPR <= 16) {
                                         if (add_lane) unsafeAtomicAdd(dst + comp, rr[0] * scale);
                                     } else {
@@ -496,11 +543,12 @@ sweep_kernel(const SweepParams p)
                 scale = p.eps;
                 if (p.row_scale) scale *= p.row_scale[row];
             }
-            float *dst = p.Y + (size_t)row * (size_t)D;
+            float *dst = p.Y + (size_t)row * (size_t)p.ldy;
             const float *src = s_acc + q * D;
             for (int i = lane; i < D; i += kWave) {
                 const float val = src[i] * scale;
-                if (!use_atomic) __builtin_nontemporal_store(val, dst + i);
+                // (fused ReLU: where the row is complete at this, its only, write; shared rows: sweep_relu_fixup_kernel)
+                if (!use_atomic) __builtin_nontemporal_store(p.relu ? fmaxf(val, 0.f) : val, dst + i);
                 else unsafeAtomicAdd(dst + i, val);
             }
         }
@@ -556,6 +604,8 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
     p.flag = a.flag; p.seq = a.seq; p.trust = a.trust; p.sync = a.sync;
     p.P = a.P; p.D = a.D; p.ldx = a.ldx; p.S = a.S; p.B = a.B; p.plain_ok = a.plain_ok ? 1 : 0; p.eps = a.eps;
+    p.ldy = a.ldy > 0 ? a.ldy : a.D;
+    p.relu = (a.relu && a.plain_ok) ? 1 : 0;
     p.slack = a.slack > 0 ? a.slack : 2;
     p.ids_packed = a.packed_stale ? a.ids_packed : nullptr; p.item_off = a.item_off; p.packed_stale = a.packed_stale;
     p.num_chunks = (a.P + kWave - 1) / kWave;
@@ -581,6 +631,19 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "sweep launch: %s", hipGetErrorString(e));
     count_event(CTR_SWEEP_LAUNCHES);
+    if (a.relu) {
+        const bool whole = !a.plain_ok;
+        const int64_t num_sets = (int64_t)grid * p.rounds;
+        const int64_t units = whole ? a.num_out_rows : num_sets;
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((units + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16));
+        // (the kernel's accumulator capacity at this width, in rows: ACC / D of the variant that runs)
+        const int acc = wgs == 1 ? (lpr >= 16 ? acc_floats<16, 1>() : acc_floats<8, 1>()) : (lpr >= 16 ? acc_floats<16, 2>() : acc_floats<8, 2>());
+        hipLaunchKernelGGL(sweep_relu_fixup_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a.Y, a.num_out_rows, a.D, p.ldy,
+                           a.pp, a.p2n, a.P, num_sets, p.ids_packed ? 1 : 0, acc / std::max(1, a.D), a.flag, a.seq, a.trust,
+                           whole ? 1 : 0);
+        e = hipGetLastError();
+        if (e != hipSuccess) return fail(GNNA_ERR_HIP, "epilogue launch: %s", hipGetErrorString(e));
+    }
     return GNNA_OK;
 }
 

@@ -9,7 +9,7 @@
 // libgnna.so (include/gnna.h); the dense updates X W and G W^T stay torch::mm (rocBLAS /
 // hipBLASLt) exactly where the reference calls it, the weight gradient X^T G goes to libgnna's
 // MFMA kernel (gnna_xtg_f32).  Extension functions beyond the reference's six: backward_weight,
-// aggregate_gin, xtg (used by ops.py).
+// aggregate_gin, xtg, aggregate_ld (used by ops.py).
 //
 // Differences from the reference, all deliberate (DESIGN.md "Boundary"):
 //   * work is enqueued on PyTorch's *current* HIP stream of the input's device (the
@@ -88,6 +88,51 @@ torch::Tensor aggregate(AggKind kind, const torch::Tensor &input, const torch::T
                               warpPerBlock, stream);
         break;
     }
+    TORCH_CHECK(rc == GNNA_OK, "GNNAdvisor (libgnna) error ", rc, ": ", gnna_last_error());
+    return out;
+}
+
+// The general entry (gnna_agg_ld_f32): `input` and `out` may be row-strided views (stride(1) == 1; stride(0) is the leading
+// dimension), the result can be added to `out` and clamped at zero in the same call.
+torch::Tensor aggregate_general(int mode, const torch::Tensor &input, const torch::Tensor &column_index,
+                                const c10::optional<torch::Tensor> &degrees, double epsilon,
+                                const torch::Tensor &part_pointers, const torch::Tensor &part2Node, int partSize,
+                                c10::optional<torch::Tensor> out_opt, bool accumulate, bool relu)
+{
+    CHECK_CUDA(input);
+    TORCH_CHECK(input.dim() == 2, "input must be 2-D [num_nodes, dim]");
+    CHECK_F32(input);
+    CHECK_INPUT(column_index); CHECK_I32(column_index);
+    CHECK_INPUT(part_pointers); CHECK_I32(part_pointers);
+    CHECK_INPUT(part2Node); CHECK_I32(part2Node);
+    TORCH_CHECK(mode >= 0 && mode <= 2, "mode must be 0 (sag), 1 (gcn) or 2 (gin)");
+    TORCH_CHECK(input.size(1) <= 1 || input.stride(1) == 1, "input: the floats of a row must be contiguous (stride(1) == 1)");
+    const int64_t n = input.size(0);
+    const int64_t dim = input.size(1);
+    auto ld_of = [&](const torch::Tensor &t) { return t.size(0) > 1 ? t.stride(0) : std::max<int64_t>(t.size(1), t.stride(0)); };
+    if (mode == 1) {
+        TORCH_CHECK(degrees.has_value(), "mode 1 (gcn) needs the degree norms");
+        CHECK_INPUT((*degrees)); CHECK_F32((*degrees));
+        TORCH_CHECK(degrees->size(0) >= n, "degrees shorter than num_nodes");
+    }
+    at::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(input.device());
+    static const bool poison = std::getenv("GNNA_DEBUG_POISON") && std::atoi(std::getenv("GNNA_DEBUG_POISON")) != 0;
+    torch::Tensor out;
+    if (out_opt.has_value()) {
+        out = *out_opt;
+        CHECK_CUDA(out); CHECK_F32(out);
+        TORCH_CHECK(out.dim() == 2 && out.size(0) == n && out.size(1) == dim, "out must be [num_nodes, dim] like input");
+        TORCH_CHECK(dim <= 1 || out.stride(1) == 1, "out: the floats of a row must be contiguous (stride(1) == 1)");
+    } else {
+        TORCH_CHECK(!accumulate, "accumulate needs an existing `out`");
+        out = poison ? torch::full({n, dim}, std::numeric_limits<float>::quiet_NaN(), input.options()) : torch::empty({n, dim}, input.options());
+    }
+    void *stream = at::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    const float *deg = degrees.has_value() ? degrees->data_ptr<float>() : nullptr;
+    const unsigned flags = (accumulate ? GNNA_ACCUMULATE : 0u) | (relu ? GNNA_EPILOGUE_RELU : 0u);
+    int rc = gnna_agg_ld_f32(mode, input.data_ptr<float>(), ld_of(input), n, column_index.data_ptr<int32_t>(), deg, deg,
+                             (float)epsilon, part_pointers.data_ptr<int32_t>(), part2Node.data_ptr<int32_t>(),
+                             out.data_ptr<float>(), ld_of(out), n, (int)dim, part2Node.size(0), partSize, flags, stream);
     TORCH_CHECK(rc == GNNA_OK, "GNNAdvisor (libgnna) error ", rc, ": ", gnna_last_error());
     return out;
 }
@@ -336,6 +381,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("backward_weight", &spmm_backward_weight, "GNNAdvisor backward, d_weight only (extension)");
     m.def("forward_gin", &spmm_forward_gin, "GNNAdvisor forward GIN (HIP, gfx950)");
     m.def("backward_gin", &spmm_backward_gin, "GNNAdvisor backward GIN (HIP, gfx950)");
+    m.def("aggregate_ld", &aggregate_general,
+          "general aggregation (extension): mode 0 sag / 1 gcn / 2 gin; input and out may be row-strided views; "
+          "accumulate adds into out; relu clamps the result at zero in the same call",
+          pybind11::arg("mode"), pybind11::arg("input"), pybind11::arg("column_index"), pybind11::arg("degrees"),
+          pybind11::arg("epsilon"), pybind11::arg("part_pointers"), pybind11::arg("part2Node"), pybind11::arg("partSize"),
+          pybind11::arg("out") = pybind11::none(), pybind11::arg("accumulate") = false, pybind11::arg("relu") = false);
     m.def("build_part", &build_part, "GNNAdvisor neighbor-group partitioner (CPU)", pybind11::arg("partSize"),
           pybind11::arg("indptr"), pybind11::arg("float_compat") = false);
 }

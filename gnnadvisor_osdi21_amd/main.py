@@ -157,7 +157,7 @@ def main(argv=None):
                 self.conv2 = GCNConv(args.hidden, dataset.num_classes)
 
             def forward(self):
-                x = F.relu(self.conv1(dataset.x, inputInfo.set_input()))
+                x = self.conv1(dataset.x, inputInfo.set_input(), relu=True)   # F.relu(conv1(...)), fused (GNNA_main.py:151)
                 x = self.conv2(x, inputInfo.set_hidden())
                 return F.log_softmax(x, dim=1)
     else:
@@ -170,9 +170,8 @@ def main(argv=None):
             def forward(self):
                 x = dataset.x
                 for i, conv in enumerate(self.convs):
-                    x = conv(x, inputInfo.set_input() if i == 0 else inputInfo.set_hidden())
-                    if i + 1 < len(self.convs):
-                        x = F.relu(x)
+                    # F.relu after every layer but the last (GNNA_main.py:166-169), fused where the aggregation ends the layer
+                    x = conv(x, inputInfo.set_input() if i == 0 else inputInfo.set_hidden(), relu=i + 1 < len(self.convs))
                 return F.log_softmax(x, dim=1)
 
     model = Net().to(device)

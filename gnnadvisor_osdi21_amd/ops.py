@@ -53,11 +53,35 @@ class GNNAFunction(Function):
     @staticmethod
     def backward(ctx, d_output):
         X, weight = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
-            # first layer: the features need no gradient (the reference computes and drops d_input)
-            return None, GNNA.backward_weight(d_output.contiguous(), X, *ctx.graph, *ctx.knobs)[0], None
-        d_input, d_weight = GNNA.backward(d_output.contiguous(), X, weight, *ctx.graph, *ctx.knobs)
-        return d_input, d_weight, None
+        return _gcn_backward(ctx, d_output.contiguous(), X, weight)
+
+
+def _gcn_backward(ctx, d_output, X, weight):
+    """(d_input, d_weight, None) of a GCN layer from the gradient of its (pre-activation) output."""
+    if not ctx.needs_input_grad[0]:
+        # first layer: the features need no gradient (the reference computes and drops d_input)
+        return None, GNNA.backward_weight(d_output, X, *ctx.graph, *ctx.knobs)[0], None
+    d_input, d_weight = GNNA.backward(d_output, X, weight, *ctx.graph, *ctx.knobs)
+    return d_input, d_weight, None
+
+
+class GNNAFunction_ReLU(Function):
+    """relu(GCN layer) in one pass: the aggregation's epilogue clamps every row where it is written (libgnna
+    GNNA_EPILOGUE_RELU; reference call site F.relu(conv1(...)), GNNA_main.py:151) -- one elementwise pass over [N, hidden]
+    less per layer.  Backward masks dY with (Y > 0), which the saved output itself provides."""
+
+    @staticmethod
+    def forward(ctx, X, weight, inputInfo):
+        rp, ci, deg, pp, p2n = _graph_args(inputInfo)
+        ctx.graph, ctx.knobs = (rp, ci, deg, pp, p2n), _knobs(inputInfo)
+        Y = GNNA.aggregate_ld(1, torch.mm(X, weight), ci, deg, 1.0, pp, p2n, inputInfo.partSize, None, False, True)
+        ctx.save_for_backward(X, weight, Y)
+        return Y
+
+    @staticmethod
+    def backward(ctx, d_output):
+        X, weight, Y = ctx.saved_tensors
+        return _gcn_backward(ctx, d_output * (Y > 0), X, weight)
 
 
 class GNNAFunction_GIN(Function):
@@ -97,19 +121,26 @@ class GNNAFunction_GIN_UpdateFirst(Function):
     output width.  Chosen by GINConv when the layer narrows (Reddit layer 1: 602 -> 64)."""
 
     @staticmethod
-    def forward(ctx, X, weight, inputInfo, eplison):
+    def forward(ctx, X, weight, inputInfo, eplison, relu=False):
         rp, ci, _deg, pp, p2n = _graph_args(inputInfo)
         ctx.graph, ctx.knobs, ctx.eplison = (rp, ci, pp, p2n), _knobs(inputInfo), eplison
+        ctx.relu = bool(relu)
+        if relu:      # the aggregation is the layer's last step here, so its epilogue can clamp
+            Y = GNNA.aggregate_ld(2, torch.mm(X, weight), ci, None, eplison, pp, p2n, inputInfo.partSize, None, False, True)
+            ctx.save_for_backward(X, weight, Y)
+            return Y
         ctx.save_for_backward(X, weight)
         return GNNA.aggregate_gin(torch.mm(X, weight), rp, ci, eplison, pp, p2n, *ctx.knobs)
 
     @staticmethod
     def backward(ctx, d_output):
-        X, weight = ctx.saved_tensors
+        X, weight = ctx.saved_tensors[:2]
         rp, ci, pp, p2n = ctx.graph
+        if ctx.relu:
+            d_output = d_output * (ctx.saved_tensors[2] > 0)
         G = GNNA.aggregate_gin(d_output.contiguous(), rp, ci, ctx.eplison, pp, p2n, *ctx.knobs)   # A symmetric
         d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
-        return d_input, GNNA.xtg(X, G), None, None
+        return d_input, GNNA.xtg(X, G), None, None, None
 
 
 class _NeighborConv(Module):
@@ -127,10 +158,11 @@ class _NeighborConv(Module):
 
 
 class GCNConv(_NeighborConv):
-    def forward(self, X, inputInfo):
+    def forward(self, X, inputInfo, relu=False):
         """X: [num_nodes, input_dim]; inputInfo: decider.inputProperty holding the CSR, the
-        sqrt-degree vector and the neighbor-group partition on X's device."""
-        return GNNAFunction.apply(X, self.weights, inputInfo)
+        sqrt-degree vector and the neighbor-group partition on X's device.  relu=True returns relu(layer) with the
+        clamp fused into the aggregation (same values as F.relu(conv(X, inputInfo)))."""
+        return (GNNAFunction_ReLU if relu else GNNAFunction).apply(X, self.weights, inputInfo)
 
 
 class GINConv(_NeighborConv):
@@ -150,6 +182,10 @@ class GINConv(_NeighborConv):
         needs_dx = X.requires_grad and torch.is_grad_enabled()
         return 2 * fout < (2 * fin if needs_dx else fin)
 
-    def forward(self, X, inputInfo):
-        fn = GNNAFunction_GIN_UpdateFirst if self._use_update_first(X) else GNNAFunction_GIN
-        return fn.apply(X, self.weights, inputInfo, self.eplison)
+    def forward(self, X, inputInfo, relu=False):
+        """relu=True returns relu(layer): fused into the aggregation when the layer runs update-first (the aggregation is
+        its last step), an ordinary F.relu behind the dense update otherwise."""
+        if self._use_update_first(X):
+            return GNNAFunction_GIN_UpdateFirst.apply(X, self.weights, inputInfo, self.eplison, relu)
+        Y = GNNAFunction_GIN.apply(X, self.weights, inputInfo, self.eplison)
+        return torch.relu(Y) if relu else Y

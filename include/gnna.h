@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 400 /* 0.4.0: gnna_forget_graph; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
+#define GNNA_VERSION 400 /* 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -172,18 +172,41 @@ GNNA_API int gnna_agg_rect_f32(int mode, const float *input, int64_t num_in_rows
                       float *out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
                       int accumulate, void *stream);
 
+/* General form: gnna_agg_rect_f32 with leading dimensions and an epilogue.
+ *   ld_in / ld_out: floats between the starts of consecutive rows of `input` / `out` (>= dim; == dim: the contiguous
+ *     layout every other entry point assumes -- the reference insists on contiguous tensors, GNNAdvisor.cpp:71-73).
+ *     With them a producer can write the layout the gather likes best itself -- rows of 17..64 floats that start at
+ *     multiples of 2 x ceil(4 dim / 128) x 128 bytes (stride 64 / 128 / 128 floats for dim 32 / 41 / 64), rows padded
+ *     to a 128-byte-line-friendly stride (41 -> 48) -- and the library then gathers from `input` directly instead of
+ *     staging a copy per call; a column block of a wider matrix (dim = 64, ld = 256) can be aggregated in place, and
+ *     the result can land in a slice of a wider buffer (concatenated layer outputs).
+ *   flags: GNNA_ACCUMULATE     add into the existing contents of `out` (the `accumulate` of gnna_agg_rect_f32);
+ *          GNNA_EPILOGUE_RELU  out = max(out, 0) after the aggregation (and the accumulate): fused into the store wherever a
+ *                              row is written once (sweep kernel, owned rows of a single pass), a small pass over the rows
+ *                              that several work items add to otherwise.  Reference call sites: F.relu(conv(...)) after
+ *                              every layer, GNNA_main.py:151,166-169.
+ * mode, degrees_out / degrees_in, epsilon as for gnna_agg_rect_f32. */
+#define GNNA_ACCUMULATE 1u
+#define GNNA_EPILOGUE_RELU 2u
+GNNA_API int gnna_agg_ld_f32(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
+                      const int32_t *column_index, const float *degrees_out, const float *degrees_in,
+                      float epsilon, const int32_t *part_pointers, const int32_t *part2Node,
+                      float *out, int64_t ld_out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
+                      unsigned flags, void *stream);
+
 /* Windowed form of gnna_agg_rect_f32, for pipelining the aggregation with a chunked feature
  * exchange (multi-GPU: the all-gather is issued in `num_windows` pieces and each piece is
  * aggregated as soon as it has arrived).  The source rows are cut into `num_windows` (1..16) equal
  * windows of ceil(num_in_rows / num_windows) rows; this call aggregates the edges whose source
  * lies in windows [window_begin, window_end) and must only read those rows of `input`.
- * Contract: the calls of one aggregation are issued on one stream in increasing window order,
- * starting at window 0 and ending at window num_windows-1, with identical other arguments and no
- * other multi-launch (chunk-walk phased) aggregation or SDDMM on that stream in between (per-run
- * cursors live in the stream's scratch).  A window call that does not continue the sequence in
- * progress on its stream is refused with GNNA_ERR_INVALID_ARGUMENT instead of summing wrongly.  The first call overwrites `out` unless accumulate != 0; later calls add.  Column
- * ids need not be sorted; an id below the current windows that was skipped earlier is consumed
- * by a later call, and the last window consumes everything that is left.
+ * Contract: the calls of one aggregation cover every window exactly once, in increasing window order, with
+ * identical other arguments; the call with window_begin == 0 overwrites `out` unless accumulate != 0, later calls
+ * add.  The column ids of every neighbor-group must be in non-decreasing order (the loader's CSR; checked -- once per
+ * graph, by the counting pass that builds the per-window counts -- and refused with GNNA_ERR_UNSUPPORTED otherwise:
+ * a window call takes the id POSITIONS of its windows, which are its ids only when the ids are sorted).  Stateless
+ * between the calls (0.4.0: runs on the streaming kernel; the per-run cursors of the earlier implementation are gone);
+ * the first call of a sequence on a graph the library has not seen synchronises the stream once (not inside a stream
+ * capture: GNNA_ERR_UNSUPPORTED there -- run the sequence once before capturing it).
  */
 GNNA_API int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows,
                       const int32_t *column_index, const float *degrees_out, const float *degrees_in,
@@ -217,14 +240,13 @@ GNNA_API int gnna_xtg_f32(const float *X, const float *G, float *dW, int64_t num
 typedef struct gnna_tuning {
     int groups_per_chunk; /* neighbor-groups a wavefront walks per work item (1..64)      */
     int loads_in_flight;  /* wave-wide row loads issued before the first add (4, 8, 16)   */
-    int blocks_per_cu;    /* > 0: persistent grid of this many 256-thread blocks per CU;
-                             0: one wavefront per work item (hardware scheduled)          */
+    int blocks_per_cu;    /* sweep kernel only: workgroups per CU (1: one 16-wavefront workgroup with all of the
+                             CU's LDS, 2: two); the streaming kernel's grid is hardware scheduled            */
     int xcd_remap;        /* 1: consecutive work items stay on one XCD's L2; 0: off       */
     int trust_canonical;  /* 1: skip the partition validation pass (build_part output)    */
     int column_phases;    /* 1: single pass; 2..32: gather X in that many source-id ranges (cache-resident
-                             slices; the streaming kernel runs them as one launch, the chunk-walk kernel one
-                             launch each); 0: automatic -- streaming kernel: from the library's own statistics of
-                             the partition; chunk-walk kernel: from the size of X and the two hints below */
+                             slices, all in one launch); 0: automatic, from the library's own statistics of
+                             the partition */
     int avg_degree;       /* hint: average edges per destination row (0 = unknown)           */
     int nonlocal_ids;     /* hint: 1 = source ids of a row are scattered over the whole id
                              range (no community ordering), 0 = unknown / locality-ordered  */
@@ -239,10 +261,8 @@ typedef struct gnna_tuning {
                              multiples of twice their 128-byte lines -- stride 64 / 128 / 128 floats for
                              32 / 41 / 64 -- while the copy stays Infinity-Cache sized: 2-6 % off the
                              gather), > 2 = this stride in floats (experiments) */
-    int stream_kernel;    /* 0/1 = the streaming kernel with the sliced (single-launch, stateless) schedule
-                             where it applies (rows of >= 4 floats, unweighted or pre-scaled gather, no
-                             source windows), 2 = always the chunk-walk kernel with per-launch column
-                             phases (round-1 schedule; what source windows and rows narrower than 4 floats always use) */
+    int stream_kernel;    /* reserved (ignored): selected round 1's chunk-walk kernel, retired in 0.4.0 -- the streaming
+                             kernel runs every width and the windowed entry now; kept so that the struct's layout stays */
     int zero_fill;        /* what the prologue clears before a single pass of the streaming kernel that overwrites
                              `out`: 1 = only the rows that pass does not store (rows without edges, rows shared by
                              two work items), 2 = the whole output, 0 = automatic (1 once `out` is >= 32 MiB).

@@ -22,8 +22,8 @@ SCHEDULES = {
     "default": dict(),
     "sliced_3": dict(column_phases=3),
     "sliced_16_g5": dict(column_phases=16, groups_per_chunk=5),
-    "chunk_walk": dict(stream_kernel=2),
-    "chunk_walk_3_phases": dict(stream_kernel=2, column_phases=3),
+    "seven_groups_per_item": dict(groups_per_chunk=7),
+    "sliced_5_g64_deterministic": dict(column_phases=5, groups_per_chunk=64, deterministic=1),
     "gcn_per_edge": dict(gcn_prescale=2),
     "gcn_prescaled": dict(gcn_prescale=1, pad_rows=1),
     "one_group_per_item": dict(groups_per_chunk=1),

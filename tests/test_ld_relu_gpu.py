@@ -1,0 +1,214 @@
+"""gnna_agg_ld_f32: leading dimensions for `input` / `out` and the fused ReLU epilogue (0.4.0), against the oracle
+(checker only).  The reference insists on contiguous tensors (GNNAdvisor.cpp:71-73) and applies F.relu as a separate
+elementwise op after every layer (GNNA_main.py:151,166-169); both are relaxed / fused here, the values must not change."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from gnnadvisor_osdi21_amd import _lib, graph, load_extension
+from util import assert_close_f64, make_case, dev
+
+pytestmark = pytest.mark.gpu
+
+MODES = ((0, 1.0), (1, 1.0), (2, 0.5))
+
+
+def _padded(rows, dim, ld, fill, gen=None, device="cuda"):
+    """A [rows, ld] buffer filled with `fill` whose [:, :dim] view is what the library sees."""
+    buf = torch.full((rows, ld), fill, device=device)
+    return buf, buf[:, :dim]
+
+
+@pytest.mark.parametrize("dim", [4, 16, 41, 64, 100])
+@pytest.mark.parametrize("phases", [1, 3])
+def test_leading_dimensions_for_input_and_output(dim, phases):
+    """ld in {D, D + 4, 2 D, 128}: the gather reads rows `ld_in` apart (directly where the layout suits it, through the
+    staged copy otherwise), the result lands in rows `ld_out` apart, and the floats between the rows are never touched."""
+    g, Xc, ppc, p2nc = make_case(2500, 150000, dim, 32, seed=dim + phases, kind="powerlaw")
+    rp, ci, deg, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), Xc.numpy()
+    cid, degd, pp, p2n = dev(g.column_index, g.degrees, ppc, p2nc)
+    n = g.num_nodes
+    try:
+        _lib.set_tuning(column_phases=phases)
+        for ld in sorted({dim, dim + 4, 2 * dim, max(128, dim)}):
+            xbuf, xv = _padded(n, dim, ld, 7.5)
+            xv.copy_(Xc)
+            for mode, eps in MODES:
+                ref = oracle.csr_f64(mode, Xn, rp, ci, deg, eps)
+                scale = oracle.csr_f64(mode, np.abs(Xn), rp, ci, deg, eps)
+                ybuf, yv = _padded(n, dim, ld, -3.25)
+                _lib.agg_ld(mode, xv, cid, pp, p2n, n, 32, degrees_out=degd, degrees_in=degd, epsilon=eps, out=yv)
+                assert_close_f64(yv.cpu().numpy(), ref, what=f"D={dim} ld={ld} mode={mode} phases={phases}", scale=scale)
+                if ld > dim:
+                    assert bool((ybuf[:, dim:] == -3.25).all()), "the floats between the output rows were written"
+                    assert bool((xbuf[:, dim:] == 7.5).all())
+                # accumulate + a different stride on each side
+                ybuf2, yv2 = _padded(n, dim, ld + 8, 0.0)
+                base = torch.randn(n, dim, generator=torch.Generator().manual_seed(3))
+                yv2.copy_(base)
+                _lib.agg_ld(mode, xv, cid, pp, p2n, n, 32, degrees_out=degd, degrees_in=degd, epsilon=eps, out=yv2,
+                            accumulate=True)
+                assert_close_f64(yv2.cpu().numpy(), ref + base.double().numpy(), what=f"accumulate D={dim} ld={ld} mode={mode}",
+                                 scale=scale + np.abs(base.numpy()))
+                assert bool((ybuf2[:, dim:] == 0.0).all())
+    finally:
+        _lib.reset_tuning()
+
+
+def test_a_gapped_layout_from_the_caller_is_gathered_without_a_staging_copy():
+    """Reddit-like rows (gathered hundreds of times each) of 64 floats: the library would stage them into a copy with
+    stride 128; a caller that hands over that layout itself (ld_in = 128, 512-byte aligned) gets the same schedule with
+    no scale_rows_kernel launch -- and the same values."""
+    g = graph.make_config_graph("reddit-like", device="cuda", scale=0.3)
+    pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
+    ppd, p2nd = pp.cuda(), p2n.cuda()
+    n, D = g.num_nodes, 64
+    X = torch.randn(n, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    buf = torch.zeros(n, 128, device="cuda")
+    assert buf.data_ptr() % 512 == 0
+    Xg = buf[:, :D]
+    Xg.copy_(X)
+    y0 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
+    y1 = _lib.agg_ld(0, Xg, g.column_index, ppd, p2nd, n, 64)
+    scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double().clamp(min=1.0)
+    assert bool(((y0.double() - y1.double()).abs() <= 1e-5 * scale).all())
+    # X = ones through the gapped view: exact row counts
+    Xg.fill_(1.0)
+    y = _lib.agg_ld(0, Xg, g.column_index, ppd, p2nd, n, 64)
+    degs = (g.row_pointers[1:] - g.row_pointers[:-1]).float()
+    assert bool((y == degs[:, None]).all())
+
+
+def test_column_blocks_of_a_wide_matrix_are_aggregated_in_place():
+    """dim = 64 blocks of a [N, 256] matrix, ld_in = ld_out = 256: four calls fill the four column blocks of a [N, 256] output."""
+    g, Xc, ppc, p2nc = make_case(3000, 200000, 256, 32, seed=12, kind="powerlaw")
+    rp, ci = g.row_pointers.numpy(), g.column_index.numpy()
+    X, cid, pp, p2n = dev(Xc, g.column_index, ppc, p2nc)
+    n = g.num_nodes
+    Y = torch.full((n, 256), float("nan"), device="cuda")
+    for b in range(4):
+        _lib.agg_ld(0, X[:, 64 * b:64 * b + 64], cid, pp, p2n, n, 32, out=Y[:, 64 * b:64 * b + 64])
+    assert_close_f64(Y.cpu().numpy(), oracle.csr_f64(0, Xc.numpy(), rp, ci), what="column blocks",
+                     scale=oracle.csr_f64(0, np.abs(Xc.numpy()), rp, ci))
+
+
+def _hub_graph(n, hub_deg, seed):
+    """A graph with one row of `hub_deg` edges (split over many work items) in front of ordinary rows."""
+    rng = np.random.default_rng(seed)
+    deg = rng.integers(0, 40, size=n)
+    deg[3] = hub_deg
+    deg[n // 2] = hub_deg // 2
+    deg[5] = 0
+    rp = np.zeros(n + 1, dtype=np.int32)
+    rp[1:] = np.cumsum(deg)
+    ci = np.concatenate([np.sort(rng.choice(n, size=min(d, n), replace=False)) for d in deg]).astype(np.int32)
+    return torch.from_numpy(rp), torch.from_numpy(ci)
+
+
+RELU_SCHEDULES = {
+    "single_pass": dict(column_phases=1),
+    "single_pass_g3": dict(column_phases=1, groups_per_chunk=3),
+    "single_pass_sparse_fill": dict(column_phases=1, zero_fill=1),
+    "sliced_4": dict(column_phases=4),
+    "sweep_8": dict(column_phases=8, sweep=1),
+    "sweep_4_two_wgs": dict(column_phases=4, sweep=1, blocks_per_cu=2),
+    "sweep_many_sets": dict(column_phases=4, sweep=1, groups_per_chunk=64 * 5),
+    "deterministic_3": dict(column_phases=3, deterministic=1),
+}
+
+
+@pytest.mark.parametrize("schedule", sorted(RELU_SCHEDULES))
+@pytest.mark.parametrize("dim", [3, 16, 41, 64])
+def test_fused_relu_equals_relu_of_the_oracle(schedule, dim):
+    """GNNA_EPILOGUE_RELU under every schedule: rows stored once are clamped in the kernel, rows that several work items add
+    to (a hub row split over many chunks / sets, every row of a sliced call) by the fix-up pass -- the result is
+    max(oracle, 0) within the usual bound, and rows without edges are exactly 0."""
+    n = 4000
+    rp_t, ci_t = _hub_graph(n, 3000, seed=dim)
+    X = torch.randn(n, dim, generator=torch.Generator().manual_seed(dim))
+    deg_t = torch.sqrt(torch.clamp((rp_t[1:] - rp_t[:-1]).float(), min=1.0))
+    ps = 16
+    pp, p2n = _lib.build_part(ps, rp_t)
+    rp, ci, deg, Xn = rp_t.numpy(), ci_t.numpy(), deg_t.numpy(), X.numpy()
+    Xd, cid, degd, ppd, p2nd = dev(X, ci_t, deg_t, pp, p2n)
+    try:
+        _lib.set_tuning(**RELU_SCHEDULES[schedule])
+        for mode, eps in ((0, 1.0), (1, 1.0), (2, -0.5)):
+            ref = oracle.csr_f64(mode, Xn, rp, ci, deg, eps)
+            scale = oracle.csr_f64(mode, np.abs(Xn), rp, ci, deg, abs(eps))
+            y = _lib.agg_ld(mode, Xd, cid, ppd, p2nd, n, ps, degrees_out=degd, degrees_in=degd, epsilon=eps, relu=True)
+            got = y.cpu().numpy()
+            assert (got >= 0).all(), f"{schedule} D={dim} mode={mode}: negative values survived the epilogue"
+            # |max(a, 0) - max(b, 0)| <= |a - b|
+            assert_close_f64(got, np.maximum(ref, 0.0), what=f"relu {schedule} D={dim} mode={mode}", scale=scale)
+            assert (got[5] == 0).all()
+        # accumulate + relu: max(base + A X, 0)
+        base = torch.randn(n, dim, generator=torch.Generator().manual_seed(1))
+        out = base.clone().cuda()
+        _lib.agg_ld(0, Xd, cid, ppd, p2nd, n, ps, out=out, accumulate=True, relu=True)
+        ref = oracle.csr_f64(0, Xn, rp, ci) + base.double().numpy()
+        assert_close_f64(out.cpu().numpy(), np.maximum(ref, 0.0), what=f"relu + accumulate {schedule} D={dim}",
+                         scale=oracle.csr_f64(0, np.abs(Xn), rp, ci) + np.abs(base.numpy()))
+    finally:
+        _lib.reset_tuning()
+
+
+def test_fused_relu_on_a_partition_that_is_not_canonical():
+    """Shuffled neighbor-groups: every row is added atomically, so the epilogue must be the whole-output pass."""
+    g, Xc, ppc, p2nc = make_case(800, 30000, 20, 8, seed=77, kind="powerlaw")
+    rp, ci, Xn = g.row_pointers.numpy(), g.column_index.numpy(), Xc.numpy()
+    P = p2nc.numel()
+    perm = torch.randperm(P, generator=torch.Generator().manual_seed(2))
+    # groups in shuffled order: part_pointers cannot stay a prefix array, so every group gets its own copy of its edges
+    lens = (ppc[1:] - ppc[:-1])[perm]
+    pp_s = torch.zeros(P + 1, dtype=torch.int32)
+    pp_s[1:] = torch.cumsum(lens, 0)
+    ci_s = torch.cat([g.column_index[int(ppc[p]):int(ppc[p + 1])] for p in perm.tolist()]).contiguous()
+    p2n_s = p2nc[perm].contiguous()
+    Xd, cid, ppd, p2nd = dev(Xc, ci_s, pp_s, p2n_s)
+    ref = oracle.csr_f64(0, Xn, rp, ci)
+    for kw in (dict(column_phases=1), dict(column_phases=4, sweep=1), dict(column_phases=3)):
+        try:
+            _lib.set_tuning(**kw)
+            y = _lib.agg_ld(0, Xd, cid, ppd, p2nd, g.num_nodes, 8, relu=True)
+        finally:
+            _lib.reset_tuning()
+        assert_close_f64(y.cpu().numpy(), np.maximum(ref, 0.0), what=f"relu, shuffled groups {kw}",
+                         scale=oracle.csr_f64(0, np.abs(Xn), rp, ci))
+
+
+def test_relu_layers_of_the_op_layer_match_the_unfused_ones():
+    """ops.GCNConv(relu=True) / ops.GINConv(relu=True) == F.relu(conv(...)): outputs and all gradients."""
+    from gnnadvisor_osdi21_amd import ops
+    from gnnadvisor_osdi21_amd.decider import inputProperty
+    g = graph.powerlaw_graph(3000, 120000, 800, seed=21)
+    class _DS:
+        num_nodes, avg_degree, avg_edgeSpan, num_features, reorder_flag = g.num_nodes, g.avg_degree, g.avg_edgeSpan, 20, False
+
+        def rabbit_reorder(self):
+            pass
+    info = inputProperty(g.row_pointers, g.column_index, g.degrees.cuda(), 32, 32, 4, 100, hiddenDim=16, dataset_obj=_DS(),
+                         manual_mode=True)
+    info.decider()
+    GNNA = load_extension()
+    pp, p2n = GNNA.build_part(info.partSize, info.row_pointers)
+    info.row_pointers, info.column_index = info.row_pointers.cuda(), info.column_index.cuda()
+    info.partPtr, info.part2Node = pp.int().cuda(), p2n.int().cuda()
+    info = info.set_hidden()
+    torch.manual_seed(4)
+    for make, fin, fout in ((lambda a, b: ops.GCNConv(a, b), 20, 16), (lambda a, b: ops.GINConv(a, b, update_first=True), 40, 8),
+                            (lambda a, b: ops.GINConv(a, b, update_first=False), 12, 24)):
+        layer = make(fin, fout).cuda()
+        X = torch.randn(g.num_nodes, fin, device="cuda")
+        wgt = torch.randn(g.num_nodes, fout, device="cuda")
+        res = []
+        for fused in (False, True):
+            Xr = X.clone().requires_grad_(True)
+            layer.zero_grad()
+            y = layer(Xr, info, relu=True) if fused else torch.relu(layer(Xr, info))
+            (y * wgt).sum().backward()
+            res.append((y.detach(), Xr.grad.detach(), layer.weights.grad.detach().clone()))
+        for a, b, name in zip(res[0], res[1], ("out", "dX", "dW")):
+            tol = 1e-4 * max(1.0, float(a.abs().max()))
+            assert float((a - b).abs().max()) <= tol, (name, fin, fout, float((a - b).abs().max()))
