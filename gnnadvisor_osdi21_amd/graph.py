@@ -165,6 +165,75 @@ def powerlaw_shard(num_local: int, num_global: int, num_edges: int, max_degree: 
     return rp.to(torch.int32), c.to(torch.int32)
 
 
+def rmat_graph(num_nodes: int, num_edges: int, *, a: float = 0.57, b: float = 0.19, c: float = 0.19, seed: int = 0,
+               device="cpu", permute: bool = True) -> CSRGraph:
+    """Seeded R-MAT graph (SURVEY.md 8d names it beside the Chung-Lu generator: a, b, c = 0.57, 0.19, 0.19) with
+    ~num_edges CSR entries: every undirected pair picks, level by level, one quadrant of the adjacency matrix with
+    probabilities (a, b, c, 1 - a - b - c); ids beyond ``num_nodes`` are folded back (modulo).  R-MAT's own numbering
+    puts the hubs at the low ids and correlates the ids of neighbours; ``permute`` relabels the nodes at random (the
+    "natural order" of the other generators), ``permute=False`` keeps the structured numbering.  Symmetrised and
+    deduplicated by ``csr_from_edges`` like every other graph here."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    m = num_edges // 2
+    if num_nodes == 0 or m == 0:
+        e = torch.zeros(0, dtype=torch.int64, device=dev)
+        return graph_from_edges(e, e, num_nodes)
+    levels = max(1, (num_nodes - 1).bit_length())
+    u = torch.zeros(m, dtype=torch.int64, device=dev)
+    v = torch.zeros(m, dtype=torch.int64, device=dev)
+    for _ in range(levels):
+        r = torch.rand(m, generator=g, device=dev)
+        down = r >= a + b                                   # quadrants c, d: the source's bit is 1
+        right = ((r >= a) & (r < a + b)) | (r >= a + b + c)  # quadrants b, d: the destination's bit is 1
+        u = u * 2 + down.to(torch.int64)
+        v = v * 2 + right.to(torch.int64)
+    u, v = u.remainder(num_nodes), v.remainder(num_nodes)
+    if permute:
+        perm = torch.randperm(num_nodes, generator=g, device=dev)
+        u, v = perm[u], perm[v]
+    keep = u != v
+    u, v = u[keep], v[keep]
+    return graph_from_edges(torch.cat([u, v]), torch.cat([v, u]), num_nodes)
+
+
+def community_graph(num_nodes: int, num_edges: int, num_communities: int, *, p_in: float = 0.9, exponent: float = 2.1,
+                    max_degree: int = 0, seed: int = 0, device="cpu", scramble: bool = False) -> CSRGraph:
+    """Seeded community-structured graph (a degree-corrected block model): ``num_communities`` equal, contiguous id
+    ranges; the first end point of a pair is drawn with power-law popularity, the second inside the first one's
+    community with probability ``p_in`` (power-law inside the community too), anywhere otherwise.  ``scramble`` relabels
+    the nodes at random -- the same structure with its locality hidden, which is what a renumbering has to recover."""
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    m = num_edges // 2
+    if num_nodes == 0 or m == 0:
+        e = torch.zeros(0, dtype=torch.int64, device=dev)
+        return graph_from_edges(e, e, num_nodes)
+    C = max(1, min(int(num_communities), num_nodes))
+    size = (num_nodes + C - 1) // C
+    w = _powerlaw_weights(num_nodes, num_edges / num_nodes, float(max_degree or num_nodes - 1), exponent, dev)
+    w = w[torch.randperm(num_nodes, generator=g, device=dev)]           # popularity is independent of the community
+    cdf = torch.cumsum(w, 0)
+    u = torch.searchsorted(cdf, torch.rand(m, generator=g, device=dev, dtype=torch.float64) * cdf[-1]).clamp_(max=num_nodes - 1)
+    v = torch.searchsorted(cdf, torch.rand(m, generator=g, device=dev, dtype=torch.float64) * cdf[-1]).clamp_(max=num_nodes - 1)
+    # inside the community of u: a popularity-weighted draw from the community's own stretch of the cdf
+    lo = torch.div(u, size, rounding_mode="floor") * size
+    hi = (lo + size).clamp_(max=num_nodes)
+    base = torch.where(lo > 0, cdf[(lo - 1).clamp_(min=0)], torch.zeros_like(cdf[lo]))
+    span = cdf[hi - 1] - base
+    inside = torch.searchsorted(cdf, base + torch.rand(m, generator=g, device=dev, dtype=torch.float64) * span)
+    inside = torch.minimum(torch.maximum(inside, lo), hi - 1)
+    v = torch.where(torch.rand(m, generator=g, device=dev) < p_in, inside, v)
+    if scramble:
+        perm = torch.randperm(num_nodes, generator=g, device=dev)
+        u, v = perm[u], perm[v]
+    keep = u != v
+    u, v = u[keep], v[keep]
+    return graph_from_edges(torch.cat([u, v]), torch.cat([v, u]), num_nodes)
+
+
 def uniform_graph(num_nodes: int, num_edges: int, *, seed: int = 0, symmetric: bool = True,
                   device="cpu") -> CSRGraph:
     """Seeded Erdos-Renyi-style multigraph edge list (duplicates and self loops allowed in

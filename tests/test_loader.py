@@ -223,3 +223,31 @@ def test_sharded_loader_with_renumbering_is_a_relabelled_graph():
     for s in shards:
         lo, hi = s.row_range
         assert torch.equal(s.column_index, ci_all[int(rp_all[lo]):int(rp_all[hi])])
+
+
+def test_rmat_and_community_generators_are_seeded_symmetric_and_shaped_as_named():
+    """SURVEY 8(d) names R-MAT (a, b, c = 0.57, 0.19, 0.19) beside the Chung-Lu generator; the community generator is the
+    structured counterpart the selection rules are also checked on.  Both: symmetric, no self loops, sorted rows,
+    reproducible from the seed; R-MAT is heavy-tailed, the community graph keeps most edges inside a block and hides that
+    when scrambled."""
+    import scipy.sparse as sp
+    for make in (lambda s: graph.rmat_graph(3000, 80000, seed=s), lambda s: graph.community_graph(3000, 60000, 10, seed=s)):
+        g, g_again, g_other = make(5), make(5), make(6)
+        assert torch.equal(g.column_index, g_again.column_index) and torch.equal(g.row_pointers, g_again.row_pointers)
+        assert not torch.equal(g.column_index, g_other.column_index[:g.nnz]) or g.nnz != g_other.nnz
+        rp, ci = g.row_pointers.numpy(), g.column_index.numpy()
+        A = sp.csr_matrix((np.ones(len(ci)), ci, rp), shape=(g.num_nodes, g.num_nodes))
+        assert (A != A.T).nnz == 0 and A.diagonal().sum() == 0
+        for i in (0, 17, g.num_nodes - 1):
+            row = ci[rp[i]:rp[i + 1]]
+            assert (np.diff(row) > 0).all()
+        assert np.allclose(g.degrees.numpy(), np.sqrt(np.maximum(np.diff(rp), 1)))
+    r = graph.rmat_graph(1 << 12, 120000, seed=1)
+    deg = np.diff(r.row_pointers.numpy())
+    assert deg.max() > 20 * deg.mean() and np.median(deg) < deg.mean()          # heavy tail
+    c = graph.community_graph(6000, 120000, 10, seed=2, p_in=0.9)
+    rows = np.repeat(np.arange(6000), np.diff(c.row_pointers.numpy()))
+    inside = (rows // 600 == c.column_index.numpy() // 600).mean()
+    assert inside > 0.8
+    cs = graph.community_graph(6000, 120000, 10, seed=2, p_in=0.9, scramble=True)
+    assert cs.nnz == c.nnz and cs.avg_edgeSpan > 2.5 * c.avg_edgeSpan

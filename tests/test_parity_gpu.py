@@ -589,13 +589,13 @@ def test_a_scattered_ids_hint_overrides_the_locality_test():
     g = graph.make_config_graph("reddit-like", device="cuda", scale=0.25, locality=0.97)
     pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
     ppd, p2nd = pp.cuda(), p2n.cuda()
-    X = torch.randn(g.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    X = torch.randn(g.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     try:
         y1 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
         assert _lib.last_num_phases() == 1                     # ids near the diagonal: the L2 keeps the window anyway
         _lib.set_tuning(nonlocal_ids=1)
         y2 = _lib.sag(X, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4)
-        assert _lib.last_num_phases() >= 2                     # told otherwise: X = 59.6 MB is sliced
+        assert _lib.last_num_phases() >= 2                     # told otherwise: X = 14.9 MB is sliced
     finally:
         _lib.reset_tuning()
     scale = _lib.sag(X.abs(), g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4).double()
@@ -825,14 +825,14 @@ def test_per_graph_hints_are_keyed_by_the_column_index_array():
     for g in (g1, g2):
         pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
         parts.append((pp.cuda(), p2n.cuda()))
-    X1 = torch.randn(g1.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
-    X2 = torch.randn(g2.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    X1 = torch.randn(g1.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    X2 = torch.randn(g2.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
     run1 = lambda: _lib.sag(X1, g1.row_pointers, g1.column_index, g1.degrees, *parts[0], 64, 32, 4)
     run2 = lambda: _lib.sag(X2, g2.row_pointers, g2.column_index, g2.degrees, *parts[1], 64, 32, 4)
     try:
         y1 = run1(); assert _lib.last_num_phases() == 1
         _lib.set_graph_hints(g1.column_index, g1.nnz / g1.num_nodes, True)
-        y1h = run1(); assert _lib.last_num_phases() >= 2       # 59.6 MB of X, "scattered" ids, degree ~490
+        y1h = run1(); assert _lib.last_num_phases() >= 2       # 14.9 MB of X, "scattered" ids, degree ~490
         run2(); assert _lib.last_num_phases() == 1             # the other graph is unaffected
         _lib.set_graph_hints(g2.column_index, 30, False)
         _lib.set_tuning(avg_degree=500, nonlocal_ids=1)        # process-wide hints lose against per-graph ones
