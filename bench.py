@@ -156,7 +156,7 @@ class Workload:
     """One single-GPU aggregation workload: graph + partition + features, and its step()."""
 
     def __init__(self, config, dim, dev, *, scale=1.0, locality=0.0, manual=False, part_size=0,
-                 calibrate=True, force_phases=0, prepare=True):
+                 calibrate=True, force_phases=0, prepare=True, producer_layout=True):
         import torch
         from gnnadvisor_osdi21_amd import _lib, graph
         from gnnadvisor_osdi21_amd.decider import inputProperty, calibrate_phases
@@ -181,8 +181,17 @@ class Workload:
         self.ppd, self.p2nd = self.pp.to(dev), self.p2n.to(dev)
         self.P = int(self.p2n.numel())
         gen = torch.Generator(device=dev).manual_seed(1234)
-        self.X = torch.randn(g.num_nodes, dim, device=dev, generator=gen)
-        self.out = torch.empty_like(self.X)
+        self.Xc = torch.randn(g.num_nodes, dim, device=dev, generator=gen)          # the contiguous layout of the reference
+        # the layout a producer writes for this gather (gnna_preferred_ld: e.g. torch::mm into buf[:, :64] of a [N, 128]
+        # allocation -- every 256-byte row on its own 512-byte boundary): gathered from directly through gnna_agg_ld_f32,
+        # no staged copy per call.  The contiguous-layout figure (gnna_sag_f32 stages the copy itself) rides beside it.
+        self.ld = dim if (manual or not producer_layout) else _lib.preferred_ld(dim, g.num_nodes, g.nnz)
+        if self.ld != dim:
+            self.X = _lib.empty_rows(g.num_nodes, dim, self.ld, dev)
+            self.X.copy_(self.Xc)
+        else:
+            self.X = self.Xc
+        self.out = torch.empty_like(self.Xc)
         self.calibrated = None
         if not manual:
             # Decider auto mode, measuring part: register this graph's hints and let the tuner time the
@@ -203,8 +212,11 @@ class Workload:
 
     def step(self, X=None, out=None):
         g = self.g
-        return self._lib.sag(self.X if X is None else X, g.row_pointers, g.column_index, g.degrees,
-                             self.ppd, self.p2nd, self.ps, 32, 4, out=self.out if out is None else out)
+        X = self.X if X is None else X
+        out = self.out if out is None else out
+        if not X.is_contiguous():         # rows with a leading dimension: the general entry
+            return self._lib.agg_ld(0, X, g.column_index, self.ppd, self.p2nd, g.num_nodes, self.ps, out=out)
+        return self._lib.sag(X, g.row_pointers, g.column_index, g.degrees, self.ppd, self.p2nd, self.ps, 32, 4, out=out)
 
     def time(self, steps, warmup):
         import torch
@@ -239,8 +251,9 @@ class Workload:
             1e-4 * max(1, sum |x_j|) per element (north_star: 1e-4 fp32)."""
         import torch
         g = self.g
-        ones = torch.ones_like(self.X)
-        y1 = torch.empty_like(self.X)
+        ones = torch.empty_like(self.X) if self.X.is_contiguous() else self._lib.empty_rows(g.num_nodes, self.dim, self.ld, self.dev)
+        ones.fill_(1.0)                                        # (same layout as the timed input)
+        y1 = torch.empty_like(self.Xc)
         self.step(ones, y1)
         deg = (g.row_pointers[1:] - g.row_pointers[:-1]).to(torch.float32)
         exact = bool((y1 == deg[:, None]).all())
@@ -254,7 +267,7 @@ class Workload:
         ok = True
         for i in rows:
             b, e = int(g.row_pointers[i]), int(g.row_pointers[i + 1])
-            xs = self.X[g.column_index[b:e].long()].double()
+            xs = self.Xc[g.column_index[b:e].long()].double()
             ref = xs.sum(0)
             scale = torch.clamp(xs.abs().sum(0), min=1.0)
             err = (self.out[i].double() - ref).abs()
@@ -772,7 +785,7 @@ def reference_style_ms(w, dims=(16, 64), warmup: int = 10, calls: int = 200):
     GNNA = load_extension()
     g, res = w.g, {}
     for d in dims:
-        X = w.X if d == w.dim else torch.randn(g.num_nodes, d, device=w.dev, generator=torch.Generator(device=w.dev).manual_seed(d))
+        X = w.Xc if d == w.dim else torch.randn(g.num_nodes, d, device=w.dev, generator=torch.Generator(device=w.dev).manual_seed(d))
         for _ in range(warmup):
             GNNA.SAG(X, g.row_pointers, g.column_index, g.degrees, w.ppd, w.p2nd, w.ps, 32, 4)
         torch.cuda.synchronize()
@@ -791,9 +804,9 @@ def other_modes(w, steps: int = 10):
     import torch
     _lib, g = w._lib, w.g
     res = {}
-    for name, fn in (("gcn_weighted", lambda: _lib.agg_gcn(w.X, g.row_pointers, g.column_index, g.degrees, w.ppd,
+    for name, fn in (("gcn_weighted", lambda: _lib.agg_gcn(w.Xc, g.row_pointers, g.column_index, g.degrees, w.ppd,
                                                            w.p2nd, w.ps, 32, 4, out=w.out)),
-                     ("gin_eps", lambda: _lib.agg_gin(w.X, g.row_pointers, g.column_index, 0.5, w.ppd, w.p2nd,
+                     ("gin_eps", lambda: _lib.agg_gin(w.Xc, g.row_pointers, g.column_index, 0.5, w.ppd, w.p2nd,
                                                       w.ps, 32, 4, out=w.out))):
         for _ in range(3):
             fn()
@@ -803,23 +816,30 @@ def other_modes(w, steps: int = 10):
             fn()
         torch.cuda.synchronize()
         res[name + "_edges_per_s"] = g.nnz * steps / (time.perf_counter() - t0)
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        _lib.profile_begin(steps)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        pr = _lib.profile_end()
+        return {"edges_per_s": g.nnz * steps / el, "ms_per_step": el * 1e3 / steps, "kernel_ms": pr["main_ms"]}
+    sag_contiguous = lambda: _lib.sag(w.Xc, g.row_pointers, g.column_index, g.degrees, w.ppd, w.p2nd, w.ps, 32, 4, out=w.out)
+    if getattr(w, "ld", w.dim) != w.dim:
+        # the reference's contiguous layout through gnna_sag_f32 (the library stages the gapped copy itself, per call)
+        res["sag_contiguous_input"] = dict(timed(sag_contiguous), what="contiguous X through gnna_sag_f32 (prepared graph); the "
+                                           "library stages the rows into its gapped layout on every call")
     if getattr(w, "prepared", False):
-        # the same SAG calls with the ids read from column_index (gnna_tuning.pack_ids = 2): what a caller gets who
-        # uses the six reference functions only, without gnna_prepare_graph
+        # what a caller of the six reference functions gets: contiguous X, gnna_sag_f32, no gnna_prepare_graph
+        # (gnna_tuning.pack_ids = 2: the ids are read from column_index)
         _lib.set_tuning(pack_ids=2)
         try:
-            for _ in range(3):
-                w.step()
-            torch.cuda.synchronize()
-            _lib.profile_begin(steps)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                w.step()
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            pr = _lib.profile_end()
-            res["sag_without_prepare_graph"] = {"edges_per_s": g.nnz * steps / el, "ms_per_step": el * 1e3 / steps,
-                                                "kernel_ms": pr["main_ms"], "what": "column ids read from column_index (no packed copy)"}
+            res["sag_without_prepare_graph"] = dict(timed(sag_contiguous), what="six reference functions only: contiguous X, "
+                                                    "column ids read from column_index (no packed copy)")
         finally:
             _lib.set_tuning(pack_ids=0)
     return res
@@ -897,6 +917,10 @@ def run_single(args, result_fd):
                    "feature_MB": x_mb, "parallelism": "single GPU", "world_size": 1, "device": str(dev),
                    "decider": "manual (partSize 32)" if args.manual else "auto (mi355x policy)",
                    "column_phases_used": w.phases, "calibrated_phases": w.calibrated, "tuning": tuning,
+                   "input_leading_dimension": w.ld,
+                   "input_layout": ("rows written by the producer with leading dimension %d floats (gnna_preferred_ld) and gathered "
+                                    "through gnna_agg_ld_f32 without a staged copy; contiguous-layout figure: contiguous_ms_per_step"
+                                    % w.ld) if w.ld != args.dim else "contiguous rows (gnna_sag_f32)",
                    "graph_lifecycle": ("gnna_prepare_graph before the timed region (as the driver does): plan pinned, column ids "
                                        "packed in the order the sliced schedule reads them" if w.prepared else "none (six reference functions only)")},
         "roofline": roofline_record(w, kern_ms, pro_ms, traffic.get(id(w)),
@@ -950,6 +974,8 @@ def run_single(args, result_fd):
         rec["config"].update({"dropin_ms_per_step": drop["ms_per_step"] if drop else (ms_per_step if not w.prepared else None),
                               "dropin_value": drop["edges_per_s"] if drop else (rec["value"] if not w.prepared else None),
                               "dropin_kernel_ms": drop["kernel_ms"] if drop else (kern_ms if not w.prepared else None),
+                              "contiguous_ms_per_step": (modes.get("sag_contiguous_input") or {}).get("ms_per_step"),
+                              "contiguous_value": (modes.get("sag_contiguous_input") or {}).get("edges_per_s"),
                               "gcn_weighted_value": modes.get("gcn_weighted_edges_per_s"),
                               "gin_value": modes.get("gin_eps_edges_per_s")})
     # the driver keeps only the contract's keys of this line: everything else rides inside `config` / `roofline`
@@ -961,7 +987,7 @@ def run_single(args, result_fd):
     if others:
         rec["roofline"]["other_workloads"] = others
     if extras and not args.no_cpu_baseline:
-        rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.X.cpu(), w.pp, w.p2n, args.dim)
+        rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.Xc.cpu(), w.pp, w.p2n, args.dim)
     os.write(result_fd, (json.dumps(rec) + "\n").encode())
 
 

@@ -29,7 +29,7 @@ class Tuning(ctypes.Structure):
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
                 ("pad_rows", ctypes.c_int), ("stream_kernel", ctypes.c_int), ("zero_fill", ctypes.c_int),
                 ("sweep", ctypes.c_int), ("sweep_slack", ctypes.c_int), ("deterministic", ctypes.c_int),
-                ("pack_ids", ctypes.c_int)]
+                ("pack_ids", ctypes.c_int), ("wide_blocks", ctypes.c_int)]
 
 
 _lib = None
@@ -46,7 +46,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
            "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
-           "gnna_forget_graph", "gnna_agg_ld_f32")
+           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld")
 
 
 def load() -> ctypes.CDLL:
@@ -86,6 +86,8 @@ def load() -> ctypes.CDLL:
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                   ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
+    L.gnna_preferred_ld.restype = ctypes.c_int64
+    L.gnna_preferred_ld.argtypes = [ctypes.c_int, ctypes.c_int64, ctypes.c_int64]
     L.gnna_agg_rect_windows_f32.restype = ctypes.c_int
     L.gnna_agg_rect_windows_f32.argtypes = (L.gnna_agg_rect_f32.argtypes[:-1]
                                             + [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p])
@@ -155,10 +157,11 @@ def _stream(device: torch.device) -> int:
 
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
-               pad_rows=-1, stream_kernel=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1) -> None:
+               pad_rows=-1, stream_kernel=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1,
+               wide_blocks=-1) -> None:
     t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
                avg_degree, nonlocal_ids, gcn_prescale, pad_rows, stream_kernel, zero_fill, sweep, sweep_slack, deterministic,
-               pack_ids)
+               pack_ids, wide_blocks)
     load().gnna_set_tuning(ctypes.byref(t))
 
 
@@ -444,6 +447,21 @@ def agg_ld(mode, X, column_index, part_pointers, part2Node, num_out_rows, partSi
                                       yp, ld_out, int(num_out_rows), dim, part2Node.numel(), int(partSize), flags,
                                       _stream(X.device)))
     return out
+
+
+def preferred_ld(dim: int, num_in_rows: int, num_edges: int) -> int:
+    """The leading dimension (floats) a producer should write `dim`-float source rows with so that the gather needs no
+    staged copy (== dim: the contiguous layout is fine)."""
+    return int(load().gnna_preferred_ld(int(dim), int(num_in_rows), int(num_edges)))
+
+
+def empty_rows(num_rows: int, dim: int, ld: int, device) -> torch.Tensor:
+    """A [num_rows, dim] float32 view with leading dimension `ld` of a fresh, (ld x 4)-byte aligned allocation."""
+    if ld == dim:
+        return torch.empty(num_rows, dim, dtype=torch.float32, device=device)
+    buf = torch.empty(num_rows * ld + ld, dtype=torch.float32, device=device)
+    off = (-buf.data_ptr() // 4) % ld
+    return buf[off: off + num_rows * ld].view(num_rows, ld)[:, :dim]
 
 
 def prepare_graph(column_index, part_pointers, part2Node, num_in_rows: int, num_out_rows: int, partSize: int,

@@ -407,7 +407,53 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
                const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
                const int32_t *part2Node, float *out, int64_t ld_out, int64_t num_nodes, int dim, int64_t num_parts,
                int partSize, int dimWorker, int warpPerBlock, void *stream_v, unsigned flags,
-               int num_windows = 1, int win_begin = 0, int win_end = 1)
+               int num_windows = 1, int win_begin = 0, int win_end = 1, bool profiled = true);
+
+// Wide rows in column blocks.  A row of 256 floats is eight 128-byte lines: the lines a source slice touches stop
+// fitting an XCD's L2 long before the slicing rule runs out of phases (>= 16 edges per (row, slice) piece), and rows wider
+// than 128 floats leave the sweep kernel's accumulators.  A 64-float column block of the same rows is the well-behaved
+// two-line case again, so when every source row is gathered many times and the matrix is Infinity-Cache sized the call is
+// split into ceil(dim / 64) calls over column blocks of `input` and `out` (leading dimensions: the blocks are aggregated in
+// place; the ids are re-read per block, which is cheap).  Measured, Reddit-like D = 256: DESIGN.md 3.1.
+int column_blocks(const gnna_tuning &tune, int dim, int64_t num_in_rows, int64_t est_edges)
+{
+    if (tune.wide_blocks == 2 || dim < (tune.wide_blocks == 1 ? 72 : 192)) return 1;
+    const bool hot = est_edges >= 32 * num_in_rows;
+    if (tune.wide_blocks == 0 && (!hot || (size_t)num_in_rows * (size_t)dim * sizeof(float) > ((size_t)250000000))) return 1;
+    return (dim + 63) / 64;
+}
+
+int launch_agg_blocked(int nb, int mode, const float *input, int64_t ld_in, int64_t num_in_rows, const int32_t *column_index,
+                       const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
+                       const int32_t *part2Node, float *out, int64_t ld_out, int64_t num_nodes, int dim, int64_t num_parts,
+                       int partSize, int dimWorker, int warpPerBlock, void *stream_v, unsigned flags)
+{
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const int prof_call = profile_acquire_call(num_parts > 0);
+    profile_record(prof_call, 0, stream);
+    profile_record(prof_call, 1, stream);
+    const int w = ((dim + nb - 1) / nb + 3) / 4 * 4;        // block width: a multiple of 4 floats
+    int launches = 0, phases = 1;
+    for (int c0 = 0; c0 < dim; c0 += w) {
+        const int wb = std::min(w, dim - c0);
+        const int rc = launch_agg(mode, input + c0, ld_in, num_in_rows, column_index, degrees, degrees_in, epsilon, part_pointers,
+                                  part2Node, out + c0, ld_out, num_nodes, wb, num_parts, partSize, dimWorker, warpPerBlock, stream_v,
+                                  flags, 1, 0, 1, /*profiled=*/false);
+        if (rc != GNNA_OK) return rc;
+        launches += t_last_launches;
+        phases = std::max(phases, t_last_phases);
+    }
+    t_last_launches = launches;
+    t_last_phases = phases;
+    profile_record(prof_call, 2, stream);
+    return GNNA_OK;
+}
+
+int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows, const int32_t *column_index,
+               const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
+               const int32_t *part2Node, float *out, int64_t ld_out, int64_t num_nodes, int dim, int64_t num_parts,
+               int partSize, int dimWorker, int warpPerBlock, void *stream_v, unsigned flags,
+               int num_windows, int win_begin, int win_end, bool profiled)
 {
     const bool accumulate_into_out = (flags & GNNA_ACCUMULATE) != 0;
     const bool relu = (flags & GNNA_EPILOGUE_RELU) != 0;
@@ -448,11 +494,18 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
     gnna_get_tuning(&tune);
     apply_graph_hints(column_index, dim, &tune);
 
+    const bool windowed = num_windows > 1;
+    if (profiled && !windowed && num_parts > 0) {
+        const int64_t est = num_parts * (int64_t)(tune.avg_degree > 0 ? std::min(partSize, tune.avg_degree) : partSize / 2 + 1);
+        const int nb = column_blocks(tune, dim, num_in_rows, est);
+        if (nb > 1)
+            return launch_agg_blocked(nb, mode, input, ld_in, num_in_rows, column_index, degrees, degrees_in, epsilon, part_pointers,
+                                      part2Node, out, ld_out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream_v, flags);
+    }
     int32_t *flag = nullptr;
     const int32_t seq = next_call_seq(ds, &flag);
-    const int prof_call = profile_acquire_call(num_parts > 0);
+    const int prof_call = profiled ? profile_acquire_call(num_parts > 0) : -1;
     profile_record(prof_call, 0, stream);
-    const bool windowed = num_windows > 1;
     const int ldy = (int)ld_out;
 
     // prologue: zero-fill + validation.  `sparse_G` > 0: the streaming kernel is about to run a single pass with
@@ -762,6 +815,15 @@ int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num_in_rows,
     return launch_agg(mode, input, dim, num_in_rows, column_index, degrees_out, degrees_in, epsilon, part_pointers,
                       part2Node, out, dim, num_out_rows, dim, num_parts, partSize, 32, 4, stream,
                       accumulate != 0 ? GNNA_ACCUMULATE : 0u, num_windows, window_begin, window_end);
+}
+
+int64_t gnna_preferred_ld(int dim, int64_t num_in_rows, int64_t num_edges)
+{
+    if (dim <= 0 || num_in_rows <= 0) return dim > 0 ? dim : 0;
+    gnna_tuning tune;
+    gnna_get_tuning(&tune);
+    const bool hot = num_edges >= 32 * num_in_rows && (size_t)num_in_rows * (size_t)dim * sizeof(float) <= ((size_t)1 << 30);
+    return dim < 4 ? dim : pick_row_stride(tune, dim, hot, num_in_rows, true);
 }
 
 int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers, const int32_t *part2Node,

@@ -27,7 +27,8 @@ const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*
                                     /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0,
                                     /*column_phases=*/0, /*avg_degree=*/0, /*nonlocal_ids=*/0,
                                     /*gcn_prescale=*/0, /*pad_rows=*/0, /*stream_kernel=*/0, /*zero_fill=*/0,
-                                    /*sweep=*/0, /*sweep_slack=*/0, /*deterministic=*/0, /*pack_ids=*/0};
+                                    /*sweep=*/0, /*sweep_slack=*/0, /*deterministic=*/0, /*pack_ids=*/0,
+                                    /*wide_blocks=*/0};
 gnna_tuning g_tuning = kDefaultTuning;
 std::mutex g_tuning_mutex;
 std::once_flag g_env_once;
@@ -74,6 +75,7 @@ void apply_env()
         else if (!std::strcmp(tok, "SLACK")) g_tuning.sweep_slack = v;
         else if (!std::strcmp(tok, "DET")) g_tuning.deterministic = v;
         else if (!std::strcmp(tok, "PACK")) g_tuning.pack_ids = v;
+        else if (!std::strcmp(tok, "BLOCKS")) g_tuning.wide_blocks = v;
     }
 }
 
@@ -156,6 +158,7 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->sweep_slack >= 0) g_tuning.sweep_slack = t->sweep_slack;
     if (t->deterministic >= 0) g_tuning.deterministic = t->deterministic;
     if (t->pack_ids >= 0) g_tuning.pack_ids = t->pack_ids;
+    if (t->wide_blocks >= 0) g_tuning.wide_blocks = t->wide_blocks;
 }
 
 int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids)

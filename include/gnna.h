@@ -194,6 +194,12 @@ GNNA_API int gnna_agg_ld_f32(int mode, const float *input, int64_t ld_in, int64_
                       float *out, int64_t ld_out, int64_t num_out_rows, int dim, int64_t num_parts, int partSize,
                       unsigned flags, void *stream);
 
+/* The row stride (in floats, >= dim) the library would stage `dim`-float source rows into before gathering them
+ * `num_edges` times from `num_in_rows` rows -- dim itself when it would gather from the contiguous layout.  A producer
+ * that writes its output with this leading dimension into a buffer aligned to (stride x 4) bytes (torch::mm into
+ * buf[:, :dim] of a [N, stride] allocation) and calls gnna_agg_ld_f32 saves the library's staging copy per call. */
+GNNA_API int64_t gnna_preferred_ld(int dim, int64_t num_in_rows, int64_t num_edges);
+
 /* Windowed form of gnna_agg_rect_f32, for pipelining the aggregation with a chunked feature
  * exchange (multi-GPU: the all-gather is issued in `num_windows` pieces and each piece is
  * aggregated as soon as it has arrived).  The source rows are cut into `num_windows` (1..16) equal
@@ -296,6 +302,9 @@ typedef struct gnna_tuning {
                              rewritten in place while the library holds a plan for it (the reference's own call sequence
                              never does; without the promise a stale copy would give wrong results, which is why it is
                              not the default) */
+    int wide_blocks;      /* rows of >= 192 floats in 64-float column blocks (one call per block, leading dimensions): 0 = automatic
+                             (when every source row is gathered >= ~32 times and the matrix is Infinity-Cache sized), 1 = whenever
+                             dim >= 72, 2 = never */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */

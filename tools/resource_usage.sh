@@ -11,7 +11,7 @@ for line in sys.stdin:
     m=re.search(r'Function Name: (\S+)',line)
     if m:
         cur={'name':m.group(1)}; rows.append(cur); continue
-    m=re.search(r'remark: [^:]*:\d+:\d+:\s+(\w[\w \[\]/]*): (\S+)',line)
+    m=re.search(r'remark:\s+(\w[\w \[\]/]*): (\S+)',line)
     if m and cur is not None: cur[m.group(1).strip()]=m.group(2)
 for r in rows:
     n=subprocess.run(['c++filt',r['name']],capture_output=True,text=True).stdout.strip()
