@@ -317,7 +317,7 @@ int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in
 //    measurable when rows and columns share one numbering; a caller's "scattered ids" hint settles it otherwise;
 //  * slices of at most 8 MiB of source rows (Reddit-like graph, D = 16 / 32 / 64 / 128: best 4 / 4 / 8 / 16
 //    phases; two slices are live while the chip moves from one to the next, and an XCD's L2 is 4 MiB);
-//  * at least ~16 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses -- ~8 are
+//  * at least ~12 edges per (row, slice) piece, else a phase costs more in flushes than it saves in misses -- ~8 are
 //    enough for the split that makes a slice fit the Infinity Cache (products-like, average degree 50, X = 627 MB: best
 //    4 phases; amazon0505-like, degree 12: none).
 // Phases for the sweep kernel when the library picks it by itself (gnna_tuning.sweep = 0), or 0: the streaming kernel
@@ -378,7 +378,9 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     auto piece = [&](int l) {   // edges per (row, slice) piece: cells of one row that are adjacent merge
         return st.edges / std::max(rows, st.cells[l] - (st.groups - rows));
     };
-    // Two regimes (measured, D = 64).  Slices that fit an XCD's L2 pay from ~16 edges per (row, slice) piece -- every
+    // Two regimes (measured, D = 64).  Slices that fit an XCD's L2 pay from ~12 edges per (row, slice) piece (16 until the
+    // regret test of round 4: a scrambled community graph of 105 edges per row runs 7 % faster with 8 slices of 13 edges
+    // per piece than with 4; tests/test_regret_gpu.py, profiles/r4/regret_table.log) -- every
     // piece costs a flush of the row: Reddit-like shards of a 2- / 4- / 8-GPU job (246 / 369 / 430 remote edges per
     // row, X = 119 / 238 / 477 MB) run fastest with 12-16 / 16 / 16 slices (15-27 edges per piece).  Slices that
     // only fit the 256 MiB Infinity Cache still pay from ~8 edges per piece, because a miss there goes to HBM:
@@ -388,7 +390,7 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     int levels = 0;                               // cells[l] <-> S >> l slices, l = 0 .. levels - 1 (down to 2 slices)
     for (int t = S; t > 1; t >>= 1) levels++;
     levels = std::min(levels, kSliceLevels);
-    while (b > 1 && lvl < levels && piece(lvl) < 16.0) { b >>= 1; lvl++; }
+    while (b > 1 && lvl < levels && piece(lvl) < 12.0) { b >>= 1; lvl++; }
     if (lvl >= levels) b = 1;
     const size_t mall = (size_t)250000000;   // (of 256 MiB; products-like D = 100: four slices of 245 MB, 7.0 ms against 7.8 with two)
     if (x_bytes > mall) {
@@ -669,8 +671,8 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
         }
         rc = run_prologue(0);
         if (rc != GNNA_OK) return rc;
-        uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * (kXcds * 16);
-        hipError_t em = hipMemsetAsync(sync, 0, kXcds * 16 * sizeof(uint32_t), stream);
+        uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * kSweepSlotWords;
+        hipError_t em = hipMemsetAsync(sync, 0, (kXcds * 16 + 2) * sizeof(uint32_t), stream);
         if (em != hipSuccess) return fail(GNNA_ERR_HIP, "sweep counters: %s", hipGetErrorString(em));
         SweepLaunch w;
         w.mode = mode; w.X = X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;

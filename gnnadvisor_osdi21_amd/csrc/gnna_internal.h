@@ -141,7 +141,7 @@ struct SweepLaunch {
     const uint8_t *cnt;       // slice counts (required)
     const float *row_scale;
     const int32_t *flag; int32_t seq; int32_t trust;
-    uint32_t *sync;           // kXcds counters, 64 bytes apart, zero when the kernel starts
+    uint32_t *sync;           // kXcds counters, 64 bytes apart, + the shared-row list's two header words: zero when the kernel starts
     int64_t P;
     int D, ldx, U, S, B;
     int ldy = 0;              // row stride of Y in floats (0: D)
@@ -163,7 +163,9 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream);
 // Phases of the sweep kernel when the library picks it on its own (gnna_tuning.sweep = 0) for this call, else 0 (gnna_agg.hip).
 int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
                       double edges, int B, int num_cus, bool deterministic, int part_size);
-constexpr int kSweepSyncSlots = 64;    // ring of per-call counter blocks (kXcds x 64 bytes each)
+constexpr int kSweepSyncSlots = 64;    // ring of per-call blocks: kXcds step counters 64 bytes apart, then the ReLU epilogue's
+constexpr int kSweepListCap = 2046;    // list of rows that sets share: [count][overflow][rows ...]
+constexpr int kSweepSlotWords = 8 * 16 + 2 + kSweepListCap;
 
 // ---- optional per-call kernel timing (gnna_profile_begin/end) ---------------------------------------
 // Returns the index of this call in the active profile (-1 when not profiling).

@@ -44,7 +44,7 @@ int get_device_state(DeviceState **out)
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(gap lists): %s", hipGetErrorString(e));
             e = hipMemset(s.gap_lists, 0, gap_bytes);
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMemset(gap lists): %s", hipGetErrorString(e));
-            const size_t sync_bytes = (size_t)kSweepSyncSlots * 8 * 64;
+            const size_t sync_bytes = (size_t)kSweepSyncSlots * kSweepSlotWords * sizeof(uint32_t);
             e = hipMalloc(reinterpret_cast<void **>(&s.sweep_sync), sync_bytes);
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(sweep counters): %s", hipGetErrorString(e));
             e = hipMemset(s.sweep_sync, 0, sync_bytes);

@@ -147,40 +147,31 @@ __device__ __forceinline__ int64_t sweep_set_start(int64_t i, int64_t num_sets, 
 }
 
 // The ReLU epilogue's second half: a row two sets share was ADDED to the output by both (float atomics), so it is clamped
-// here, behind the kernel -- one wavefront per set boundary; everything when the partition is not canonical (every row was
-// added per slice) or `whole` is set (the call accumulates into an existing output).
+// here, behind the kernel.  The sweep kernel lists those rows itself while it runs (list[0] = count, list[2 ...] = rows:
+// the first row of every set that continues from its predecessor) and raises list[1] when the list is full or a set holds
+// rows beyond its accumulators (flushed per slice with atomics, never stored); then, and for a partition that is not
+// canonical or a call that accumulates into an existing output (`whole`), the whole output is clamped.
 __global__ void __launch_bounds__(kBlock)
-sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const int32_t *__restrict__ pp,
-                        const int32_t *__restrict__ p2n, int64_t P, int64_t num_sets, int align64, int cap_rows,
+sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const uint32_t *__restrict__ list,
                         const int32_t *flag, int32_t seq, int32_t trust, int whole)
 {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const bool canonical = trust || (*flag != seq);
-    if (whole || !canonical) {
+    if (whole || !canonical || list[1] != 0u) {
         for (int64_t r = wave; r < N; r += nwaves) {
             float *row = Y + (size_t)r * (size_t)ldy;
             for (int i = lane; i < D; i += kWave) row[i] = fmaxf(row[i], 0.f);
         }
         return;
     }
-    const int64_t nnz = (int64_t)pp[P];
-    for (int64_t i = wave; i < num_sets; i += nwaves) {
-        const int64_t g_lo = sweep_set_start(i, num_sets, nnz, pp, P, true, align64 != 0, lane);
-        const int64_t g_hi = sweep_set_start(i + 1, num_sets, nnz, pp, P, true, align64 != 0, lane);
-        if (g_hi <= g_lo) continue;
-        const int row_first = p2n[g_lo], row_last = p2n[g_hi - 1];
-        // the row the set shares with its predecessor (the row it shares with its successor is that set's first row) ...
-        if (g_lo > 0 && p2n[g_lo - 1] == row_first && row_first >= 0 && row_first < N) {
-            float *row = Y + (size_t)row_first * (size_t)ldy;
-            for (int k = lane; k < D; k += kWave) row[k] = fmaxf(row[k], 0.f);
-        }
-        // ... and the rows beyond the set's accumulators: flushed per slice with atomics, never stored
-        for (int64_t r = (int64_t)row_first + cap_rows; r <= row_last && r < N; r++) {
-            float *row = Y + (size_t)r * (size_t)ldy;
-            for (int k = lane; k < D; k += kWave) row[k] = fmaxf(row[k], 0.f);
-        }
+    const uint32_t n = list[0] < (uint32_t)kSweepListCap ? list[0] : (uint32_t)kSweepListCap;
+    for (int64_t i = wave; i < (int64_t)n; i += nwaves) {
+        const int64_t r = (int64_t)list[2 + i];
+        if (r >= N) continue;
+        float *row = Y + (size_t)r * (size_t)ldy;
+        for (int k = lane; k < D; k += kWave) row[k] = fmaxf(row[k], 0.f);
     }
 }
 
@@ -255,6 +246,16 @@ sweep_kernel(const SweepParams p)
         }
         int nrows = 0;                                                   // rows of the set kept in LDS
         if (canonical && row_last >= row_first) nrows = row_last - row_first + 1 < CAP ? row_last - row_first + 1 : CAP;
+        if (p.relu && canonical && threadIdx.x == 0 && g_hi > g_lo) {
+            // ReLU epilogue: the rows this set does not finish alone go on the call's list for the pass behind the kernel
+            uint32_t *list = p.sync + kXcds * 16;
+            if (set_prev_row == row_first) {
+                const uint32_t idx = atomicAdd(&list[0], 1u);
+                if (idx < (uint32_t)kSweepListCap) list[2 + idx] = (uint32_t)row_first;
+                else list[1] = 1u;
+            }
+            if (row_last - row_first + 1 > CAP) list[1] = 1u;
+        }
         for (int i = threadIdx.x; i < nrows * D; i += kSweepBlock) s_acc[i] = 0.f;
         __syncthreads();
 
@@ -633,14 +634,10 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     count_event(CTR_SWEEP_LAUNCHES);
     if (a.relu) {
         const bool whole = !a.plain_ok;
-        const int64_t num_sets = (int64_t)grid * p.rounds;
-        const int64_t units = whole ? a.num_out_rows : num_sets;
+        const int64_t units = whole ? a.num_out_rows : std::min<int64_t>((int64_t)grid * p.rounds, kSweepListCap);
         const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((units + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16));
-        // (the kernel's accumulator capacity at this width, in rows: ACC / D of the variant that runs)
-        const int acc = wgs == 1 ? (lpr >= 16 ? acc_floats<16, 1>() : acc_floats<8, 1>()) : (lpr >= 16 ? acc_floats<16, 2>() : acc_floats<8, 2>());
         hipLaunchKernelGGL(sweep_relu_fixup_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a.Y, a.num_out_rows, a.D, p.ldy,
-                           a.pp, a.p2n, a.P, num_sets, p.ids_packed ? 1 : 0, acc / std::max(1, a.D), a.flag, a.seq, a.trust,
-                           whole ? 1 : 0);
+                           a.sync + kXcds * 16, a.flag, a.seq, a.trust, whole ? 1 : 0);
         e = hipGetLastError();
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "epilogue launch: %s", hipGetErrorString(e));
     }

@@ -109,6 +109,20 @@ class GNNAFunction_GIN(Function):
         return d_input, d_weight, None, None
 
 
+def _mm_for_gather(X, weight, column_index):
+    """X W written in the layout the following (unweighted) aggregation gathers best: rows with the leading dimension
+    `gnna_preferred_ld` names (e.g. 128 floats for 64-float rows that are gathered hundreds of times -- every row on its own
+    512-byte boundary), so that the library needs no staged copy of them.  rocBLAS writes a leading dimension for free."""
+    from . import _lib
+    n, dim = X.shape[0], weight.shape[1]
+    ld = _lib.preferred_ld(dim, n, column_index.numel())
+    if ld == dim:
+        return torch.mm(X, weight)
+    out = _lib.empty_rows(n, dim, ld, X.device)
+    torch.mm(X, weight, out=out)
+    return out
+
+
 def _row_units(width: int) -> int:
     """Cost of aggregating one neighbor row of `width` floats, in 64-float wavefront sweeps."""
     return (int(width) + 63) // 64
@@ -125,12 +139,14 @@ class GNNAFunction_GIN_UpdateFirst(Function):
         rp, ci, _deg, pp, p2n = _graph_args(inputInfo)
         ctx.graph, ctx.knobs, ctx.eplison = (rp, ci, pp, p2n), _knobs(inputInfo), eplison
         ctx.relu = bool(relu)
-        if relu:      # the aggregation is the layer's last step here, so its epilogue can clamp
-            Y = GNNA.aggregate_ld(2, torch.mm(X, weight), ci, None, eplison, pp, p2n, inputInfo.partSize, None, False, True)
+        with torch.no_grad():
+            XW = _mm_for_gather(X, weight, ci)
+        Y = GNNA.aggregate_ld(2, XW, ci, None, eplison, pp, p2n, inputInfo.partSize, None, False, bool(relu))
+        if relu:      # (the aggregation is the layer's last step here, so its epilogue can clamp)
             ctx.save_for_backward(X, weight, Y)
-            return Y
-        ctx.save_for_backward(X, weight)
-        return GNNA.aggregate_gin(torch.mm(X, weight), rp, ci, eplison, pp, p2n, *ctx.knobs)
+        else:
+            ctx.save_for_backward(X, weight)
+        return Y
 
     @staticmethod
     def backward(ctx, d_output):
