@@ -146,11 +146,11 @@ __device__ __forceinline__ int64_t sweep_set_start(int64_t i, int64_t num_sets, 
     return g;
 }
 
-// The ReLU epilogue's second half: a row two sets share was ADDED to the output by both (float atomics), so it is clamped
-// here, behind the kernel.  The sweep kernel lists those rows itself while it runs (list[0] = count, list[2 ...] = rows:
-// the first row of every set that continues from its predecessor) and raises list[1] when the list is full or a set holds
-// rows beyond its accumulators (flushed per slice with atomics, never stored); then, and for a partition that is not
-// canonical or a call that accumulates into an existing output (`whole`), the whole output is clamped.
+// The ReLU epilogue's second half: rows the sweep kernel ADDED to the output instead of storing them once -- a row two sets
+// share (float atomics from both), the rows of a set beyond its accumulators (flushed per slice) -- are clamped here,
+// behind the kernel.  The kernel lists them itself while it runs, as (first row, rows) ranges: list[0] = number of
+// ranges, list[2 + 2 i], list[3 + 2 i] = range i; list[1] is raised when the list is full.  Then, and for a partition that
+// is not canonical or a call that accumulates into an existing output (`whole`), the whole output is clamped.
 __global__ void __launch_bounds__(kBlock)
 sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const uint32_t *__restrict__ list,
                         const int32_t *flag, int32_t seq, int32_t trust, int whole)
@@ -159,19 +159,18 @@ sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const 
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const bool canonical = trust || (*flag != seq);
+    auto clamp_row = [&](int64_t r) {
+        float *row = Y + (size_t)r * (size_t)ldy;
+        for (int i = lane; i < D; i += kWave) row[i] = fmaxf(row[i], 0.f);
+    };
     if (whole || !canonical || list[1] != 0u) {
-        for (int64_t r = wave; r < N; r += nwaves) {
-            float *row = Y + (size_t)r * (size_t)ldy;
-            for (int i = lane; i < D; i += kWave) row[i] = fmaxf(row[i], 0.f);
-        }
+        for (int64_t r = wave; r < N; r += nwaves) clamp_row(r);
         return;
     }
     const uint32_t n = list[0] < (uint32_t)kSweepListCap ? list[0] : (uint32_t)kSweepListCap;
-    for (int64_t i = wave; i < (int64_t)n; i += nwaves) {
-        const int64_t r = (int64_t)list[2 + i];
-        if (r >= N) continue;
-        float *row = Y + (size_t)r * (size_t)ldy;
-        for (int k = lane; k < D; k += kWave) row[k] = fmaxf(row[k], 0.f);
+    for (uint32_t i = 0; i < n; i++) {                       // (a handful of ranges: every wavefront walks the list)
+        const int64_t first = (int64_t)list[2 + 2 * i], cnt = (int64_t)list[3 + 2 * i];
+        for (int64_t r = first + wave; r < first + cnt && r < N; r += nwaves) clamp_row(r);
     }
 }
 
@@ -249,12 +248,13 @@ sweep_kernel(const SweepParams p)
         if (p.relu && canonical && threadIdx.x == 0 && g_hi > g_lo) {
             // ReLU epilogue: the rows this set does not finish alone go on the call's list for the pass behind the kernel
             uint32_t *list = p.sync + kXcds * 16;
-            if (set_prev_row == row_first) {
+            auto push = [&](int first, int cnt) {
                 const uint32_t idx = atomicAdd(&list[0], 1u);
-                if (idx < (uint32_t)kSweepListCap) list[2 + idx] = (uint32_t)row_first;
+                if (idx < (uint32_t)kSweepListCap) { list[2 + 2 * idx] = (uint32_t)first; list[3 + 2 * idx] = (uint32_t)cnt; }
                 else list[1] = 1u;
-            }
-            if (row_last - row_first + 1 > CAP) list[1] = 1u;
+            };
+            if (set_prev_row == row_first) push(row_first, 1);
+            if (row_last - row_first + 1 > CAP) push(row_first + CAP, row_last - row_first + 1 - CAP);
         }
         for (int i = threadIdx.x; i < nrows * D; i += kSweepBlock) s_acc[i] = 0.f;
         __syncthreads();
@@ -634,8 +634,9 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream)
     count_event(CTR_SWEEP_LAUNCHES);
     if (a.relu) {
         const bool whole = !a.plain_ok;
-        const int64_t units = whole ? a.num_out_rows : std::min<int64_t>((int64_t)grid * p.rounds, kSweepListCap);
-        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((units + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 16));
+        // (which of the two jobs it is, is decided on the device -- the list may have overflowed: always a grid that can
+        // do the whole output; idle blocks cost nothing next to the aggregation)
+        const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((a.num_out_rows + kWavesPerBlock - 1) / kWavesPerBlock, 256 * 8));
         hipLaunchKernelGGL(sweep_relu_fixup_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, a.Y, a.num_out_rows, a.D, p.ldy,
                            a.sync + kXcds * 16, a.flag, a.seq, a.trust, whole ? 1 : 0);
         e = hipGetLastError();

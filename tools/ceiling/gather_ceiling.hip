@@ -213,17 +213,27 @@ extern "C" __attribute__((visibility("default")))
 int gather_ceiling_hub_launch(const float *X, const int32_t *ids, int64_t n, int dim, int seg, int U, float *out,
                               const float *hub, int hub_rows, int lds_bytes, int blocks)
 {
-    if (seg % 64 != 0 || seg <= 0 || dim != 64) return -1;
+    if (seg % 64 != 0 || seg <= 0 || (dim != 64 && dim != 32 && dim != 16)) return -1;
     if ((size_t)hub_rows * dim * 4 > (size_t)lds_bytes) return -4;
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)gather_ceiling_hub<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    if (U == 4) hipLaunchKernelGGL((gather_ceiling_hub<16, 4>), dim3(blocks), dim3(1024), lds_bytes, 0, X, ids, n, seg, out, hub, hub_rows, lds_bytes);
-    else if (U == 8) hipLaunchKernelGGL((gather_ceiling_hub<16, 8>), dim3(blocks), dim3(1024), lds_bytes, 0, X, ids, n, seg, out, hub, hub_rows, lds_bytes);
+#define HUB(L, UU) hipLaunchKernelGGL((gather_ceiling_hub<L, UU>), dim3(blocks), dim3(1024), lds_bytes, 0, X, ids, n, seg, out, hub, hub_rows, lds_bytes)
+    if (dim == 64 && U == 4) HUB(16, 4);
+    else if (dim == 64 && U == 8) HUB(16, 8);
+    else if (dim == 32 && U == 4) HUB(8, 4);
+    else if (dim == 32 && U == 8) HUB(8, 8);
+    else if (dim == 16 && U == 4) HUB(4, 4);
+    else if (dim == 16 && U == 2) HUB(4, 2);
     else return -2;
+#undef HUB
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
