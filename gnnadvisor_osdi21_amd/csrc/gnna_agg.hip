@@ -418,17 +418,6 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
 // two-line case again, so when every source row is gathered many times and the matrix is Infinity-Cache sized the call is
 // split into ceil(dim / 64) calls over column blocks of `input` and `out` (leading dimensions: the blocks are aggregated in
 // place; the ids are re-read per block, which is cheap).  Measured, Reddit-like D = 256: DESIGN.md 3.1.
-// work items per wavefront of a hot-row-cache workgroup (GNNA_HUB_REPS: experiments)
-int hub_reps()
-{
-    static const int v = [] {
-        const char *e = std::getenv("GNNA_HUB_REPS");
-        const int r = e ? std::atoi(e) : 0;
-        return r > 0 && r <= 64 ? r : 4;
-    }();
-    return v;
-}
-
 int column_blocks(const gnna_tuning &tune, int dim, int64_t num_in_rows, int64_t est_edges)
 {
     if (tune.wide_blocks == 2 || dim < (tune.wide_blocks == 1 ? 72 : 192)) return 1;
@@ -745,7 +734,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
             rc = get_packed_ids(ds, stream, plan.handle, B, kWave, false, false, &a.ids_packed, &a.item_off, &chk_sum, &chk_n, hcap,
                                 &a.hot_rows);
             if (rc != GNNA_OK) return rc;
-            if (a.ids_packed) { a.hub_cap = hcap; a.G = kWave; a.hub_reps = hub_reps(); }
+            if (a.ids_packed) { a.hub_cap = hcap; a.G = kWave; a.num_cus = ds->num_cus; a.hub_u = std::getenv("GNNA_HUB_U4") ? 4 : (std::getenv("GNNA_HUB_U16") ? 16 : 8); }
         }
         if (!a.ids_packed)
             rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,

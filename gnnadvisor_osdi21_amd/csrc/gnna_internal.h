@@ -133,7 +133,7 @@ struct StreamLaunch {
     float *det_part = nullptr; int32_t *det_stamp = nullptr;   // [num_chunks][2][D] partial rows / [num_chunks][2] stamps
     const int32_t *ids_packed = nullptr; const uint32_t *item_off = nullptr;   // packed ids of a prepared graph for (B, G)
     const int32_t *packed_stale = nullptr;   // *packed_stale == seq: column_index no longer matches the copy, read column_index
-    const int32_t *hot_rows = nullptr; int hub_cap = 0; int hub_reps = 4;   // hot-row cache (ids_packed is the marked copy)
+    const int32_t *hot_rows = nullptr; int hub_cap = 0; int hub_u = 8; int num_cus = 256;   // hot-row cache (ids_packed is the marked copy)
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
 // The ReLU epilogue over the whole output on its own (a call that has nothing to aggregate but accumulates into `out`).

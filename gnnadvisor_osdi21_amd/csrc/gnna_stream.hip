@@ -123,10 +123,9 @@ struct StreamParams {
     const uint32_t *item_off;
     const int32_t *packed_stale;   // *packed_stale == seq: the prologue found column_index changed since the copy was made
     // HUB variant: hot_rows[phase * hub_cap + slot] = source row kept in LDS slot `slot` during `phase`; marked ids in
-    // ids_packed; a workgroup runs `reps` x 16 consecutive work items of one phase
+    // ids_packed; one persistent workgroup per CU
     const int32_t *hot_rows;
     int32_t hub_cap;
-    int32_t reps;
 };
 
 // ---- slice counts ---------------------------------------------------------------------------------
@@ -330,28 +329,85 @@ stream_kernel(const StreamParams p)
     // block -> (phase, chunks): blocks are numbered phase-major, inside a phase every XCD gets one
     // contiguous range of chunks (blocks land on XCD blockIdx % 8)
     const int64_t bpp = p.blocks_per_phase;
-    const int phase = p.phase_lo + (int)((int64_t)blockIdx.x / bpp);
+    int phase = p.phase_lo + (int)((int64_t)blockIdx.x / bpp);
     int64_t item = (int64_t)blockIdx.x % bpp;
     if (p.xcd_remap) item = (item % kXcds) * (bpp / kXcds) + item / kXcds;
     const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr && *p.packed_stale != p.seq;
-    const int reps = HUB ? p.reps : 1;
-    if constexpr (HUB) {
-        // the phase's hot rows -> LDS (every thread copies 16-byte pieces; the rows are L2 residents by construction)
-        if (packed && item * reps * kSWavesT < p.num_chunks) {
-            const int32_t *__restrict__ hot = p.hot_rows + (size_t)phase * (size_t)p.hub_cap;
+    // HUB: ONE persistent workgroup per CU owns a contiguous range of chunks -- an equal share of the edges -- for all
+    // phases; per phase it loads the phase's hot rows into LDS, then its 16 wavefronts draw the chunks of the range from a
+    // counter in LDS.  (Workgroups that reload the cache per 64 work items lose more to the reload, the ramp-up and the
+    // tail of a block than the cache wins: 0.81 against 0.70 ms on Reddit-like D = 16.)
+    __shared__ int64_t s_range[2];
+    __shared__ int s_next;
+    int64_t c_lo = 0, c_hi = 0;
+    auto load_cache = [&](int ph) {
+        if constexpr (HUB) {
+            // the phase's hot rows -> LDS: every thread copies PER 16-byte pieces; all slot lookups first, then all row
+            // loads, then the LDS stores -- two round trips for the whole cache, not two per piece
+            const int32_t *__restrict__ hot = p.hot_rows + (size_t)ph * (size_t)p.hub_cap;
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int pieces = D >> 2;                                  // (HUB: D % 4 == 0)
-            for (int i = threadIdx.x; i < p.hub_cap * LPR; i += kSBlockT) {
-                const int hs = i / LPR, pc = i % LPR;
-                if (pc < pieces)
-                    reinterpret_cast<f32x4 *>(s_hub)[i] = *reinterpret_cast<const f32x4 *>(xbase + (uint32_t)hot[hs] * row_bytes32 + pc * 16);
+            constexpr int PER = (hub_cap<LPR>() * LPR + kHubBlock - 1) / kHubBlock;
+            uint32_t ro[PER];
+            f32x4 val[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = (int)threadIdx.x + k * kHubBlock;
+                ro[k] = i < hub_cap<LPR>() * LPR ? (uint32_t)hot[i / LPR] * row_bytes32 + (uint32_t)(i % LPR) * 16u : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = (int)threadIdx.x + k * kHubBlock;
+                val[k] = (i < hub_cap<LPR>() * LPR && (i % LPR) < pieces) ? *reinterpret_cast<const f32x4 *>(xbase + ro[k]) : (f32x4)(0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int i = (int)threadIdx.x + k * kHubBlock;
+                if (i < hub_cap<LPR>() * LPR) reinterpret_cast<f32x4 *>(s_hub)[i] = val[k];
             }
         }
+    };
+    if constexpr (HUB) {
+        if (wib < 2) {
+            // first chunk of workgroup i of n: the chunk that holds edge nnz * i / n (a search in part_pointers; equal
+            // shares of the chunks for a partition that is not canonical)
+            const int64_t i = (int64_t)blockIdx.x + wib, n = (int64_t)gridDim.x;
+            int64_t cb;
+            if (i <= 0) cb = 0;
+            else if (i >= n) cb = p.num_chunks;
+            else if (!canonical) cb = (p.num_chunks * i) / n;
+            else cb = lower_bound64(p.pp, p.P, ((int64_t)p.pp[p.P] * i) / n, lane) / p.G;
+            if (lane == 0) s_range[wib] = cb < p.num_chunks ? cb : p.num_chunks;
+        }
+        if (threadIdx.x == 0) s_next = 0;
+        __syncthreads();
+        c_lo = s_range[0]; c_hi = s_range[1];
+        phase = 0;
+        if (packed) load_cache(0);
         __syncthreads();
     }
-    for (int rep = 0; rep < reps; rep++) {
-    const int64_t chunk = (item * reps + rep) * kSWavesT + wib;
-    if (chunk >= p.num_chunks) break;
+    for (int it = 0;; it++) {
+    int64_t chunk;
+    if constexpr (HUB) {
+        // draw the next chunk of this phase; when the range is used up, all 16 wavefronts meet, the next phase's hot rows
+        // replace the cache, and the range is walked again
+        int d = 0;
+        if (lane == 0) d = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        d = __builtin_amdgcn_readfirstlane(d);
+        if (c_lo + d >= c_hi) {
+            __syncthreads();                                  // everyone is done with this phase's cache (and has drawn)
+            if (++phase >= p.B) break;
+            if (threadIdx.x == 0) s_next = 0;
+            if (packed) load_cache(phase);
+            __syncthreads();
+            continue;
+        }
+        chunk = c_lo + d;
+    } else {
+        if (it > 0) break;
+        chunk = item * kSWavesT + wib;
+        if (chunk >= p.num_chunks) break;
+    }
     const int G = p.G;
     const int64_t g0 = chunk * G;
     const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
@@ -660,7 +716,7 @@ stream_kernel(const StreamParams p)
             if (npend > PEND / 2 || r0 + RL >= L) drain();   // between rounds: nothing of the ring waits behind these
         }
     }
-    }   // rep
+    }   // items
 }
 
 // ---- deterministic schedule: shared rows ---------------------------------------------------------------
@@ -967,11 +1023,12 @@ size_t stats_offset(int64_t P) { return (((size_t)P * (size_t)(kMaxSlices - 1)) 
 typedef void (*StreamKernel)(const StreamParams);
 
 template <int MODE>
-StreamKernel pick_stream_hub(int lpr)
+StreamKernel pick_stream_hub(int lpr, int u)
 {
     if constexpr (MODE == MODE_SAG || MODE == MODE_GIN) {
-        if (lpr == 4) return stream_kernel<4, MODE, 4, false, true>;
-        if (lpr == 8) return stream_kernel<8, MODE, 4, false, true>;
+        // (16 wavefronts per CU: 8 row loads in flight per wavefront unless the caller asks for 4)
+        if (lpr == 4) return u == 4 ? stream_kernel<4, MODE, 4, false, true> : (u == 16 ? stream_kernel<4, MODE, 16, false, true> : stream_kernel<4, MODE, 8, false, true>);
+        if (lpr == 8) return u == 4 ? stream_kernel<8, MODE, 4, false, true> : (u == 16 ? stream_kernel<8, MODE, 16, false, true> : stream_kernel<8, MODE, 8, false, true>);
     }
     return nullptr;
 }
@@ -1282,6 +1339,8 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         }
         // not worth a cache (and the 16-wavefront workgroups that come with it) unless a good share of the edges hits it
         if (hot_edges < 0.2 * (double)nnz) { (void)hipFree(slot_dev); return GNNA_OK; }
+        if (std::getenv("GNNA_HUB_NOCACHE"))                 // experiments: the variant's workgroup form with nothing marked
+            std::fill(slot_host.begin(), slot_host.end(), -1);
         e = hipMemcpyAsync(slot_dev, slot_host.data(), (size_t)plan_rows * sizeof(int32_t), hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);      // (slot_host goes out of scope below)
         if (e != hipSuccess) { (void)hipFree(slot_dev); return fail(GNNA_ERR_HIP, "hot-row slots: %s", hipGetErrorString(e)); }
@@ -1398,20 +1457,16 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
     p.ids_packed = (a.mode == MODE_SDDMM || !a.packed_stale) ? nullptr : a.ids_packed; p.item_off = a.item_off;
     p.packed_stale = a.packed_stale;
-    p.hot_rows = nullptr; p.hub_cap = 0; p.reps = 1;
+    p.hot_rows = nullptr; p.hub_cap = 0;
     if (a.hot_rows && a.hub_cap > 0 && p.ids_packed && !a.det && !a.wide && lpr <= 8 && (a.D & 3) == 0 && (a.ldx & 3) == 0 &&
         (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.mode == MODE_SAG || a.mode == MODE_GIN) && p.G == kWave) {
-        // hot-row cache: 16-wavefront workgroups, each loads its phase's hot rows into LDS and runs `reps` x 16 work items
-        StreamKernel kh = a.mode == MODE_GIN ? pick_stream_hub<MODE_GIN>(lpr) : pick_stream_hub<MODE_SAG>(lpr);
+        // hot-row cache: one persistent 16-wavefront workgroup per CU (see the kernel)
+        StreamKernel kh = a.mode == MODE_GIN ? pick_stream_hub<MODE_GIN>(lpr, a.hub_u) : pick_stream_hub<MODE_SAG>(lpr, a.hub_u);
         if (kh) {
             k = kh;
             p.hot_rows = a.hot_rows; p.hub_cap = a.hub_cap;
-            p.reps = std::max(1, a.hub_reps);
-            items = (p.num_chunks + (int64_t)(kHubBlock / kWave) * p.reps - 1) / ((int64_t)(kHubBlock / kWave) * p.reps);
-            if (p.xcd_remap) items = (items + kXcds - 1) / kXcds * kXcds;
-            p.blocks_per_phase = items;
-            const int64_t hgrid = items * (int64_t)p.B;
-            if (hgrid > 0x7fffffffLL) return fail(GNNA_ERR_UNSUPPORTED, "aggregation grid too large (%lld blocks)", (long long)hgrid);
+            p.blocks_per_phase = 1;                     // (unused by the persistent form)
+            const int64_t hgrid = std::max(1, a.num_cus);
             hipLaunchKernelGGL(k, dim3((unsigned)hgrid), dim3(kHubBlock), 0, stream, p);
             hipError_t eh = hipGetLastError();
             if (eh != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(eh));

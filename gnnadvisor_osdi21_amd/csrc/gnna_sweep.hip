@@ -113,25 +113,6 @@ struct SweepParams {
     int64_t num_chunks;        // ceil(P / 64)
 };
 
-// First index g in [0, P] with pp[g] >= target (pp non-decreasing, pp[P] >= target), searched 64 ways per round
-// trip by one wavefront.
-__device__ __forceinline__ int64_t lower_bound64(const int32_t *__restrict__ pp, int64_t P, int64_t target, int lane)
-{
-    int64_t lo = 0, hi = P;
-    while (hi > lo) {
-        const int64_t span = hi - lo;
-        const int64_t idx = lo + (span * lane) / kWave;                  // lo <= idx < hi
-        const bool below = (int64_t)pp[idx] < target;
-        const int c = __popcll(__ballot(below));                        // a prefix of the lanes
-        if (c == 0) { hi = lo; break; }
-        const int64_t new_lo = lo + (span * (c - 1)) / kWave + 1;
-        const int64_t new_hi = c < kWave ? lo + (span * c) / kWave : hi;
-        lo = new_lo;
-        hi = new_hi > new_lo ? new_hi : new_lo;
-    }
-    return lo;
-}
-
 // First group of set i of num_sets (one wavefront; every lane returns it): an equal share of the EDGES, found by a search
 // in part_pointers -- for a partition that is not canonical (no search can be trusted on its part_pointers; every group
 // then flushes per slice anyway) an equal share of the GROUPS.  With packed ids the sets start at multiples of 64 groups,
@@ -168,9 +149,9 @@ sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const 
         return;
     }
     const uint32_t n = list[0] < (uint32_t)kSweepListCap ? list[0] : (uint32_t)kSweepListCap;
-    for (uint32_t i = 0; i < n; i++) {                       // (a handful of ranges: every wavefront walks the list)
+    for (int64_t i = wave; i < (int64_t)n; i += nwaves) {    // one wavefront per range (the kernel lists ranges of <= 16 rows)
         const int64_t first = (int64_t)list[2 + 2 * i], cnt = (int64_t)list[3 + 2 * i];
-        for (int64_t r = first + wave; r < first + cnt && r < N; r += nwaves) clamp_row(r);
+        for (int64_t r = first; r < first + cnt && r < N; r++) clamp_row(r);
     }
 }
 
@@ -254,7 +235,10 @@ sweep_kernel(const SweepParams p)
                 else list[1] = 1u;
             };
             if (set_prev_row == row_first) push(row_first, 1);
-            if (row_last - row_first + 1 > CAP) push(row_first + CAP, row_last - row_first + 1 - CAP);
+            const int over_rows = row_last - row_first + 1 - CAP;       // rows beyond the accumulators, in ranges of <= 16
+            if (over_rows > 2048) list[1] = 1u;
+            else
+                for (int r0 = 0; r0 < over_rows; r0 += 16) push(row_first + CAP + r0, over_rows - r0 < 16 ? over_rows - r0 : 16);
         }
         for (int i = threadIdx.x; i < nrows * D; i += kSweepBlock) s_acc[i] = 0.f;
         __syncthreads();
