@@ -29,7 +29,7 @@ class Tuning(ctypes.Structure):
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
                 ("pad_rows", ctypes.c_int), ("stream_kernel", ctypes.c_int), ("zero_fill", ctypes.c_int),
                 ("sweep", ctypes.c_int), ("sweep_slack", ctypes.c_int), ("deterministic", ctypes.c_int),
-                ("pack_ids", ctypes.c_int), ("row_cache", ctypes.c_int), ("wide_blocks", ctypes.c_int)]
+                ("pack_ids", ctypes.c_int), ("wide_blocks", ctypes.c_int)]
 
 
 _lib = None
@@ -46,7 +46,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
            "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
-           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld", "gnna_runtime_counter")
+           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld")
 
 
 def load() -> ctypes.CDLL:
@@ -133,8 +133,6 @@ def load() -> ctypes.CDLL:
     L.gnna_forget_graph.argtypes = [ctypes.c_void_p]
     L.gnna_runtime_counters.restype = None
     L.gnna_runtime_counters.argtypes = [ctypes.POINTER(ctypes.c_int64)]
-    L.gnna_runtime_counter.restype = ctypes.c_int64
-    L.gnna_runtime_counter.argtypes = [ctypes.c_int]
     L.gnna_profile_begin.restype = ctypes.c_int
     L.gnna_profile_begin.argtypes = [ctypes.c_int]
     L.gnna_profile_end.restype = ctypes.c_int
@@ -160,10 +158,10 @@ def _stream(device: torch.device) -> int:
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
                pad_rows=-1, stream_kernel=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1,
-               row_cache=-1, wide_blocks=-1) -> None:
+               wide_blocks=-1) -> None:
     t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
                avg_degree, nonlocal_ids, gcn_prescale, pad_rows, stream_kernel, zero_fill, sweep, sweep_slack, deterministic,
-               pack_ids, row_cache, wide_blocks)
+               pack_ids, wide_blocks)
     load().gnna_set_tuning(ctypes.byref(t))
 
 
@@ -500,9 +498,7 @@ def runtime_counters() -> dict:
     load().gnna_runtime_counters(out)
     names = ("plan_builds", "launch_syncs", "launch_frees", "launch_mallocs", "backoff_skips", "sweep_launches",
              "pack_builds", "packed_launches")
-    res = {n: int(out[i]) for i, n in enumerate(names)}
-    res["hub_launches"] = int(load().gnna_runtime_counter(8))
-    return res
+    return {n: int(out[i]) for i, n in enumerate(names)}
 
 
 def set_graph_phases(column_index, dim: int, column_phases: int) -> None:

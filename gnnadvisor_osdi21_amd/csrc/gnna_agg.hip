@@ -22,7 +22,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
-#include <cstdlib>
 
 #include "gnna.h"
 #include "gnna_device.h"
@@ -727,18 +726,8 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
     // prepared graph: the ids in the order the sliced schedule consumes them (built by gnna_prepare_graph for the
     // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
     if (cnt && !windowed && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned))) {
-        // narrow rows: the copy marked for the hot-row cache, if gnna_prepare_graph made one (64 groups per work item)
-        const int hcap = (tune.row_cache != 2 && !a.det && !wide && (mode == MODE_SAG || mode == MODE_GIN) && (ldx & 3) == 0 &&
-                          (reinterpret_cast<uintptr_t>(X) & 15) == 0) ? hub_cap_for(dim) : 0;
-        if (hcap > 0) {
-            rc = get_packed_ids(ds, stream, plan.handle, B, kWave, false, false, &a.ids_packed, &a.item_off, &chk_sum, &chk_n, hcap,
-                                &a.hot_rows);
-            if (rc != GNNA_OK) return rc;
-            if (a.ids_packed) { a.hub_cap = hcap; a.G = kWave; a.num_cus = ds->num_cus; a.hub_u = std::getenv("GNNA_HUB_U4") ? 4 : (std::getenv("GNNA_HUB_U16") ? 16 : 8); }
-        }
-        if (!a.ids_packed)
-            rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
-                                &chk_sum, &chk_n);
+        rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
+                            &chk_sum, &chk_n);
         a.packed_stale = stale_flag;
         if (rc != GNNA_OK) return rc;
         if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
@@ -895,18 +884,10 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
             if (t.sweep == 1 && t.deterministic != 1 && sweep_supports(mode_guess, dim, x_bytes))
                 Bs = t.column_phases >= 2 ? B : std::max(2, std::min(std::min(16, 2 * B), std::max(2, partSize / 4)));
             Bs = std::min(Bs, plan.S);
-            const int hcap = (t.row_cache != 2 && t.deterministic != 1 && mode_guess == MODE_SAG && (ldx & 3) == 0) ? hub_cap_for(dim) : 0;
-            if (Bs >= 2 && t.xcd_remap != 0) {
+            if (Bs >= 2 && t.xcd_remap != 0)
                 rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, true, &ids, &off);
-            } else {
-                const int32_t *hot = nullptr;
-                if (hcap > 0) {                       // narrow rows: the copy marked for the hot-row cache, when it is worth one
-                    rc = get_packed_ids(ds, stream, plan.handle, B, kWave, true, true, &ids, &off, nullptr, nullptr, hcap, &hot);
-                    if (rc != GNNA_OK) return rc;
-                }
-                if (!ids)
-                    rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
-            }
+            else
+                rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
             if (rc != GNNA_OK) return rc;
             if (phases_out && Bs >= 2) phases_out[i] = Bs;
         }

@@ -170,25 +170,6 @@ __device__ __forceinline__ unsigned long long sample_checksum(const int32_t *__r
     return sum;
 }
 
-// First index g in [0, P] with pp[g] >= target (pp non-decreasing, pp[P] >= target), searched 64 ways per round
-// trip by one wavefront.
-__device__ __forceinline__ int64_t lower_bound64(const int32_t *__restrict__ pp, int64_t P, int64_t target, int lane)
-{
-    int64_t lo = 0, hi = P;
-    while (hi > lo) {
-        const int64_t span = hi - lo;
-        const int64_t idx = lo + (span * lane) / kWave;                  // lo <= idx < hi
-        const bool below = (int64_t)pp[idx] < target;
-        const int c = __popcll(__ballot(below));                        // a prefix of the lanes
-        if (c == 0) { hi = lo; break; }
-        const int64_t new_lo = lo + (span * (c - 1)) / kWave + 1;
-        const int64_t new_hi = c < kWave ? lo + (span * c) / kWave : hi;
-        lo = new_lo;
-        hi = new_hi > new_lo ? new_hi : new_lo;
-    }
-    return lo;
-}
-
 // What a packed copy of the ids remembers about the graph it was made from: samples of column_index AND of part_pointers
 // (the item starts of the copy are derived from the latter; its last entry -- the edge count -- is always among the
 // samples' end points) -- 1024 + 1024 entries, so a buffer that was rewritten is noticed, a few changed entries are not.

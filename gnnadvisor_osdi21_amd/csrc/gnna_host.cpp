@@ -28,7 +28,7 @@ const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*
                                     /*column_phases=*/0, /*avg_degree=*/0, /*nonlocal_ids=*/0,
                                     /*gcn_prescale=*/0, /*pad_rows=*/0, /*stream_kernel=*/0, /*zero_fill=*/0,
                                     /*sweep=*/0, /*sweep_slack=*/0, /*deterministic=*/0, /*pack_ids=*/0,
-                                    /*row_cache=*/0, /*wide_blocks=*/0};
+                                    /*wide_blocks=*/0};
 gnna_tuning g_tuning = kDefaultTuning;
 std::mutex g_tuning_mutex;
 std::once_flag g_env_once;
@@ -76,7 +76,6 @@ void apply_env()
         else if (!std::strcmp(tok, "DET")) g_tuning.deterministic = v;
         else if (!std::strcmp(tok, "PACK")) g_tuning.pack_ids = v;
         else if (!std::strcmp(tok, "BLOCKS")) g_tuning.wide_blocks = v;
-        else if (!std::strcmp(tok, "CACHE")) g_tuning.row_cache = v;
     }
 }
 
@@ -160,7 +159,6 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->deterministic >= 0) g_tuning.deterministic = t->deterministic;
     if (t->pack_ids >= 0) g_tuning.pack_ids = t->pack_ids;
     if (t->wide_blocks >= 0) g_tuning.wide_blocks = t->wide_blocks;
-    if (t->row_cache >= 0) g_tuning.row_cache = t->row_cache;
 }
 
 int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids)

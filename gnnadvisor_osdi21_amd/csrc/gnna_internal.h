@@ -83,13 +83,9 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
 void drop_slice_plans();
 // Packed column ids of a plan for (B phases, G groups per chunk): see gnna_stream.hip.  *ids == null: none.  The
 // caller decides whether the plan may have them (pinned, or gnna_tuning.pack_ids = 1).
-// hub_cap > 0 (with hot_rows): the copy marked for the streaming kernel's hot-row cache of `hub_cap` LDS slots per phase
-// (built only with `force`, i.e. by gnna_prepare_graph; *ids stays null when there is none -- ask for the plain copy then).
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
                    const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum = nullptr,
-                   int64_t *num_ids = nullptr, int hub_cap = 0, const int32_t **hot_rows = nullptr);
-// LDS slots of the hot-row cache for rows of `dim` floats (0: no cache at this width).
-int hub_cap_for(int dim);
+                   int64_t *num_ids = nullptr);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
 // deferred: the device buffers are not freed now (no synchronisation: safe from a finalizer on any thread, during a
 // stream capture) but at the next gnna_prepare_graph / gnna_release_graph / plan allocation with no launch in flight.
@@ -110,7 +106,7 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
                   bool square, bool hinted_scattered);
 // Events on the launch path that the contract promises not to happen after gnna_prepare_graph (gnna_runtime_counters).
 enum { CTR_PLAN_BUILDS = 0, CTR_LAUNCH_SYNCS = 1, CTR_LAUNCH_FREES = 2, CTR_LAUNCH_MALLOCS = 3, CTR_BACKOFF_SKIPS = 4,
-       CTR_SWEEP_LAUNCHES = 5, CTR_PACK_BUILDS = 6, CTR_PACKED_LAUNCHES = 7, CTR_HUB_LAUNCHES = 8, CTR_COUNT = 9 };
+       CTR_SWEEP_LAUNCHES = 5, CTR_PACK_BUILDS = 6, CTR_PACKED_LAUNCHES = 7, CTR_COUNT = 8 };
 void count_event(int which);
 
 struct StreamLaunch {
@@ -133,7 +129,6 @@ struct StreamLaunch {
     float *det_part = nullptr; int32_t *det_stamp = nullptr;   // [num_chunks][2][D] partial rows / [num_chunks][2] stamps
     const int32_t *ids_packed = nullptr; const uint32_t *item_off = nullptr;   // packed ids of a prepared graph for (B, G)
     const int32_t *packed_stale = nullptr;   // *packed_stale == seq: column_index no longer matches the copy, read column_index
-    const int32_t *hot_rows = nullptr; int hub_cap = 0; int hub_u = 8; int num_cus = 256;   // hot-row cache (ids_packed is the marked copy)
 };
 int launch_stream(const StreamLaunch &a, hipStream_t stream);
 // The ReLU epilogue over the whole output on its own (a call that has nothing to aggregate but accumulates into `out`).

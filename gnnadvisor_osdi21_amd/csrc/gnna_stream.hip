@@ -61,21 +61,8 @@ constexpr int kIdSlots = 512;    // at most this many column ids parked in LDS p
 // (rows of <= 16 floats: 16 rows per load, so 512 slots would be only 32 loads per round; with 1024 a round holds 64
 // like every other width -- Reddit-like D = 16: 0.900 -> 0.860 ms, D = 8: 0.857 -> 0.810 ms.  Not for the modes that
 // park a second per-slot array in LDS: 3 x 16 KiB per block would cost occupancy)
-template <int LPR, int MODE, bool HUB = false>
-constexpr int id_slots() { return (LPR == 4 && MODE != MODE_GCN && MODE != MODE_SDDMM && !HUB) ? GNNA_NARROW_SLOTS : kIdSlots; }
-
-// ---- hot-row cache (HUB variant of stream_kernel; rows of <= 32 floats) ----------------------------------------------
-// A 64-byte row costs a whole 128-byte L2 request, so narrow rows run at the request rate of rows twice their size with
-// half of every request wasted (Reddit-like D = 16: 1.0 request per edge, the same 165 G requests/s as D = 64).  What the L2
-// cannot do for them, LDS can: 96 KB hold 1536 rows of 16 floats -- with power-law ids the most popular 1536 source rows of a
-// 58 K-row slice take ~35-40 % of the slice's edges.  A prepared graph's packed ids mark those ids "0x80000000 | slot"
-// (per phase: hot_rows[phase][slot] names the row; within a destination row's piece the hot ids come first, so that most
-// wave-wide loads are all-LDS or all-memory); a 16-wavefront workgroup loads the phase's hot rows into LDS once and then
-// runs kHubReps x 16 work items of that phase.  Bare access stream with the cache (tools/ceiling/probe_hub_narrow.py,
-// profiles/r4/hub_narrow_*.log), Reddit-like D = 16, 4 / 8 slices: 0.67 / 0.64 -> 0.50 / 0.46 ms; D = 32, 8 slices: 0.77 -> 0.58.
-constexpr int kHubBytes = 96 * 1024;
-constexpr int kHubBlock = 1024;
-template <int LPR> constexpr int hub_cap() { return kHubBytes / (LPR * 16); }
+template <int LPR, int MODE>
+constexpr int id_slots() { return (LPR == 4 && MODE != MODE_GCN && MODE != MODE_SDDMM) ? GNNA_NARROW_SLOTS : kIdSlots; }
 
 struct StreamParams {
     const float *X;
@@ -122,10 +109,6 @@ struct StreamParams {
     const int32_t *ids_packed;
     const uint32_t *item_off;
     const int32_t *packed_stale;   // *packed_stale == seq: the prologue found column_index changed since the copy was made
-    // HUB variant: hot_rows[phase * hub_cap + slot] = source row kept in LDS slot `slot` during `phase`; marked ids in
-    // ids_packed; one persistent workgroup per CU
-    const int32_t *hot_rows;
-    int32_t hub_cap;
 };
 
 // ---- slice counts ---------------------------------------------------------------------------------
@@ -282,25 +265,20 @@ __device__ __forceinline__ void emit_row(const float *__restrict__ buf, float *_
 constexpr int kSBlock = GNNA_STREAM_BLOCK;        // threads per block of stream_kernel
 constexpr int kSWaves = kSBlock / kWave;
 
-template <int LPR, int MODE, int U, bool WIDE, bool HUB = false>
-__global__ void __launch_bounds__(HUB ? kHubBlock : kSBlock)
+template <int LPR, int MODE, int U, bool WIDE>
+__global__ void __launch_bounds__(kSBlock)
 stream_kernel(const StreamParams p)
 {
     typedef typename VecOf<4>::T VT;
     typedef typename VecOf<4>::M MT;
     typedef typename std::conditional<WIDE, uint64_t, uint32_t>::type OffT;
-    static_assert(!HUB || (!WIDE && LPR <= 8 && (MODE == MODE_SAG || MODE == MODE_GIN)), "hot-row cache: narrow rows, 32-bit offsets");
-    constexpr int kSBlockT = HUB ? kHubBlock : kSBlock;                // threads per block of this variant
-    constexpr int kSWavesT = kSBlockT / kWave;
     constexpr int RPI = kWave / LPR;                                   // neighbor rows per wave-wide load
-    constexpr int RL = (id_slots<LPR, MODE, HUB>() / RPI < kWave) ? id_slots<LPR, MODE, HUB>() / RPI : kWave;  // loads per round
+    constexpr int RL = (id_slots<LPR, MODE>() / RPI < kWave) ? id_slots<LPR, MODE>() / RPI : kWave;  // loads per round
     static_assert(RL % U == 0, "a round is a whole number of batches");
     // per wavefront: the round's list slots as row offsets into X (bytes; row index when X > 4 GiB)
-    __shared__ uint32_t s_off[kSWavesT][RL * RPI];
+    __shared__ uint32_t s_off[kSWaves][RL * RPI];
     // MODE_GCN: the per-edge coefficient round(deg_i * deg_j) of every list slot (reference .cu:355,389)
-    __shared__ float s_cf[kSWavesT][MODE == MODE_GCN ? RL * RPI : 1];
-    // HUB: the phase's hot source rows, slot s at byte s * LPR * 16 (natural float order)
-    __shared__ float s_hub[HUB ? kHubBytes / 4 : 1];
+    __shared__ float s_cf[kSWaves][MODE == MODE_GCN ? RL * RPI : 1];
     // folded rows waiting to be written: the float atomics of the sliced schedule are memory-side round
     // trips that sit in the same in-order vmcnt queue as the row loads, so a flush in the middle of the
     // stream would stall the ring until it retires.  Rows are parked here (2 KiB per wavefront) and
@@ -309,7 +287,7 @@ stream_kernel(const StreamParams p)
     constexpr int PEND_FLOATS = LPR * 4;                               // floats per parked row (one dimension sweep)
     // (MODE_SDDMM parks the round's dot products there instead: one float per list slot)
     constexpr int PEND_TOTAL = MODE == MODE_SDDMM ? RL * RPI : PEND * PEND_FLOATS;
-    __shared__ float s_pend[kSWavesT][PEND_TOTAL];
+    __shared__ float s_pend[kSWaves][PEND_TOTAL];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -326,88 +304,14 @@ stream_kernel(const StreamParams p)
     int pend_meta = 0;      // lane q: (row << 2 | atomic) of parked row q
     int npend = 0;
 
-    // block -> (phase, chunks): blocks are numbered phase-major, inside a phase every XCD gets one
+    // block -> (phase, chunk): blocks are numbered phase-major, inside a phase every XCD gets one
     // contiguous range of chunks (blocks land on XCD blockIdx % 8)
     const int64_t bpp = p.blocks_per_phase;
-    int phase = p.phase_lo + (int)((int64_t)blockIdx.x / bpp);
+    const int phase = p.phase_lo + (int)((int64_t)blockIdx.x / bpp);
     int64_t item = (int64_t)blockIdx.x % bpp;
     if (p.xcd_remap) item = (item % kXcds) * (bpp / kXcds) + item / kXcds;
-    const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr && *p.packed_stale != p.seq;
-    // HUB: ONE persistent workgroup per CU owns a contiguous range of chunks -- an equal share of the edges -- for all
-    // phases; per phase it loads the phase's hot rows into LDS, then its 16 wavefronts draw the chunks of the range from a
-    // counter in LDS.  (Workgroups that reload the cache per 64 work items lose more to the reload, the ramp-up and the
-    // tail of a block than the cache wins: 0.81 against 0.70 ms on Reddit-like D = 16.)
-    __shared__ int64_t s_range[2];
-    __shared__ int s_next;
-    int64_t c_lo = 0, c_hi = 0;
-    auto load_cache = [&](int ph) {
-        if constexpr (HUB) {
-            // the phase's hot rows -> LDS: every thread copies PER 16-byte pieces; all slot lookups first, then all row
-            // loads, then the LDS stores -- two round trips for the whole cache, not two per piece
-            const int32_t *__restrict__ hot = p.hot_rows + (size_t)ph * (size_t)p.hub_cap;
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-            const int pieces = D >> 2;                                  // (HUB: D % 4 == 0)
-            constexpr int PER = (hub_cap<LPR>() * LPR + kHubBlock - 1) / kHubBlock;
-            uint32_t ro[PER];
-            f32x4 val[PER];
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                const int i = (int)threadIdx.x + k * kHubBlock;
-                ro[k] = i < hub_cap<LPR>() * LPR ? (uint32_t)hot[i / LPR] * row_bytes32 + (uint32_t)(i % LPR) * 16u : 0u;
-            }
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                const int i = (int)threadIdx.x + k * kHubBlock;
-                val[k] = (i < hub_cap<LPR>() * LPR && (i % LPR) < pieces) ? *reinterpret_cast<const f32x4 *>(xbase + ro[k]) : (f32x4)(0.f);
-            }
-#pragma unroll
-            for (int k = 0; k < PER; k++) {
-                const int i = (int)threadIdx.x + k * kHubBlock;
-                if (i < hub_cap<LPR>() * LPR) reinterpret_cast<f32x4 *>(s_hub)[i] = val[k];
-            }
-        }
-    };
-    if constexpr (HUB) {
-        if (wib < 2) {
-            // first chunk of workgroup i of n: the chunk that holds edge nnz * i / n (a search in part_pointers; equal
-            // shares of the chunks for a partition that is not canonical)
-            const int64_t i = (int64_t)blockIdx.x + wib, n = (int64_t)gridDim.x;
-            int64_t cb;
-            if (i <= 0) cb = 0;
-            else if (i >= n) cb = p.num_chunks;
-            else if (!canonical) cb = (p.num_chunks * i) / n;
-            else cb = lower_bound64(p.pp, p.P, ((int64_t)p.pp[p.P] * i) / n, lane) / p.G;
-            if (lane == 0) s_range[wib] = cb < p.num_chunks ? cb : p.num_chunks;
-        }
-        if (threadIdx.x == 0) s_next = 0;
-        __syncthreads();
-        c_lo = s_range[0]; c_hi = s_range[1];
-        phase = 0;
-        if (packed) load_cache(0);
-        __syncthreads();
-    }
-    for (int it = 0;; it++) {
-    int64_t chunk;
-    if constexpr (HUB) {
-        // draw the next chunk of this phase; when the range is used up, all 16 wavefronts meet, the next phase's hot rows
-        // replace the cache, and the range is walked again
-        int d = 0;
-        if (lane == 0) d = __hip_atomic_fetch_add(&s_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        d = __builtin_amdgcn_readfirstlane(d);
-        if (c_lo + d >= c_hi) {
-            __syncthreads();                                  // everyone is done with this phase's cache (and has drawn)
-            if (++phase >= p.B) break;
-            if (threadIdx.x == 0) s_next = 0;
-            if (packed) load_cache(phase);
-            __syncthreads();
-            continue;
-        }
-        chunk = c_lo + d;
-    } else {
-        if (it > 0) break;
-        chunk = item * kSWavesT + wib;
-        if (chunk >= p.num_chunks) break;
-    }
+    const int64_t chunk = item * kSWaves + wib;
+    if (chunk >= p.num_chunks) return;
     const int G = p.G;
     const int64_t g0 = chunk * G;
     const int ng = (int)(p.P - g0 < (int64_t)G ? p.P - g0 : (int64_t)G);
@@ -428,6 +332,7 @@ stream_kernel(const StreamParams p)
     int prev_row = -1, next_row = -1;
     if (g0 > 0) prev_row = p.p2n[g0 - 1];
     if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
+    const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr && *p.packed_stale != p.seq;
     const uint32_t item_base = packed ? p.item_off[(size_t)phase * (size_t)p.num_chunks + (size_t)chunk] : 0u;
     const int32_t *__restrict__ ids = packed ? p.ids_packed : p.col;
 
@@ -439,7 +344,7 @@ stream_kernel(const StreamParams p)
     int end = cum_hi < len ? cum_hi : len;
     end = end > beg ? end : beg;
     const int n_own = gl ? end - beg : 0;  // edges of this group in this phase
-    if (__ballot(n_own > 0) == 0) continue;  // nothing of this chunk in this phase
+    if (__ballot(n_own > 0) == 0) return;  // nothing of this chunk in this phase
 
     // destination-row segments and who flushes
     const int up_row = __shfl_up(my_row, 1);
@@ -584,12 +489,7 @@ stream_kernel(const StreamParams p)
                 }
 #pragma unroll
                 for (int s = 0; s < RPI; s++) {
-                    if constexpr (HUB) {
-                        // a marked id (0x80000000 | slot) becomes the mark + the slot's byte offset in the cache
-                        o[s] = (o[s] >> 31) ? (0x80000000u | ((o[s] & 0x7fffffffu) * (uint32_t)(LPR * 16))) : o[s] * row_bytes32;
-                    } else if constexpr (!WIDE) {
-                        o[s] *= row_bytes32;
-                    }
+                    if constexpr (!WIDE) o[s] *= row_bytes32;
                     offs[lane * RPI + s] = o[s];
                 }
             }
@@ -598,13 +498,6 @@ stream_kernel(const StreamParams p)
             auto row_ptr = [&](uint32_t o) -> const MT * {
                 if constexpr (WIDE) return reinterpret_cast<const MT *>(xbase + ((uint64_t)o * (uint64_t)row_bytes32 + col_off));
                 else return reinterpret_cast<const MT *>(xbase + (o + col_off));
-            };
-            // one row piece: from the LDS cache when the slot is marked (HUB), else from memory
-            auto load_row = [&](uint32_t o) -> VT {
-                if constexpr (HUB) {
-                    if (o >> 31) return *reinterpret_cast<const VT *>(reinterpret_cast<const char *>(s_hub) + ((o & 0x7fffffffu) + col_off));
-                }
-                return *row_ptr(o);
             };
             const int nb = (nr + U - 1) / U;
             VT v[U];
@@ -666,7 +559,7 @@ stream_kernel(const StreamParams p)
                 continue;
             }
 #pragma unroll
-            for (int u = 0; u < U; u++) v[u] = load_row(offs[u * RPI + slot]);
+            for (int u = 0; u < U; u++) v[u] = *row_ptr(offs[u * RPI + slot]);
             auto consume = [&](int u, int j) {
                 if ((TM >> j) & 1ull) {
                     const int vj = __builtin_amdgcn_readlane(v_j, j);
@@ -704,7 +597,7 @@ stream_kernel(const StreamParams p)
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     consume(u, b * U + u);
-                    v[u] = load_row(nn[u]);
+                    v[u] = *row_ptr(nn[u]);
                 }
             }
             // the last batch only consumes (its slots past the round's end hold row 0 and are skipped)
@@ -716,7 +609,6 @@ stream_kernel(const StreamParams p)
             if (npend > PEND / 2 || r0 + RL >= L) drain();   // between rounds: nothing of the ring waits behind these
         }
     }
-    }   // items
 }
 
 // ---- deterministic schedule: shared rows ---------------------------------------------------------------
@@ -882,70 +774,6 @@ item_pack_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp
     }
 }
 
-// freq[id] = number of edges whose source is `id` (the popularity the hot-row cache selects by)
-__global__ void __launch_bounds__(kBlock)
-id_histogram_kernel(const int32_t *__restrict__ col, int64_t n, uint32_t *__restrict__ freq, int64_t rows)
-{
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < n; i += nthreads) {
-        const uint32_t id = (uint32_t)col[i];
-        if ((int64_t)id < rows) atomicAdd(&freq[id], 1u);
-    }
-}
-
-// item_pack_kernel for the hot-row cache: slot_of[id] >= 0 names the LDS slot of source row `id` in the phase that owns
-// the row's id range.  An id is written as 0x80000000 | slot when it is consumed in THAT phase (positions and id ranges
-// coincide for sorted ids; an id that the position-based phases consume elsewhere stays an ordinary id, so unsorted ids
-// only lose the cache, never correctness).  Inside a run of groups of one destination row the hot ids come first:
-// the kernel reads the run as one piece, so most of its wave-wide loads are all-LDS or all-memory.
-__global__ void __launch_bounds__(kBlock)
-item_pack_hub_kernel(const int32_t *__restrict__ col, const int32_t *__restrict__ pp, const int32_t *__restrict__ p2n,
-                     const uint8_t *__restrict__ cnt, int64_t P, int64_t num_chunks, int G, int S, int B, uint32_t slice_rows,
-                     const int32_t *__restrict__ slot_of, int64_t rows, const uint32_t *__restrict__ item_off,
-                     int32_t *__restrict__ out)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t items = num_chunks * B;
-    const unsigned long long upto = (2ull << lane) - 1ull;
-    for (int64_t q = wave; q < items; q += nwaves) {
-        const int phase = (int)(q / num_chunks);
-        const int64_t g = (q % num_chunks) * G + lane;
-        const bool valid = lane < G && g < P;
-        int first = 0;
-        const int n = valid ? group_part(pp, cnt, P, S, B, phase, g, &first) : 0;
-        const int row = valid ? p2n[g] : -1 - lane;                      // (invalid lanes: each its own run)
-        // the source rows this phase owns
-        const int64_t id_lo = (int64_t)(phase * S / B) * slice_rows;
-        const int64_t id_hi = (phase + 1) * S / B >= S ? rows : (int64_t)((phase + 1) * S / B) * slice_rows;
-        auto slot_at = [&](int id) -> int {
-            return ((int64_t)id >= id_lo && (int64_t)id < id_hi && (int64_t)id < rows) ? slot_of[id] : -1;
-        };
-        int h = 0;
-        for (int j = 0; j < n; j++) h += slot_at(col[first + j]) >= 0 ? 1 : 0;
-        const int c = n - h;
-        const int up_row = __shfl_up(row, 1);
-        const unsigned long long SS = __ballot(lane == 0 || row != up_row);   // run starts
-        const int run_first = 63 - __builtin_clzll(SS & upto);
-        const unsigned long long above = SS & ~upto;
-        const int run_last = above ? __builtin_ctzll(above) - 1 : kWave - 1;
-        const int ih = wave_inclusive_scan(h), ic = wave_inclusive_scan(c), in = wave_inclusive_scan(n);
-        const int h0 = __shfl(ih - h, run_first), c0 = __shfl(ic - c, run_first), n0 = __shfl(in - n, run_first);
-        const int run_hot = __shfl(ih, run_last) - h0;
-        int32_t *run_base = out + item_off[q] + (uint32_t)n0;
-        int32_t *hot_dst = run_base + ((ih - h) - h0);
-        int32_t *cold_dst = run_base + run_hot + ((ic - c) - c0);
-        for (int j = 0; j < n; j++) {
-            const int id = col[first + j];
-            const int sl = slot_at(id);
-            if (sl >= 0) *hot_dst++ = (int32_t)(0x80000000u | (uint32_t)sl);
-            else *cold_dst++ = id;
-        }
-    }
-}
-
 __global__ void __launch_bounds__(kWave)
 ids_checksum_kernel(const int32_t *__restrict__ col, int64_t n, const int32_t *__restrict__ pp, int64_t P,
                     unsigned long long *__restrict__ out)
@@ -978,8 +806,6 @@ struct Plan {
         uint32_t *item_off = nullptr;
         unsigned long long *checksum = nullptr;   // sample_checksum of column_index when the copy was made
         int64_t num_ids = 0;
-        int cap = 0;                     // hot-row cache: LDS slots per phase the ids are marked for (0: plain copy)
-        int32_t *hot_rows = nullptr;     // [B][cap] source row of every slot
         hipEvent_t ready = nullptr;
         hipStream_t made_on = nullptr;
         uint64_t stamp = 0;              // value of the plan's lookup counter at the last use
@@ -1021,17 +847,6 @@ void drain_dead_locked(int allowed_in_flight)
 size_t stats_offset(int64_t P) { return (((size_t)P * (size_t)(kMaxSlices - 1)) + 255) & ~(size_t)255; }
 
 typedef void (*StreamKernel)(const StreamParams);
-
-template <int MODE>
-StreamKernel pick_stream_hub(int lpr, int u)
-{
-    if constexpr (MODE == MODE_SAG || MODE == MODE_GIN) {
-        // (16 wavefronts per CU: 8 row loads in flight per wavefront unless the caller asks for 4)
-        if (lpr == 4) return u == 4 ? stream_kernel<4, MODE, 4, false, true> : (u == 16 ? stream_kernel<4, MODE, 16, false, true> : stream_kernel<4, MODE, 8, false, true>);
-        if (lpr == 8) return u == 4 ? stream_kernel<8, MODE, 4, false, true> : (u == 16 ? stream_kernel<8, MODE, 16, false, true> : stream_kernel<8, MODE, 8, false, true>);
-    }
-    return nullptr;
-}
 
 template <int LPR, int MODE>
 StreamKernel pick_stream_wide(bool wide, int u)
@@ -1227,14 +1042,11 @@ void drop_slice_plans() { (void)release_slice_plans(nullptr, false); }
 // plan that already holds kMaxPacked is replaced after a device synchronisation -- at a launch only if it has not been
 // used for a while, in gnna_prepare_graph (force) always).  *ids stays null when there is none.
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
-                   const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum, int64_t *num_ids,
-                   int hub_cap, const int32_t **hot_rows)
+                   const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum, int64_t *num_ids)
 {
     *ids = nullptr; *item_off = nullptr;
     if (checksum) *checksum = nullptr;
     if (num_ids) *num_ids = 0;
-    if (hot_rows) *hot_rows = nullptr;
-    if (!hot_rows) hub_cap = 0;
     if (!plan_handle || B < 2 || G < 1) return GNNA_OK;
     std::lock_guard<std::mutex> lock(g_plan_mutex);
     Plan *pl = nullptr;
@@ -1244,20 +1056,16 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     (void)hipStreamIsCapturing(stream, &cap);
     pl->pack_lookups++;
     for (auto &pk : pl->packed) {
-        if (pk.B == B && pk.G == G && pk.cap == hub_cap && pk.ids) {
+        if (pk.B == B && pk.G == G && pk.ids) {
             if (pk.made_on != stream && cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, pk.ready, 0);
             pk.stamp = pl->pack_lookups;
             *ids = pk.ids; *item_off = pk.item_off;
             if (checksum) *checksum = pk.checksum;
             if (num_ids) *num_ids = pk.num_ids;
-            if (hot_rows) *hot_rows = pk.hot_rows;
             return GNNA_OK;
         }
     }
     if (!may_build || cap != hipStreamCaptureStatusNone) return GNNA_OK;
-    // a copy marked for the hot-row cache needs the ids' popularity on the host (one synchronisation, temporaries):
-    // only where the caller allows that -- gnna_prepare_graph
-    if (hub_cap > 0 && (!force || (int64_t)pl->slice_rows * kMaxSlices > ((int64_t)64 << 20))) return GNNA_OK;
     if (!force && pl->pack_lookups < pl->pack_no_memory_until) return GNNA_OK;   // a recent build ran out of memory
     const int64_t num_chunks = (pl->P + G - 1) / G;
     const int64_t items = num_chunks * B;
@@ -1290,68 +1098,11 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         }
         slot->ids = nullptr; slot->item_off = nullptr;
     }
-    // ---- hot-row cache: which rows, per phase (host side: popularity histogram -> the hub_cap most gathered rows of every
-    // phase's id range -> slot table)
-    std::vector<int32_t> hot_host;
-    int32_t *slot_dev = nullptr;
-    const int64_t plan_rows = (int64_t)pl->slice_rows * kMaxSlices;
-    if (hub_cap > 0) {
-        uint32_t *freq_dev = nullptr;
-        e = hipMalloc(reinterpret_cast<void **>(&freq_dev), (size_t)plan_rows * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&slot_dev), (size_t)plan_rows * sizeof(int32_t));
-        if (e != hipSuccess) {
-            (void)hipGetLastError();
-            if (freq_dev) (void)hipFree(freq_dev);
-            if (slot_dev) (void)hipFree(slot_dev);
-            return GNNA_OK;                                  // no memory for the temporaries: no copy of this kind
-        }
-        (void)hipMemsetAsync(freq_dev, 0, (size_t)plan_rows * sizeof(uint32_t), stream);
-        const int64_t hb = std::max<int64_t>(1, std::min<int64_t>((nnz + kBlock - 1) / kBlock, (int64_t)ds->num_cus * 16));
-        hipLaunchKernelGGL(id_histogram_kernel, dim3((unsigned)hb), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col), nnz,
-                           freq_dev, plan_rows);
-        std::vector<uint32_t> freq((size_t)plan_rows);
-        e = hipMemcpyAsync(freq.data(), freq_dev, (size_t)plan_rows * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        (void)hipFree(freq_dev);
-        if (e != hipSuccess) { (void)hipFree(slot_dev); return fail(GNNA_ERR_HIP, "hot-row popularity: %s", hipGetErrorString(e)); }
-        std::vector<int32_t> slot_host((size_t)plan_rows, -1);
-        hot_host.assign((size_t)B * (size_t)hub_cap, 0);
-        std::vector<int32_t> cand;
-        double hot_edges = 0;
-        for (int ph = 0; ph < B; ph++) {
-            const int64_t lo = (int64_t)(ph * kMaxSlices / B) * pl->slice_rows;
-            const int64_t hi = std::min<int64_t>(plan_rows, (int64_t)((ph + 1) * kMaxSlices / B) * pl->slice_rows);
-            cand.clear();
-            for (int64_t r = lo; r < hi; r++)
-                if (freq[(size_t)r] >= 2) cand.push_back((int32_t)r);
-            const size_t take = std::min<size_t>((size_t)hub_cap, cand.size());
-            if (take < cand.size())
-                std::nth_element(cand.begin(), cand.begin() + (long)take, cand.end(),
-                                 [&](int32_t a, int32_t b) { return freq[(size_t)a] != freq[(size_t)b] ? freq[(size_t)a] > freq[(size_t)b] : a < b; });
-            std::sort(cand.begin(), cand.begin() + (long)take);          // slots in row order: neighbouring slots, neighbouring lines
-            for (size_t k = 0; k < take; k++) {
-                slot_host[(size_t)cand[k]] = (int32_t)k;
-                hot_host[(size_t)ph * (size_t)hub_cap + k] = cand[k];
-                hot_edges += (double)freq[(size_t)cand[k]];
-            }
-            for (size_t k = take; k < (size_t)hub_cap; k++)
-                hot_host[(size_t)ph * (size_t)hub_cap + k] = take ? cand[0] : (int32_t)std::min<int64_t>(lo, plan_rows - 1);
-        }
-        // not worth a cache (and the 16-wavefront workgroups that come with it) unless a good share of the edges hits it
-        if (hot_edges < 0.2 * (double)nnz) { (void)hipFree(slot_dev); return GNNA_OK; }
-        if (std::getenv("GNNA_HUB_NOCACHE"))                 // experiments: the variant's workgroup form with nothing marked
-            std::fill(slot_host.begin(), slot_host.end(), -1);
-        e = hipMemcpyAsync(slot_dev, slot_host.data(), (size_t)plan_rows * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);      // (slot_host goes out of scope below)
-        if (e != hipSuccess) { (void)hipFree(slot_dev); return fail(GNNA_ERR_HIP, "hot-row slots: %s", hipGetErrorString(e)); }
-    }
     const size_t id_bytes = (((size_t)nnz * sizeof(int32_t)) + 255) & ~(size_t)255;
     const size_t off_bytes = ((((size_t)items + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
-    const size_t hot_bytes = (((size_t)B * (size_t)hub_cap * sizeof(int32_t)) + 15) & ~(size_t)15;
-    const size_t bytes = id_bytes + off_bytes + 16 + hot_bytes;
+    const size_t bytes = id_bytes + off_bytes + 16;
     e = hipMalloc(reinterpret_cast<void **>(&slot->ids), bytes);
     count_event(CTR_LAUNCH_MALLOCS);
-    if (e != hipSuccess && slot_dev) { (void)hipFree(slot_dev); slot_dev = nullptr; }
     if (e != hipSuccess) {
         // no memory for the copy: the ids are read from column_index.  The slot does not stay behind as an empty entry (four
         // of them would send every later launch through the replace-the-oldest branch: a device synchronisation and
@@ -1367,25 +1118,14 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     slot->item_off = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(slot->ids) + id_bytes);
     slot->checksum = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(slot->ids) + id_bytes + off_bytes);
     slot->num_ids = nnz;
-    slot->cap = hub_cap;
-    slot->hot_rows = hub_cap > 0 ? reinterpret_cast<int32_t *>(reinterpret_cast<char *>(slot->ids) + id_bytes + off_bytes + 16) : nullptr;
     slot->B = B; slot->G = G; slot->made_on = stream; slot->stamp = pl->pack_lookups;
     if (!slot->ready) (void)hipEventCreateWithFlags(&slot->ready, hipEventDisableTiming);
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((items + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)ds->num_cus * 16));
     hipLaunchKernelGGL(item_count_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->pp),
                        pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off);
     hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, stream, slot->item_off, items);
-    if (hub_cap > 0) {
-        (void)hipMemcpyAsync(slot->hot_rows, hot_host.data(), hot_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-        hipLaunchKernelGGL(item_pack_hub_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col),
-                           static_cast<const int32_t *>(pl->pp), static_cast<const int32_t *>(pl->p2n), pl->cnt, pl->P, num_chunks, G,
-                           kMaxSlices, B, pl->slice_rows, slot_dev, plan_rows, slot->item_off, slot->ids);
-        (void)hipStreamSynchronize(stream);              // (hot_host is read by the copy; slot_dev by the kernel)
-        (void)hipFree(slot_dev);
-    } else {
-        hipLaunchKernelGGL(item_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col),
-                           static_cast<const int32_t *>(pl->pp), pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off, slot->ids);
-    }
+    hipLaunchKernelGGL(item_pack_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col),
+                       static_cast<const int32_t *>(pl->pp), pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off, slot->ids);
     hipLaunchKernelGGL(ids_checksum_kernel, dim3(1), dim3(kWave), 0, stream, static_cast<const int32_t *>(pl->col), nnz,
                        static_cast<const int32_t *>(pl->pp), pl->P, slot->checksum);
     e = hipGetLastError();
@@ -1395,14 +1135,7 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     *ids = slot->ids; *item_off = slot->item_off;
     if (checksum) *checksum = slot->checksum;
     if (num_ids) *num_ids = slot->num_ids;
-    if (hot_rows) *hot_rows = slot->hot_rows;
     return GNNA_OK;
-}
-
-int hub_cap_for(int dim)
-{
-    if (dim < 4 || dim > 32 || (dim & 3)) return 0;
-    return dim <= 16 ? hub_cap<4>() : hub_cap<8>();
 }
 
 // The part of the ReLU epilogue the aggregation kernel leaves behind (nothing when the call has no epilogue).
@@ -1457,23 +1190,6 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
     p.ids_packed = (a.mode == MODE_SDDMM || !a.packed_stale) ? nullptr : a.ids_packed; p.item_off = a.item_off;
     p.packed_stale = a.packed_stale;
-    p.hot_rows = nullptr; p.hub_cap = 0;
-    if (a.hot_rows && a.hub_cap > 0 && p.ids_packed && !a.det && !a.wide && lpr <= 8 && (a.D & 3) == 0 && (a.ldx & 3) == 0 &&
-        (reinterpret_cast<uintptr_t>(a.X) & 15) == 0 && (a.mode == MODE_SAG || a.mode == MODE_GIN) && p.G == kWave) {
-        // hot-row cache: one persistent 16-wavefront workgroup per CU (see the kernel)
-        StreamKernel kh = a.mode == MODE_GIN ? pick_stream_hub<MODE_GIN>(lpr, a.hub_u) : pick_stream_hub<MODE_SAG>(lpr, a.hub_u);
-        if (kh) {
-            k = kh;
-            p.hot_rows = a.hot_rows; p.hub_cap = a.hub_cap;
-            p.blocks_per_phase = 1;                     // (unused by the persistent form)
-            const int64_t hgrid = std::max(1, a.num_cus);
-            hipLaunchKernelGGL(k, dim3((unsigned)hgrid), dim3(kHubBlock), 0, stream, p);
-            hipError_t eh = hipGetLastError();
-            if (eh != hipSuccess) return fail(GNNA_ERR_HIP, "aggregation launch: %s", hipGetErrorString(eh));
-            count_event(CTR_HUB_LAUNCHES);
-            return launch_relu_fixup(a, p.G, /*whole=*/true, stream);
-        }
-    }
     if (a.det && a.mode != MODE_SDDMM) {
         // deterministic schedule: the phases are separate launches in order, each followed by the ordered sum of
         // the rows that chunks share
@@ -1503,11 +1219,6 @@ extern "C" {
 void gnna_runtime_counters(int64_t out[8])
 {
     for (int i = 0; i < 8; i++) out[i] = i < gnna::CTR_COUNT ? (int64_t)gnna::g_counters[i].load() : 0;
-}
-
-int64_t gnna_runtime_counter(int index)
-{
-    return (index >= 0 && index < gnna::CTR_COUNT) ? (int64_t)gnna::g_counters[index].load() : -1;
 }
 #pragma GCC visibility pop
 }

@@ -113,6 +113,25 @@ struct SweepParams {
     int64_t num_chunks;        // ceil(P / 64)
 };
 
+// First index g in [0, P] with pp[g] >= target (pp non-decreasing, pp[P] >= target), searched 64 ways per round
+// trip by one wavefront.
+__device__ __forceinline__ int64_t lower_bound64(const int32_t *__restrict__ pp, int64_t P, int64_t target, int lane)
+{
+    int64_t lo = 0, hi = P;
+    while (hi > lo) {
+        const int64_t span = hi - lo;
+        const int64_t idx = lo + (span * lane) / kWave;                  // lo <= idx < hi
+        const bool below = (int64_t)pp[idx] < target;
+        const int c = __popcll(__ballot(below));                        // a prefix of the lanes
+        if (c == 0) { hi = lo; break; }
+        const int64_t new_lo = lo + (span * (c - 1)) / kWave + 1;
+        const int64_t new_hi = c < kWave ? lo + (span * c) / kWave : hi;
+        lo = new_lo;
+        hi = new_hi > new_lo ? new_hi : new_lo;
+    }
+    return lo;
+}
+
 // First group of set i of num_sets (one wavefront; every lane returns it): an equal share of the EDGES, found by a search
 // in part_pointers -- for a partition that is not canonical (no search can be trusted on its part_pointers; every group
 // then flushes per slice anyway) an equal share of the GROUPS.  With packed ids the sets start at multiples of 64 groups,
@@ -129,9 +148,10 @@ __device__ __forceinline__ int64_t sweep_set_start(int64_t i, int64_t num_sets, 
 
 // The ReLU epilogue's second half: rows the sweep kernel ADDED to the output instead of storing them once -- a row two sets
 // share (float atomics from both), the rows of a set beyond its accumulators (flushed per slice) -- are clamped here,
-// behind the kernel.  The kernel lists them itself while it runs, as (first row, rows) ranges: list[0] = number of
-// ranges, list[2 + 2 i], list[3 + 2 i] = range i; list[1] is raised when the list is full.  Then, and for a partition that
-// is not canonical or a call that accumulates into an existing output (`whole`), the whole output is clamped.
+// behind the kernel.  The kernel lists them itself while it runs, as (first row, rows) ranges of at most 16 rows:
+// list[0] = number of ranges, list[2 + 2 i], list[3 + 2 i] = range i; list[1] is raised when the list is full.  Then, and
+// for a partition that is not canonical or a call that accumulates into an existing output (`whole`), the whole output is
+// clamped.  (Measured on the headline, D = 64: aggregation 1.431 ms, with this epilogue 1.442, aggregation + torch.relu 1.451.)
 __global__ void __launch_bounds__(kBlock)
 sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const uint32_t *__restrict__ list,
                         const int32_t *flag, int32_t seq, int32_t trust, int whole)
@@ -149,7 +169,7 @@ sweep_relu_fixup_kernel(float *__restrict__ Y, int64_t N, int D, int ldy, const 
         return;
     }
     const uint32_t n = list[0] < (uint32_t)kSweepListCap ? list[0] : (uint32_t)kSweepListCap;
-    for (int64_t i = wave; i < (int64_t)n; i += nwaves) {    // one wavefront per range (the kernel lists ranges of <= 16 rows)
+    for (int64_t i = wave; i < (int64_t)n; i += nwaves) {    // one wavefront per range
         const int64_t first = (int64_t)list[2 + 2 * i], cnt = (int64_t)list[3 + 2 * i];
         for (int64_t r = first; r < first + cnt && r < N; r++) clamp_row(r);
     }

@@ -302,10 +302,6 @@ typedef struct gnna_tuning {
                              rewritten in place while the library holds a plan for it (the reference's own call sequence
                              never does; without the promise a stale copy would give wrong results, which is why it is
                              not the default) */
-    int row_cache;        /* hot-row cache of the streaming kernel for rows of <= 32 floats (a multiple of 4) on prepared graphs:
-                             the most gathered source rows of every slice are kept in 96 KB of LDS per CU, the packed ids of the
-                             graph are marked for it (a 64-byte row costs a whole 128-byte L2 request: what the L2 cannot do
-                             for narrow rows, LDS can).  0 = automatic (when >= 20 % of the edges would hit it), 2 = never */
     int wide_blocks;      /* rows of >= 192 floats in 64-float column blocks (one call per block, leading dimensions): 0 = automatic
                              (when every source row is gathered >= ~32 times and the matrix is Infinity-Cache sized), 1 = whenever
                              dim >= 72, 2 = never */
@@ -358,8 +354,6 @@ GNNA_API int gnna_forget_graph(const int32_t *column_index);
  *   never seen twice, [5] launches of the sweep kernel, [6] packed-id copies built, [7] aggregation launches that
  *   read packed ids. */
 GNNA_API void gnna_runtime_counters(int64_t out[8]);
-/* One counter by index: 0..7 as above, [8] aggregation launches that ran with the hot-row cache (-1: no such counter). */
-GNNA_API int64_t gnna_runtime_counter(int index);
 
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
 GNNA_API int gnna_last_num_phases(void);

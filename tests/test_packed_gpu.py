@@ -240,101 +240,3 @@ def test_packed_in_a_captured_graph():
     finally:
         _lib.reset_tuning()
         _lib.release_graph(ci)
-
-
-# ---- hot-row cache of the streaming kernel (rows of <= 32 floats; 0.4.0) -----------------------------------------------
-
-def hub_launches():
-    return _lib.runtime_counters()["hub_launches"]
-
-
-@pytest.mark.parametrize("dim", [4, 8, 12, 16, 20, 32])
-@pytest.mark.parametrize("phases,ps", [(2, 64), (4, 32), (8, 16), (7, 5)])
-def test_hot_row_cache_matches_the_oracle(dim, phases, ps):
-    """Prepared power-law graph, narrow rows: the packed ids are marked for the LDS cache of the most gathered source rows
-    (hot ids first inside every destination row's piece) and the 16-wavefront variant of the streaming kernel runs -- X = ones
-    exact, random inputs within the bound in all modes, fused ReLU and accumulate included."""
-    g, X, pp, p2n = make_case(20000, 1500000, dim, ps, seed=dim + phases, kind="powerlaw")
-    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
-    n = g.num_nodes
-    _lib.reset_tuning()
-    _lib.set_tuning(column_phases=phases, deterministic=0, sweep=2, gcn_prescale=1)
-    try:
-        _lib.prepare_graph(ci, ppd, p2nd, n, n, ps, [dim])
-        h0 = hub_launches()
-        check_all_modes(g, X, pp, p2n, ps, Xd, rp, ci, deg, ppd, p2nd, f"hot-row cache dim={dim} phases={phases} ps={ps}")
-        assert hub_launches() - h0 == 3, "the hot-row cache variant did not run"
-        ones = torch.ones_like(Xd)
-        y1 = _lib.sag(ones, rp, ci, deg, ppd, p2nd, ps, 32, 4)
-        assert torch.equal(y1.cpu(), (g.row_pointers[1:] - g.row_pointers[:-1]).float()[:, None].expand(-1, dim))
-        Xn, cin, rpn = X.numpy(), g.column_index.numpy(), g.row_pointers.numpy()
-        base = torch.randn(n, dim, generator=torch.Generator().manual_seed(5))
-        out = base.clone().cuda()
-        _lib.agg_ld(2, Xd, ci, ppd, p2nd, n, ps, epsilon=-0.5, out=out, accumulate=True, relu=True)
-        ref = np.maximum(oracle.csr_f64(2, Xn, rpn, cin, None, -0.5) + base.double().numpy(), 0.0)
-        assert_close_f64(out.cpu().numpy(), ref, what="hot-row cache + accumulate + relu",
-                         scale=oracle.csr_f64(0, np.abs(Xn), rpn, cin) + np.abs(base.numpy()))
-        assert hub_launches() - h0 == 5
-        # the off switch
-        _lib.set_tuning(row_cache=2)
-        h1 = hub_launches()
-        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
-        assert hub_launches() == h1
-        assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, Xn, rpn, cin), what="cache off")
-    finally:
-        _lib.reset_tuning()
-        _lib.release_graph(ci)
-
-
-def test_hot_row_cache_with_unsorted_ids_and_a_rewritten_graph():
-    """(1) Shuffled column ids inside the rows: the phases take id POSITIONS, so an id may be consumed in a phase that does
-    not own its row -- it must then stay an ordinary id (the slot number would name another row).  (2) column_index rewritten
-    after the prepare: the call notices (checksum) and reads column_index itself, without the cache's marks."""
-    dim, ps, phases = 16, 32, 4
-    g, X, pp, p2n = make_case(12000, 900000, dim, ps, seed=9, kind="powerlaw")
-    gen = torch.Generator().manual_seed(3)
-    rows = torch.repeat_interleave(torch.arange(g.num_nodes), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
-    order = torch.argsort(rows.double() + torch.rand(rows.numel(), generator=gen, dtype=torch.float64) * 0.5)
-    ci_shuf = g.column_index[order].contiguous()
-    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, ci_shuf, g.degrees, pp, p2n)
-    Xn, rpn = X.numpy(), g.row_pointers.numpy()
-    _lib.reset_tuning()
-    _lib.set_tuning(column_phases=phases, sweep=2)
-    try:
-        _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, ps, [dim])
-        h0 = hub_launches()
-        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
-        assert hub_launches() == h0 + 1
-        assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, Xn, rpn, ci_shuf.numpy()), what="shuffled ids through the cache variant")
-        # (2) another graph's ids written into the same buffer
-        g2 = graph.powerlaw_graph(g.num_nodes, 900000, 500, seed=77)
-        m = min(g2.column_index.numel(), ci.numel())
-        new_ci = ci.clone()
-        new_ci[:m] = g2.column_index[:m].cuda()
-        ci.copy_(new_ci)
-        y2 = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
-        assert_close_f64(y2.cpu().numpy(), oracle.csr_f64(0, Xn, rpn, new_ci.cpu().numpy()), what="rewritten ids")
-    finally:
-        _lib.reset_tuning()
-        _lib.release_graph(ci)
-
-
-def test_hot_row_cache_is_not_built_where_it_would_not_pay():
-    """A uniform low-degree graph: no row is gathered often enough -- gnna_prepare_graph builds the plain copy and the
-    ordinary kernel runs."""
-    g = graph.uniform_graph(60000, 600000, seed=4)
-    ps, dim = 16, 16
-    pp, p2n = _lib.build_part(ps, g.row_pointers)
-    X = torch.randn(g.num_nodes, dim, generator=torch.Generator().manual_seed(1))
-    Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
-    _lib.reset_tuning()
-    _lib.set_tuning(column_phases=4)
-    try:
-        _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, ps, [dim])
-        h0, (b0, l0) = hub_launches(), counters()
-        y = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, ps, 32, 4)
-        assert hub_launches() == h0 and counters()[1] == l0 + 1
-        assert_close_f64(y.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()), what="no cache")
-    finally:
-        _lib.reset_tuning()
-        _lib.release_graph(ci)
