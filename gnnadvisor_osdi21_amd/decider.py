@@ -53,14 +53,20 @@ def choose_part_size(avg_degree: float, dim: int) -> int:
     longer bounds shared memory; it sets (a) the metadata volume (8 B per group plus one
     chunk descriptor load per 16 groups) and (b) the granularity of load balancing (a
     wavefront work item is ``groups_per_chunk`` groups, i.e. at most 16 x partSize edges).
-    Measured on the Reddit-like graph at D = 64 (tools/sweep.py, DESIGN.md "Tuning"):
+    Measured on the Reddit-like graph at D = 64 (round 1, single pass of the first kernel):
     partSize 8 / 16 / 32 / 64 / 128 -> 4.04 / 2.80 / 2.64 / 2.51 / 2.62 ms.  Rule: the
-    power of two nearest the average degree, clamped to [16, 64].  ``dim`` is accepted for
-    future per-width rules and unused today.
+    power of two nearest the average degree, clamped to [16, 64] -- and 128 for rows of several hundred edges:
+    in the sliced schedule a work item is 64 groups of ONE source slice, i.e. partSize x 64 / phases edges, and at 16
+    phases a 64-edge group leaves 256 edges per item, little against the item's fixed round trips (descriptors -> ids ->
+    first rows).  Round 4, Reddit-like D = 64 (average degree 492), prepared graph, kernel ms at partSize 64 / 96 / 128 /
+    160 / 192: 1.386 / 1.357 / 1.352 / 1.346 / 1.363 with the sweep kernel; the streaming kernel (D = 16, 128) does not
+    care (0.725 / 0.730, 3.118 / 3.115).  ``dim`` is accepted for future per-width rules and unused today.
     """
     del dim
     target = max(1.0, float(avg_degree))
     ps = 1 << max(0, int(round(math.log2(target))))
+    if target >= 256.0:
+        return 128
     return int(min(max(ps, 16), 64))
 
 

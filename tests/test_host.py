@@ -167,7 +167,7 @@ def test_decider_mi355x_policy_is_sane():
         ip = decider.inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=h, dataset_obj=_DS(c),
                                    manual_mode=False)
         ip.decider()
-        assert 16 <= ip.partSize <= 64 and ip.partSize & (ip.partSize - 1) == 0
+        assert 16 <= ip.partSize <= 128 and ip.partSize & (ip.partSize - 1) == 0
         assert ip.dimWorker_hidden == decider.lanes_per_row(h) and 4 <= ip.dimWorker_hidden <= 64
         assert ip.warpPerBlock_hidden == 4 and 1 <= ip.groups_per_chunk <= 32
         assert ip.avg_degree_hint == max(1, int(e / n)) and ip.nonlocal_ids_hint == 1   # span n/3: scattered ids
@@ -177,7 +177,7 @@ def test_decider_mi355x_policy_is_sane():
     assert ip.nonlocal_ids_hint == 0            # community-ordered ids: never phase
     assert decider.lanes_per_row(64) == 16 and decider.lanes_per_row(16) == 4
     assert decider.lanes_per_row(41) == 64 and decider.lanes_per_row(100) == 32
-    assert decider.choose_part_size(492, 64) == 64 and decider.choose_part_size(3.9, 16) == 16
+    assert decider.choose_part_size(492, 64) == 128 and decider.choose_part_size(50.5, 64) == 64 and decider.choose_part_size(3.9, 16) == 16
 
 
 def test_graph_builders_follow_the_reference_loader():

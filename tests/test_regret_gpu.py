@@ -13,6 +13,7 @@ import pytest
 import torch
 
 from gnnadvisor_osdi21_amd import _lib, graph
+from gnnadvisor_osdi21_amd.decider import choose_part_size
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +58,7 @@ def test_the_automatic_schedule_is_within_7_percent_of_the_best_forced_one():
     for name, make, dims in CASES:
         g = make()
         avg = g.nnz / g.num_nodes
-        ps = 64 if avg >= 48 else (32 if avg >= 24 else 16)           # the mi355x policy's partSize rule
+        ps = choose_part_size(avg, 64)                                # the mi355x policy
         pp, p2n = _lib.build_part(ps, g.row_pointers.cpu())
         ppd, p2nd = pp.cuda(), p2n.cuda()
         for D in dims:
