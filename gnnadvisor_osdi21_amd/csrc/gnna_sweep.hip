@@ -389,8 +389,18 @@ sweep_kernel(const SweepParams p)
                     const int L = __builtin_amdgcn_readlane(c_offI, kWave - 1);
 
                     VT acc = vzero<4>();
-                    for (int r0 = 0; r0 < L; r0 += RL) {
-                        // ---- 2. this round's loads: lane j describes load r0 + j ----------------------------
+                    // ---- 2. a round's loads: lane j describes load r0 + j and fetches its RPI column ids.  The description
+                    // of round r + 1 -- ids included -- is made BEFORE round r is streamed: its id loads travel behind the
+                    // row loads of round r instead of standing alone between two rounds (a work item of the sliced schedule
+                    // is 2-4 rounds; with 16 wavefronts per CU nothing else covers that round trip).
+                    struct Round {
+                        uint32_t o[RPI];              // the load's row offsets (bytes)
+                        int v_j, k_meta;
+                        unsigned long long FL, TM;
+                        int nr;
+                    };
+                    auto describe = [&](int r0) -> Round {
+                        Round rd;
                         const unsigned long long below = __ballot(lane < Rn && c_offI <= r0);
                         unsigned long long inwin = __ballot(lane < Rn && c_offI > r0 && c_offI <= r0 + RL - 1);
                         unsigned long long E = 0;
@@ -401,20 +411,21 @@ sweep_kernel(const SweepParams p)
                         }
                         const int kp = __popcll(below) + __popcll(E & upto);
                         const int k_offX = __shfl(c_offX, kp), k_pbeg = __shfl(c_pbeg, kp), k_n = __shfl(c_n, kp);
-                        const int k_meta = __shfl(c_meta, kp);
+                        rd.k_meta = __shfl(c_meta, kp);
                         const int J = r0 + lane;
                         const bool active = J < L && lane < RL;
                         const int i = J - k_offX;
                         const int e_j = k_pbeg + i * RPI;
                         int v_j = active ? k_n - i * RPI : 0;
-                        const bool fl_j = active && (k_meta & 2) && v_j <= RPI;   // last load of the last piece of its row
+                        const bool fl_j = active && (rd.k_meta & 2) && v_j <= RPI;   // last load of the last piece of its row
                         v_j = v_j > RPI ? RPI : v_j;
-                        const unsigned long long FL = __ballot(fl_j);
-                        const unsigned long long TM = __ballot(active && v_j < RPI);   // loads with padded slots
-                        const int nr = (L - r0) < RL ? (L - r0) : RL;
-
+                        rd.v_j = v_j;
+                        rd.FL = __ballot(fl_j);
+                        rd.TM = __ballot(active && v_j < RPI);   // loads with padded slots
+                        rd.nr = (L - r0) < RL ? (L - r0) : RL;
+#pragma unroll
+                        for (int q = 0; q < RPI; q++) rd.o[q] = 0u;
                         if (lane < RL) {
-                            uint32_t o[RPI];
                             if (v_j == RPI) {
                                 if constexpr (RPI >= 4) {
                                     typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -422,23 +433,34 @@ sweep_kernel(const SweepParams p)
 #pragma unroll
                                     for (int s4 = 0; s4 < RPI; s4 += 4) {
                                         const i32x4 tt = *reinterpret_cast<const i32x4u *>(ids + e_j + s4);
-                                        o[s4] = (uint32_t)tt[0]; o[s4 + 1] = (uint32_t)tt[1]; o[s4 + 2] = (uint32_t)tt[2]; o[s4 + 3] = (uint32_t)tt[3];
+                                        rd.o[s4] = (uint32_t)tt[0]; rd.o[s4 + 1] = (uint32_t)tt[1]; rd.o[s4 + 2] = (uint32_t)tt[2]; rd.o[s4 + 3] = (uint32_t)tt[3];
                                     }
                                 } else {
 #pragma unroll
-                                    for (int q = 0; q < RPI; q++) o[q] = (uint32_t)ids[e_j + q];
+                                    for (int q = 0; q < RPI; q++) rd.o[q] = (uint32_t)ids[e_j + q];
                                 }
                             } else {
                                 const uint32_t first = v_j > 0 ? (uint32_t)ids[e_j] : 0u;
 #pragma unroll
                                 for (int q = 0; q < RPI; q++) {
-                                    o[q] = first;
-                                    if (q > 0 && q < v_j) o[q] = (uint32_t)ids[e_j + q];
+                                    rd.o[q] = first;
+                                    if (q > 0 && q < v_j) rd.o[q] = (uint32_t)ids[e_j + q];
                                 }
                             }
-#pragma unroll
-                            for (int q = 0; q < RPI; q++) offs[lane * RPI + q] = o[q] * row_bytes32;
                         }
+                        return rd;
+                    };
+                    Round cur = describe(0);
+                    for (int r0 = 0; r0 < L; r0 += RL) {
+                        if (lane < RL) {
+#pragma unroll
+                            for (int q = 0; q < RPI; q++) offs[lane * RPI + q] = cur.o[q] * row_bytes32;
+                        }
+                        const bool more = r0 + RL < L;
+                        Round nxt = cur;
+                        if (more) nxt = describe(r0 + RL);
+                        const int v_j = cur.v_j, k_meta = cur.k_meta, nr = cur.nr;
+                        const unsigned long long FL = cur.FL, TM = cur.TM;
 
                         // ---- 3. stream: U unpredicated row loads always in flight -----------------------------
                         auto row_ptr = [&](uint32_t o) -> const MT * {
@@ -521,6 +543,7 @@ sweep_kernel(const SweepParams p)
                             const int j = (nb - 1) * U + u;
                             if (j < nr) consume(u, j);
                         }
+                        cur = nxt;
                     }
                 }
             }
