@@ -379,8 +379,9 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
         return st.edges / std::max(rows, st.cells[l] - (st.groups - rows));
     };
     // Two regimes (measured, D = 64).  Slices that fit an XCD's L2 pay from ~12 edges per (row, slice) piece (16 until the
-    // regret test of round 4: a scrambled community graph of 105 edges per row runs 7 % faster with 8 slices of 13 edges
-    // per piece than with 4; tests/test_regret_gpu.py, profiles/r4/regret_table.log) -- every
+    // regret test of round 4: a scrambled community graph of 105 edges per row runs 7 % faster at D = 64 with 8 slices of 13
+    // edges per piece than with 4 -- and 10 % SLOWER at D = 32, where a row is one line: 24 there; tests/test_regret_gpu.py,
+    // profiles/r4/regret_table.log) -- every
     // piece costs a flush of the row: Reddit-like shards of a 2- / 4- / 8-GPU job (246 / 369 / 430 remote edges per
     // row, X = 119 / 238 / 477 MB) run fastest with 12-16 / 16 / 16 slices (15-27 edges per piece).  Slices that
     // only fit the 256 MiB Infinity Cache still pay from ~8 edges per piece, because a miss there goes to HBM:
@@ -390,7 +391,9 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
     int levels = 0;                               // cells[l] <-> S >> l slices, l = 0 .. levels - 1 (down to 2 slices)
     for (int t = S; t > 1; t >>= 1) levels++;
     levels = std::min(levels, kSliceLevels);
-    while (b > 1 && lvl < levels && piece(lvl) < 12.0) { b >>= 1; lvl++; }
+    // (a row of one 128-byte line saves half as much per avoided miss as a two-line row, at the same cost per piece)
+    const double min_piece = row_bytes_all <= 128.0 ? 24.0 : 12.0;
+    while (b > 1 && lvl < levels && piece(lvl) < min_piece) { b >>= 1; lvl++; }
     if (lvl >= levels) b = 1;
     const size_t mall = (size_t)250000000;   // (of 256 MiB; products-like D = 100: four slices of 245 MB, 7.0 ms against 7.8 with two)
     if (x_bytes > mall) {
@@ -409,7 +412,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
                const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
                const int32_t *part2Node, float *out, int64_t ld_out, int64_t num_nodes, int dim, int64_t num_parts,
                int partSize, int dimWorker, int warpPerBlock, void *stream_v, unsigned flags,
-               int num_windows = 1, int win_begin = 0, int win_end = 1, bool profiled = true);
+               int num_windows = 1, int win_begin = 0, int win_end = 1, bool profiled = true, int hint_dim = 0);
 
 // Wide rows in column blocks.  A row of 256 floats is eight 128-byte lines: the lines a source slice touches stop
 // fitting an XCD's L2 long before the slicing rule runs out of phases (>= 16 edges per (row, slice) piece), and rows wider
@@ -440,7 +443,7 @@ int launch_agg_blocked(int nb, int mode, const float *input, int64_t ld_in, int6
         const int wb = std::min(w, dim - c0);
         const int rc = launch_agg(mode, input + c0, ld_in, num_in_rows, column_index, degrees, degrees_in, epsilon, part_pointers,
                                   part2Node, out + c0, ld_out, num_nodes, wb, num_parts, partSize, dimWorker, warpPerBlock, stream_v,
-                                  flags, 1, 0, 1, /*profiled=*/false);
+                                  flags, 1, 0, 1, /*profiled=*/false, /*hint_dim=*/dim);
         if (rc != GNNA_OK) return rc;
         launches += t_last_launches;
         phases = std::max(phases, t_last_phases);
@@ -455,7 +458,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
                const float *degrees, const float *degrees_in, float epsilon, const int32_t *part_pointers,
                const int32_t *part2Node, float *out, int64_t ld_out, int64_t num_nodes, int dim, int64_t num_parts,
                int partSize, int dimWorker, int warpPerBlock, void *stream_v, unsigned flags,
-               int num_windows, int win_begin, int win_end, bool profiled)
+               int num_windows, int win_begin, int win_end, bool profiled, int hint_dim)
 {
     const bool accumulate_into_out = (flags & GNNA_ACCUMULATE) != 0;
     const bool relu = (flags & GNNA_EPILOGUE_RELU) != 0;
@@ -494,7 +497,8 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
 
     gnna_tuning tune;
     gnna_get_tuning(&tune);
-    apply_graph_hints(column_index, dim, &tune);
+    // (a column block of a wide row: a schedule measured for the whole width -- gnna_set_graph_phases -- is the blocks')
+    apply_graph_hints(column_index, hint_dim > 0 ? hint_dim : dim, &tune);
 
     const bool windowed = num_windows > 1;
     if (profiled && !windowed && num_parts > 0) {

@@ -125,7 +125,7 @@ def test_unprepared_graphs_back_off_when_no_partition_is_seen_twice():
         pytest.skip("GNNA_TUNE forces the schedule")
     _lib.release_graph(None)
     g = graph.make_config_graph("reddit-like", device="cuda", scale=0.06)
-    X = torch.randn(g.num_nodes, 256, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+    X = torch.randn(g.num_nodes, 128, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))   # (7 MB: worth slicing)
     pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
     before = _lib.runtime_counters()
     keep = []

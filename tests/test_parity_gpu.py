@@ -325,7 +325,7 @@ def _check_full_size(g, X, y, rows, what):
 
 
 def test_full_size_reddit_like_through_the_auto_path():
-    """BASELINE config 3 exactly as bench.py times it: Decider in auto mode (partSize 64, scheduler knobs), the
+    """BASELINE config 3 exactly as bench.py times it: Decider in auto mode (partSize 128, scheduler knobs), the
     library's own sliced schedule (several phases, one launch).  X = ones -> exact row nnz; sampled rows of a
     randn aggregation vs fp64; and the drop-in call sequence (no Decider, no hints) takes the same schedule."""
     if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
@@ -344,7 +344,7 @@ def test_full_size_reddit_like_through_the_auto_path():
     try:
         info.apply_tuning()
         ps = info.partSize
-        assert ps == 64
+        assert ps == 128                       # rows of ~490 edges (round 4: 64 until then)
         pp, p2n = _lib.build_part(ps, g.row_pointers.cpu())
         ppd, p2nd = pp.cuda(), p2n.cuda()
         run = lambda x: _lib.sag(x, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, ps, 32, 4)
