@@ -415,16 +415,22 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
                int num_windows = 1, int win_begin = 0, int win_end = 1, bool profiled = true, int hint_dim = 0);
 
 // Wide rows in column blocks.  A row of 256 floats is eight 128-byte lines: the lines a source slice touches stop
-// fitting an XCD's L2 long before the slicing rule runs out of phases (>= 16 edges per (row, slice) piece), and rows wider
-// than 128 floats leave the sweep kernel's accumulators.  A 64-float column block of the same rows is the well-behaved
-// two-line case again, so when every source row is gathered many times and the matrix is Infinity-Cache sized the call is
-// split into ceil(dim / 64) calls over column blocks of `input` and `out` (leading dimensions: the blocks are aggregated in
-// place; the ids are re-read per block, which is cheap).  Measured, Reddit-like D = 256: DESIGN.md 3.1.
+// fitting an XCD's L2 long before the slicing rule runs out of phases, and rows wider than 128 floats leave the sweep
+// kernel's accumulators.  A 64-float column block of the same rows is the well-behaved two-line case again, so when every
+// source row is gathered many times and the matrix is Infinity-Cache sized the call is split into ceil(dim / 64) calls over
+// column blocks of `input` and `out` (leading dimensions: the blocks are aggregated in place; the ids are re-read per block,
+// which is cheap).  Measured on the Reddit-like graph (prepared, partSize 128; tools/probe_blocks.py, profiles/r4/): D = 100 /
+// 128 / 160 / 192 / 256: 2.98 / 3.16 / 4.58 / 5.34 / 7.25 -> 2.76 / 2.88 / 4.12 / 4.13 / 5.45 ms; D = 96 loses (2.39 -> 2.72).
+// From 100 floats on when the rows are long enough that the blocks run on the sweep kernel (>= ~200 edges per row by the
+// launcher's estimate), from 192 floats on otherwise (a graph of 198-edge rows ties at D = 128).
 int column_blocks(const gnna_tuning &tune, int dim, int64_t num_in_rows, int64_t est_edges)
 {
-    if (tune.wide_blocks == 2 || dim < (tune.wide_blocks == 1 ? 72 : 192)) return 1;
+    if (tune.wide_blocks == 2 || dim < 72) return 1;
+    if (tune.wide_blocks == 1) return (dim + 63) / 64;
     const bool hot = est_edges >= 32 * num_in_rows;
-    if (tune.wide_blocks == 0 && (!hot || (size_t)num_in_rows * (size_t)dim * sizeof(float) > ((size_t)250000000))) return 1;
+    if (!hot || (size_t)num_in_rows * (size_t)dim * sizeof(float) > ((size_t)250000000)) return 1;
+    const bool long_rows = est_edges >= 200 * num_in_rows;
+    if (dim < (long_rows ? 100 : 192)) return 1;
     return (dim + 63) / 64;
 }
 

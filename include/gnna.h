@@ -302,9 +302,9 @@ typedef struct gnna_tuning {
                              rewritten in place while the library holds a plan for it (the reference's own call sequence
                              never does; without the promise a stale copy would give wrong results, which is why it is
                              not the default) */
-    int wide_blocks;      /* rows of >= 192 floats in 64-float column blocks (one call per block, leading dimensions): 0 = automatic
-                             (when every source row is gathered >= ~32 times and the matrix is Infinity-Cache sized), 1 = whenever
-                             dim >= 72, 2 = never */
+    int wide_blocks;      /* wide rows in 64-float column blocks (one call per block, leading dimensions): 0 = automatic (rows of
+                             >= 100 floats of long-row graphs, >= 192 otherwise, when every source row is gathered >= ~32 times
+                             and the matrix is Infinity-Cache sized), 1 = whenever dim >= 72, 2 = never */
 } gnna_tuning;
 
 GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
