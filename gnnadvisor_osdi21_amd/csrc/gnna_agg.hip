@@ -865,11 +865,21 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
     gnna_get_tuning(&tune);
     const bool hot = plan.stats.edges >= 32.0 * (double)num_in_rows;
     size_t staged = 0, det_bytes = 0;
+    // a width that will run in column blocks (column_blocks) is prepared as the blocks' widths: (full width, block width) pairs
+    std::vector<std::pair<int, int>> widths;     // (index into dims / phases_out, width the kernels will see)
     for (int i = 0; i < num_dims; i++) {
-        const int dim = dims[i];
-        if (dim <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_prepare_graph: dims[%d] = %d", i, dim);
+        if (dims[i] <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_prepare_graph: dims[%d] = %d", i, dims[i]);
+        const int nb = column_blocks(tune, dims[i], num_in_rows, (int64_t)plan.stats.edges);
+        if (nb <= 1) { widths.emplace_back(i, dims[i]); continue; }
+        const int w = ((dims[i] + nb - 1) / nb + 3) / 4 * 4;
+        widths.emplace_back(i, w);
+        if (dims[i] % w) widths.emplace_back(i, dims[i] % w);
+    }
+    for (const auto &wd : widths) {
+        const int i = wd.first;
+        const int dim = wd.second;
         gnna_tuning t = tune;
-        apply_graph_hints(column_index, dim, &t);
+        apply_graph_hints(column_index, dims[i], &t);
         const size_t raw = (size_t)num_in_rows * (size_t)dim * sizeof(float);
         const bool hot_rows = hot && raw <= ((size_t)1 << 30);
         const int ldx = pick_row_stride(t, dim, hot_rows, num_in_rows, true);

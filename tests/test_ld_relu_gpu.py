@@ -212,3 +212,37 @@ def test_relu_layers_of_the_op_layer_match_the_unfused_ones():
         for a, b, name in zip(res[0], res[1], ("out", "dX", "dW")):
             tol = 1e-4 * max(1.0, float(a.abs().max()))
             assert float((a - b).abs().max()) <= tol, (name, fin, fout, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("dim", [72, 100, 130, 200, 300])
+def test_automatic_column_blocks_give_the_same_results(dim):
+    """gnna_tuning.wide_blocks = 1: every call of >= 72 floats is split into 64-float column blocks of `input` and `out`
+    (what the library does by itself for hot, Infinity-Cache-sized matrices of wide rows): all modes, accumulate + ReLU,
+    prepared and not, against the oracle."""
+    g, Xc, ppc, p2nc = make_case(3000, 200000, dim, 32, seed=dim, kind="powerlaw")
+    rp, ci, deg, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), Xc.numpy()
+    X, rpd, cid, degd, pp, p2n = dev(Xc, g.row_pointers, g.column_index, g.degrees, ppc, p2nc)
+    n = g.num_nodes
+    try:
+        for prepared in (False, True):
+            _lib.reset_tuning()
+            _lib.set_tuning(wide_blocks=1, column_phases=3 if prepared else 0)
+            if prepared:
+                _lib.prepare_graph(cid, pp, p2n, n, n, 32, [dim])
+            for mode, eps, fn in ((0, 1.0, lambda: _lib.sag(X, rpd, cid, degd, pp, p2n, 32, 32, 4)),
+                                  (1, 1.0, lambda: _lib.agg_gcn(X, rpd, cid, degd, pp, p2n, 32, 32, 4)),
+                                  (2, 0.5, lambda: _lib.agg_gin(X, rpd, cid, 0.5, pp, p2n, 32, 32, 4))):
+                y = fn()
+                assert _lib.last_num_launches() >= (dim + 63) // 64
+                assert_close_f64(y.cpu().numpy(), oracle.csr_f64(mode, Xn, rp, ci, deg, eps), what=f"blocks D={dim} mode={mode} prepared={prepared}",
+                                 scale=oracle.csr_f64(mode, np.abs(Xn), rp, ci, deg, eps))
+            base = torch.randn(n, dim, generator=torch.Generator().manual_seed(2))
+            out = base.clone().cuda()
+            _lib.agg_ld(0, X, cid, pp, p2n, n, 32, out=out, accumulate=True, relu=True)
+            ref = np.maximum(oracle.csr_f64(0, Xn, rp, ci) + base.double().numpy(), 0.0)
+            assert_close_f64(out.cpu().numpy(), ref, what=f"blocks + accumulate + relu D={dim}",
+                             scale=oracle.csr_f64(0, np.abs(Xn), rp, ci) + np.abs(base.numpy()))
+            if prepared:
+                _lib.release_graph(cid)
+    finally:
+        _lib.reset_tuning()
