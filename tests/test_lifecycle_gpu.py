@@ -129,10 +129,14 @@ def test_unprepared_graphs_back_off_when_no_partition_is_seen_twice():
     pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
     before = _lib.runtime_counters()
     keep = []
-    for i in range(60):
-        ci = g.column_index.clone()                                      # a fresh address every step
-        keep.append(ci)
-        y = _lib.sag(X, g.row_pointers, ci, g.degrees, pp.cuda(), p2n.cuda(), 64, 32, 4)
+    _lib.set_tuning(wide_blocks=2)                 # (one call per aggregation: this test is about the plan cache)
+    try:
+        for i in range(60):
+            ci = g.column_index.clone()                                      # a fresh address every step
+            keep.append(ci)
+            y = _lib.sag(X, g.row_pointers, ci, g.degrees, pp.cuda(), p2n.cuda(), 64, 32, 4)
+    finally:
+        _lib.reset_tuning()
     after = _lib.runtime_counters()
     assert after["backoff_skips"] > before["backoff_skips"], (before, after)
     assert after["plan_builds"] - before["plan_builds"] < 60
