@@ -130,8 +130,9 @@ def test_sweep_reads_the_packed_ids_of_a_prepared_graph(dim, ps, phases):
 
 def test_the_library_picks_the_sweep_kernel_only_where_it_wins():
     """gnna_tuning.sweep = 0: rows of 33-64 floats, a sliced schedule over a square problem with long rows (>= 300 edges)
-    that fit the accumulators in two sets -> sweep_kernel; wider / narrower rows, short rows, rectangular problems and
-    sweep = 2 -> stream_kernel.  Both give the oracle's result."""
+    that fit the accumulators in two sets -> sweep_kernel; narrower rows, short rows, rectangular problems and sweep = 2
+    -> stream_kernel.  Wide rows of such a graph run in 64-float column blocks (round 4), each of which is a sweep call;
+    with the blocks switched off they stay on stream_kernel.  All give the oracle's result."""
     g = graph.powerlaw_graph(80000, 32000000, 8000, seed=5, device="cuda")           # ~400 edges per row, X = 20 MB at D = 64
     n = g.num_nodes
     pp, p2n = _lib.build_part(64, g.row_pointers.cpu())
@@ -146,9 +147,10 @@ def test_the_library_picks_the_sweep_kernel_only_where_it_wins():
         return _lib.runtime_counters()["sweep_launches"] - before, y
 
     try:
-        for dim, swept in ((64, 1), (41, 1), (32, 0), (128, 0)):
+        for dim, swept, blocks in ((64, 1, 0), (41, 1, 0), (32, 0, 0), (128, 2, 0), (128, 0, 2)):
             X = torch.randn(n, dim, generator=torch.Generator().manual_seed(dim))
             Xd = X.cuda()
+            _lib.set_tuning(wide_blocks=blocks)
             k, y = launches(lambda: _lib.sag(Xd, g.row_pointers, g.column_index, g.degrees, ppd, p2nd, 64, 32, 4))
             assert k == swept, (dim, k, _lib.last_num_phases())
             assert _lib.last_num_phases() >= 2
