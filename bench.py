@@ -64,6 +64,35 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL ac
 os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: pinned OpenMP threads (before libgomp starts)
 os.environ.setdefault("OMP_PLACES", "cores")
 
+
+def cpu_quota_cores():
+    """CPUs this container may use per scheduling period (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited.
+    The GPU boxes show 256 hardware threads but grant 16 CPUs: 128 OpenMP threads burn that in 12.5 ms of every 100 ms period
+    and are throttled for the rest -- the "bimodal" ~100 / ~200 ms passes of rounds 1-3 were whole throttle periods
+    (tools/probe_cpu_baseline.py, profiles/r4/cpu_baseline_probe.log)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            return float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = float(f.read())
+        if quota > 0:
+            return quota / period
+    except Exception:
+        pass
+    return None
+
+
+_QUOTA = cpu_quota_cores()
+if _QUOTA and _QUOTA < (os.cpu_count() or 1):
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, int(_QUOTA))))   # as many threads as the container is granted
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -710,9 +739,9 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
         times.append(time.perf_counter() - t0)
     order = list(times)
     times.sort()
-    # the passes on this host fall into two modes (every other pass ~1.8x slower, see pass_ms_in_order; cause not
-    # diagnosed -- thread / NUMA placement of 128 pinned threads is the suspect): `value` is the median of ALL passes, the
-    # median of the faster half (the typical undisturbed pass) rides beside it as value_best_half
+    # (rounds 1-3 ran 128 threads against a 16-CPU container quota and measured throttle periods -- passes of ~100 / ~200 ms;
+    # with as many threads as the quota grants the passes are steady.)  `value` is the median of ALL passes, the median of
+    # the faster half rides beside it as value_best_half
     med = times[len(times) // 2]
     best_half = times[len(times) // 4]
     # scalar port of the reference algorithm on ~1/16 of the groups
@@ -726,8 +755,10 @@ def cpu_baseline(g_cpu, X_cpu, pp, p2n, dim):
     e1 = int(ppn[g_end] - ppn[0])
     return {
         "value": nnz / med, "unit": "edges/s", "cores": threads, "kind": "port",
+        "cpu_quota_cores": _QUOTA, "host_hardware_threads": os.cpu_count(),
         "sample": f"full graph ({nnz} edges, D={dim}), median of all {len(times)} passes of the OpenMP "
-                  f"row-parallel fp32 CSR SpMM in oracle/gnna_oracle.c (threads pinned, NUMA first-touch)",
+                  f"row-parallel fp32 CSR SpMM in oracle/gnna_oracle.c ({threads} threads pinned"
+                  + (f" = the container's CPU quota of {_QUOTA:g}" if _QUOTA else "") + ", NUMA first-touch)",
         "value_best_half": nnz / best_half, "ms_best_half": best_half * 1e3,
         "ms_median_all_passes": times[len(times) // 2] * 1e3,
         "ms": med * 1e3, "ms_min": times[0] * 1e3, "ms_max": times[-1] * 1e3,
