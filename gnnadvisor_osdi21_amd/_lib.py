@@ -27,7 +27,7 @@ class Tuning(ctypes.Structure):
                 ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
                 ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int),
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
-                ("pad_rows", ctypes.c_int), ("stream_kernel", ctypes.c_int), ("zero_fill", ctypes.c_int),
+                ("pad_rows", ctypes.c_int), ("zero_fill", ctypes.c_int),
                 ("sweep", ctypes.c_int), ("sweep_slack", ctypes.c_int), ("deterministic", ctypes.c_int),
                 ("pack_ids", ctypes.c_int), ("wide_blocks", ctypes.c_int)]
 
@@ -157,10 +157,10 @@ def _stream(device: torch.device) -> int:
 
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
-               pad_rows=-1, stream_kernel=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1,
+               pad_rows=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1,
                wide_blocks=-1) -> None:
     t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
-               avg_degree, nonlocal_ids, gcn_prescale, pad_rows, stream_kernel, zero_fill, sweep, sweep_slack, deterministic,
+               avg_degree, nonlocal_ids, gcn_prescale, pad_rows, zero_fill, sweep, sweep_slack, deterministic,
                pack_ids, wide_blocks)
     load().gnna_set_tuning(ctypes.byref(t))
 

@@ -26,7 +26,7 @@ thread_local char t_error[512] = "";
 const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*/4,
                                     /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0,
                                     /*column_phases=*/0, /*avg_degree=*/0, /*nonlocal_ids=*/0,
-                                    /*gcn_prescale=*/0, /*pad_rows=*/0, /*stream_kernel=*/0, /*zero_fill=*/0,
+                                    /*gcn_prescale=*/0, /*pad_rows=*/0, /*zero_fill=*/0,
                                     /*sweep=*/0, /*sweep_slack=*/0, /*deterministic=*/0, /*pack_ids=*/0,
                                     /*wide_blocks=*/0};
 gnna_tuning g_tuning = kDefaultTuning;
@@ -69,7 +69,6 @@ void apply_env()
         else if (!std::strcmp(tok, "NONLOCAL")) g_tuning.nonlocal_ids = v;
         else if (!std::strcmp(tok, "PRESCALE")) g_tuning.gcn_prescale = v;
         else if (!std::strcmp(tok, "PAD")) g_tuning.pad_rows = v;
-        else if (!std::strcmp(tok, "STREAM")) g_tuning.stream_kernel = v;
         else if (!std::strcmp(tok, "ZERO")) g_tuning.zero_fill = v;
         else if (!std::strcmp(tok, "SWEEP")) g_tuning.sweep = v;
         else if (!std::strcmp(tok, "SLACK")) g_tuning.sweep_slack = v;
@@ -152,7 +151,6 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->nonlocal_ids >= 0) g_tuning.nonlocal_ids = t->nonlocal_ids;
     if (t->gcn_prescale >= 0) g_tuning.gcn_prescale = t->gcn_prescale;
     if (t->pad_rows >= 0) g_tuning.pad_rows = t->pad_rows;
-    if (t->stream_kernel >= 0) g_tuning.stream_kernel = t->stream_kernel;
     if (t->zero_fill >= 0) g_tuning.zero_fill = t->zero_fill;
     if (t->sweep >= 0) g_tuning.sweep = t->sweep;
     if (t->sweep_slack >= 0) g_tuning.sweep_slack = t->sweep_slack;

@@ -267,8 +267,6 @@ typedef struct gnna_tuning {
                              multiples of twice their 128-byte lines -- stride 64 / 128 / 128 floats for
                              32 / 41 / 64 -- while the copy stays Infinity-Cache sized: 2-6 % off the
                              gather), > 2 = this stride in floats (experiments) */
-    int stream_kernel;    /* reserved (ignored): selected round 1's chunk-walk kernel, retired in 0.4.0 -- the streaming
-                             kernel runs every width and the windowed entry now; kept so that the struct's layout stays */
     int zero_fill;        /* what the prologue clears before a single pass of the streaming kernel that overwrites
                              `out`: 1 = only the rows that pass does not store (rows without edges, rows shared by
                              two work items), 2 = the whole output, 0 = automatic (1 once `out` is >= 32 MiB).

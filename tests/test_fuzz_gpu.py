@@ -20,8 +20,7 @@ DIMS = [1, 3, 4, 6, 16, 31, 64, 100, 129, 256, 257, 300]
 def _rand_tuning(rng):
     _lib.set_tuning(int(rng.integers(1, 65)), int(rng.choice([4, 8, 16])), int(rng.choice([0, 0, 2])),
                     int(rng.integers(0, 2)), 0, int(rng.choice([1, 1, 2, 3, 7, 16, 32])), gcn_prescale=int(rng.choice([0, 1, 2])),
-                    pad_rows=int(rng.choice([0, 1, 2])), stream_kernel=int(rng.choice([0, 0, 2])),
-                    zero_fill=int(rng.choice([0, 1, 1, 2])), sweep=int(rng.choice([0, 0, 1])),
+                    pad_rows=int(rng.choice([0, 1, 2])), zero_fill=int(rng.choice([0, 1, 1, 2])), sweep=int(rng.choice([0, 0, 1])),
                     sweep_slack=int(rng.choice([0, 1, 1000])), deterministic=int(rng.choice([0, 0, 1])))
 
 

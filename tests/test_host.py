@@ -112,7 +112,7 @@ def test_tuning_roundtrip():
         _lib.set_tuning(8, 4, 2, 0, 1)
         assert _lib.get_tuning() == dict(groups_per_chunk=8, loads_in_flight=4, blocks_per_cu=2,
                                          xcd_remap=0, trust_canonical=1, column_phases=0, avg_degree=0,
-                                         nonlocal_ids=0, gcn_prescale=0, pad_rows=0, stream_kernel=0, zero_fill=0,
+                                         nonlocal_ids=0, gcn_prescale=0, pad_rows=0, zero_fill=0,
                                          sweep=0, sweep_slack=0, deterministic=0, pack_ids=0, wide_blocks=0)
         _lib.set_tuning(column_phases=8)
         assert _lib.get_tuning()["column_phases"] == 8

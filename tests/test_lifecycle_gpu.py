@@ -50,7 +50,7 @@ def test_prepare_makes_the_launch_path_silent_and_capture_takes_the_sliced_sched
     """After gnna_prepare_graph no aggregation on that graph synchronises, allocates or frees, the phase count it
     reports is the one the calls use, and a call INSIDE a stream capture takes the sliced schedule (it used to
     degrade to a single pass when the plan was missing)."""
-    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+    if _lib.get_tuning()["column_phases"] != 0:
         pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
     g, X, ppd, p2nd = _big_case()
     out = torch.empty_like(X)
@@ -121,7 +121,7 @@ def test_forty_prepared_graphs_cycle_without_a_free_on_the_launch_path():
 def test_unprepared_graphs_back_off_when_no_partition_is_seen_twice():
     """Automatic plans: a stream of partitions that are each used once (tensors re-allocated per step) stops paying a
     counting pass and a synchronisation per call after a streak of unused evictions; results stay correct."""
-    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+    if _lib.get_tuning()["column_phases"] != 0:
         pytest.skip("GNNA_TUNE forces the schedule")
     _lib.release_graph(None)
     g = graph.make_config_graph("reddit-like", device="cuda", scale=0.06)
@@ -156,7 +156,7 @@ def test_deterministic_schedule_is_bit_reproducible(dim, phases, prescale):
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     rpn, cin, degn, Xn = g.row_pointers.numpy(), g.column_index.numpy(), g.degrees.numpy(), X.numpy()
     try:
-        _lib.set_tuning(deterministic=1, column_phases=phases, gcn_prescale=prescale, stream_kernel=0)
+        _lib.set_tuning(deterministic=1, column_phases=phases, gcn_prescale=prescale)
         runs = []
         for rep in range(4):
             ys = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)

@@ -36,7 +36,7 @@ def test_packed_ids_match_the_oracle(dim, phases, ps, gpc):
     g, X, pp, p2n = make_case(3000, 200000, dim, ps, seed=dim * 3 + phases, kind="powerlaw")
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     _lib.reset_tuning()
-    _lib.set_tuning(column_phases=phases, groups_per_chunk=gpc, deterministic=0, sweep=0, stream_kernel=0, wide_blocks=2)
+    _lib.set_tuning(column_phases=phases, groups_per_chunk=gpc, deterministic=0, sweep=0, wide_blocks=2)
     try:
         for prescale in (1, 2):        # pre-scaled and per-edge GCN forms
             _lib.set_tuning(gcn_prescale=prescale)

@@ -328,7 +328,7 @@ def test_full_size_reddit_like_through_the_auto_path():
     """BASELINE config 3 exactly as bench.py times it: Decider in auto mode (partSize 128, scheduler knobs), the
     library's own sliced schedule (several phases, one launch).  X = ones -> exact row nnz; sampled rows of a
     randn aggregation vs fp64; and the drop-in call sequence (no Decider, no hints) takes the same schedule."""
-    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+    if _lib.get_tuning()["column_phases"] != 0:
         pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
     from gnnadvisor_osdi21_amd.decider import inputProperty
     g = graph.make_config_graph("reddit-like", device="cuda")
@@ -527,7 +527,7 @@ def test_sliced_schedule_is_chosen_from_the_partition_itself():
     library counts, once per graph, how the column ids of the neighbor-groups spread over 16 source slices and
     picks the number of phases itself: several for a randomly labelled high-degree graph, one when the rows
     are already local (community order), one when the rows are too short to be worth slicing."""
-    if _lib.get_tuning()["column_phases"] != 0 or _lib.get_tuning()["stream_kernel"] == 2:
+    if _lib.get_tuning()["column_phases"] != 0:
         pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
     seen = {}
     for name, D, g in (("random", 256, graph.make_config_graph("reddit-like", device="cuda", scale=0.25)),
@@ -561,7 +561,7 @@ def test_stale_slice_plan_costs_locality_not_correctness():
     for forced in (8, 32):
       ci.copy_(g.column_index)
       try:
-        _lib.set_tuning(column_phases=forced, stream_kernel=0)
+        _lib.set_tuning(column_phases=forced)
         y0 = _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 16, 32, 4)
         assert _lib.last_num_phases() == forced
         assert_close_f64(y0.cpu().numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy()),

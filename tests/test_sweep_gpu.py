@@ -21,7 +21,7 @@ class sweep_forced:
 
     def __init__(self, phases, rounds=0, slack=0, wgs=0, dynamic=1, **kw):
         # wgs: workgroups per CU (1: 16 wavefronts with all of the CU's LDS, 2: 32 wavefronts, half the rows each)
-        self.kw = dict(column_phases=phases, sweep=1, sweep_slack=slack, blocks_per_cu=wgs, deterministic=0, stream_kernel=0, xcd_remap=dynamic, **kw)
+        self.kw = dict(column_phases=phases, sweep=1, sweep_slack=slack, blocks_per_cu=wgs, deterministic=0, xcd_remap=dynamic, **kw)
         if rounds:
             self.kw["groups_per_chunk"] = 64 * rounds
 
@@ -244,7 +244,7 @@ def test_sweep_in_a_captured_graph_after_prepare():
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     out = torch.empty_like(Xd)
     _lib.reset_tuning()
-    _lib.set_tuning(sweep=1, column_phases=8, deterministic=0, stream_kernel=0)
+    _lib.set_tuning(sweep=1, column_phases=8, deterministic=0)
     try:
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
