@@ -82,6 +82,16 @@ def test_the_automatic_schedule_is_within_7_percent_of_the_best_forced_one():
                 _lib.reset_tuning()
             best_tag = min(forced, key=forced.get)
             regret = auto_ms / forced[best_tag] - 1.0
+            if regret > 0.05:
+                # a timing test must not fail on one noisy sample: measure the two contenders again, longer
+                try:
+                    _lib.set_tuning(pack_ids=2)
+                    auto_ms = min(auto_ms, _time_ms(run, reps=30, rounds=4))
+                    _lib.set_tuning(pack_ids=2, **dict(FORCED)[best_tag])
+                    forced[best_tag] = min(forced[best_tag], _time_ms(run, reps=30, rounds=4))
+                finally:
+                    _lib.reset_tuning()
+                regret = auto_ms / forced[best_tag] - 1.0
             lines.append(f"{name:28s} N={g.num_nodes:8d} nnz={g.nnz:10d} D={D:3d} ps={ps:2d} | auto {auto_kernel}-{auto_phases:<2d} "
                          f"{auto_ms:7.3f} ms | best {best_tag:9s} {forced[best_tag]:7.3f} ms | regret {100 * regret:+5.1f} % | "
                          + " ".join(f"{k}={v:.3f}" for k, v in forced.items()))
