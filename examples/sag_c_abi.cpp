@@ -83,6 +83,33 @@ int main()
             }
         }
     }
+    {
+        // the general entry (0.4.0): rows written with the leading dimension the library prefers for this gather, the
+        // result clamped at zero in the same call -- relu(A X) into a buffer whose rows are 2 * dim floats apart
+        const int64_t ld_in = gnna_preferred_ld(dim, n, nnz), ld_out = 2 * dim;
+        std::vector<float> Xl((size_t)n * ld_in, -7.f), Yl((size_t)n * ld_out, -9.f);
+        for (int64_t i = 0; i < n; i++)
+            for (int d = 0; d < dim; d++) Xl[(size_t)i * ld_in + d] = X[(size_t)i * dim + d];
+        float *dXl = to_device(Xl), *dYl = to_device(Yl);
+        GNNA_OK_OR_DIE(gnna_agg_ld_f32(0, dXl, ld_in, n, dCi, nullptr, nullptr, 1.f, dPp, dP2n, dYl, ld_out, n, dim, P, part_size,
+                                       GNNA_EPILOGUE_RELU, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpy(Yl.data(), dYl, Yl.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; i++) {
+            for (int d = 0; d < dim; d++) {
+                double ref = 0.0, scale = 0.0;
+                for (int32_t e = rp[i]; e < rp[i + 1]; e++) {
+                    ref += X[(size_t)ci[e] * dim + d];
+                    scale += std::fabs(X[(size_t)ci[e] * dim + d]);
+                }
+                ref = ref > 0.0 ? ref : 0.0;
+                const double err = std::fabs((double)Yl[(size_t)i * ld_out + d] - ref) / (scale > 1.0 ? scale : 1.0);
+                if (err > worst) worst = err;
+            }
+            for (int d = dim; d < ld_out; d++)
+                if (Yl[(size_t)i * ld_out + d] != -9.f) { std::printf("gnna_agg_ld_f32 wrote between the output rows\n"); return 1; }
+        }
+    }
     std::printf("libgnna %d: n=%lld nnz=%lld groups=%lld dim=%d  max err / scale = %.3e\n", gnna_version(),
                 (long long)n, (long long)nnz, (long long)P, dim, worst);
     if (!(worst <= 1e-4)) { std::printf("MISMATCH\n"); return 1; }
