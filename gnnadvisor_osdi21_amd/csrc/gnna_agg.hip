@@ -897,16 +897,17 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
         if (phases_out) phases_out[i] = std::max(1, B);
         if (B >= 2 && t.pack_ids != 2 && plan.handle) {   // (the plan is pinned here)
             const int32_t *ids = nullptr; const uint32_t *off = nullptr;
-            // the kernel that will run at this width: the sweep (its own phase count, 64 groups per chunk) or the streaming kernel
-            const int mode_guess = t.gcn_prescale == 2 ? MODE_GCN : MODE_SAG;
-            int Bs = sweep_auto_phases(t, mode_guess, dim, foot_bytes, num_out_rows, num_in_rows, plan.stats.edges, B, ds->num_cus,
+            // the kernel that will run at this width: the sweep (its own phase count, 64 groups per chunk) for the unweighted
+            // and pre-scaled calls where the library picks it, the streaming kernel for everything else -- and for the
+            // per-edge GCN form (gcn_prescale = 2) at any width, which the sweep does not run
+            int Bs = sweep_auto_phases(t, MODE_SAG, dim, foot_bytes, num_out_rows, num_in_rows, plan.stats.edges, B, ds->num_cus,
                                        t.deterministic == 1, partSize);
-            if (t.sweep == 1 && t.deterministic != 1 && sweep_supports(mode_guess, dim, x_bytes))
+            if (t.sweep == 1 && t.deterministic != 1 && sweep_supports(MODE_SAG, dim, x_bytes))
                 Bs = t.column_phases >= 2 ? B : std::max(2, std::min(std::min(16, 2 * B), std::max(2, partSize / 4)));
             Bs = std::min(Bs, plan.S);
-            if (Bs >= 2 && t.xcd_remap != 0)
-                rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, true, &ids, &off);
-            else
+            const bool swept = Bs >= 2 && t.xcd_remap != 0;
+            if (swept) rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, true, &ids, &off);
+            if (rc == GNNA_OK && (!swept || t.gcn_prescale == 2))
                 rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
             if (rc != GNNA_OK) return rc;
             if (phases_out && Bs >= 2) phases_out[i] = Bs;

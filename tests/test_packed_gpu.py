@@ -78,6 +78,8 @@ def test_more_phase_counts_than_copies_and_release():
     """Four copies per graph: a fifth phase count in turn with the others gets none (a copy in recent use is not replaced:
     no build storm) and reads column_index; once the others have gone unused for a while it takes the oldest one's place;
     after the release the ids are read from column_index again."""
+    if _lib.get_tuning()["pack_ids"] != 0:
+        pytest.skip("GNNA_TUNE changes the packing policy: the copy bookkeeping is not under test")
     g, X, pp, p2n = make_case(4000, 300000, 64, 16, seed=9, kind="powerlaw")
     Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
     ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
