@@ -548,7 +548,7 @@ def run_pmc_pass(counters, specs, args, workdir):
         child.append("--manual")
     if args.no_prepare:
         child.append("--no-prepare")
-    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "agg_kernel|stream_kernel|sweep_kernel|copyBuffer", "-T",
+    cmd = ["rocprofv3", "--pmc", *counters, "--kernel-include-regex", "stream_kernel|sweep_kernel|copyBuffer", "-T",
            "-d", outdir, "-o", "pmc", "-f", "csv", "--", *child]
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
@@ -565,7 +565,7 @@ def run_pmc_pass(counters, specs, args, workdir):
 def split_counters(manifest, rows, counter):
     """-> ([per-step sum of `counter` over the aggregation launches, per workload], copy-kernel values)"""
     agg = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter
-           and any(k in r["Kernel_Name"] for k in ("agg_kernel", "stream_kernel", "sweep_kernel"))]
+           and any(k in r["Kernel_Name"] for k in ("stream_kernel", "sweep_kernel"))]
     cp = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == counter and "copyBuffer" in r["Kernel_Name"]]
     cp = cp[-manifest["calib_copies"]:]      # the calibration copies are the child's last dispatches (earlier
     #                                          copyBuffer dispatches are small host-to-device transfers)
@@ -631,7 +631,7 @@ def kernel_label(w):
         return f"stream_kernel x {calls} library calls per step (local part + remote pieces)"
     if w.launches == 1:
         return "stream_kernel (sliced schedule, one launch)" if w.phases > 1 else "stream_kernel"
-    return "agg_kernel (one launch per column phase)"
+    return f"{w.launches} launches per step (wide rows in 64-float column blocks, or the deterministic schedule's ordered phases)"
 
 
 def binding_shares(fabric_bytes, l2_requests, t_s):

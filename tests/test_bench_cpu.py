@@ -29,7 +29,7 @@ def test_kernel_labels_name_what_ran():
     W.calls = 5
     assert "5 library calls" in bench.kernel_label(W)
     W.calls, W.launches = 1, 4
-    assert "agg_kernel" in bench.kernel_label(W)
+    assert "4 launches" in bench.kernel_label(W)
 
 
 def test_gpus_n_launches_n_ranks_on_localhost(monkeypatch):
@@ -72,7 +72,7 @@ def test_counter_rows_are_split_by_workload_and_calibrated_on_the_last_copies():
         add("stream_kernel", v)
     add("__amd_rocclr_copyBuffer", 9.0)
     for v in (1.0, 1.0, 10.0, 20.0, 10.0, 20.0, 10.0, 20.0):  # workload 1: two launches per step
-        add("agg_kernel", v)
+        add("sweep_kernel", v)
     for _ in range(3):
         add("__amd_rocclr_copyBuffer", 524288.0)              # the 1 GiB calibration copies (KiB, half-counted)
     per_step, copies = bench.split_counters(manifest, rows, "FETCH_SIZE")

@@ -17,7 +17,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   name=$(echo $set | tr ' ' '+' | cut -c1-40)
-  rocprofv3 --pmc $set --kernel-include-regex "agg_kernel|stream_kernel|slice_count_kernel|prologue_kernel|scale_rows_kernel|sweep_kernel" -T -d $OUT/pmc_$name -o pmc -f csv -- $PBENCH > $OUT/pmc_$name.log 2>&1
+  rocprofv3 --pmc $set --kernel-include-regex "stream_kernel|slice_count_kernel|prologue_kernel|scale_rows_kernel|sweep_kernel|relu_fixup" -T -d $OUT/pmc_$name -o pmc -f csv -- $PBENCH > $OUT/pmc_$name.log 2>&1
 done
 # FETCH_SIZE / WRITE_SIZE calibration on a known 1 GiB device copy
 rocprofv3 --pmc FETCH_SIZE -T -d $OUT/calib_fetch -o pmc -f csv -- python $R/tools/calib_copy.py > $OUT/calib_fetch.log 2>&1
