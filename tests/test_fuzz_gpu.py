@@ -147,3 +147,56 @@ def test_weight_gradient_random():
         ref = (X.double().t() @ G.double()).numpy()
         scale = (X.double().abs().t() @ G.double().abs()).numpy()
         assert_close_f64(got, ref, rtol=1e-5, scale=scale, what=f"xtg case {k}: M={M} K={K} N={N}")
+
+
+def test_leading_dimensions_and_flags_random():
+    """gnna_agg_ld_f32: random row strides on both sides (a column block of a wider matrix, a padded buffer, the
+    library's preferred stride), ACCUMULATE and the ReLU epilogue in every combination, column blocks on / off /
+    automatic, with and without the prepared graph.  The gaps between the rows of `out` must come back untouched."""
+    rng = np.random.default_rng(SEED + 4)
+    try:
+        for k in range(CASES):
+            n = int(rng.integers(2, 900)); e = int(rng.integers(0, 40 * n)); D = int(rng.choice(DIMS))
+            ps = int(rng.choice([1, 3, 8, 32, 64, 128])); mode = int(rng.choice([0, 1, 2])); eps = float(rng.uniform(-1, 2))
+            g = graph.uniform_graph(n, e, seed=SEED * 5000 + k)
+            rp, ci = g.row_pointers.numpy(), g.column_index.numpy()
+            gen = torch.Generator().manual_seed(k)
+            X = torch.randn(n, D, generator=gen)
+            acc = bool(rng.integers(0, 2)); relu = bool(rng.integers(0, 2))
+            ld_in = int(rng.choice([D, D + 1, D + 4, 2 * D + 3, _lib.preferred_ld(D, n, e), 4 * ((D + 3) // 4) + 12]))
+            ld_out = int(rng.choice([D, D + 1, D + 7, 2 * D]))
+            off_in = int(rng.integers(0, ld_in - D + 1)); off_out = int(rng.integers(0, ld_out - D + 1))
+            Xw = torch.full((n, ld_in), 1e30)                 # a poisoned wide buffer; the view is columns [off, off + D)
+            Xw[:, off_in:off_in + D] = X
+            Ow = torch.randn(n, ld_out, generator=gen)
+            ref = oracle.csr_f64(mode, X.numpy(), rp, ci, g.degrees.numpy(), eps)
+            scale = oracle.csr_f64(mode, np.abs(X.numpy()), rp, ci, g.degrees.numpy(), abs(eps))
+            prior = Ow[:, off_out:off_out + D].double().numpy()
+            if acc:
+                ref = ref + prior
+                scale = scale + np.abs(prior)
+            if relu:
+                ref = np.maximum(ref, 0.0)
+            pp, p2n = _lib.build_part(ps, g.row_pointers)
+            cid, ppd, p2nd, degd = g.column_index.cuda(), pp.cuda(), p2n.cuda(), g.degrees.cuda()
+            Xd, Od = Xw.cuda(), Ow.cuda()
+            _rand_tuning(rng)
+            _lib.set_tuning(wide_blocks=int(rng.choice([0, 1, 2])))
+            prepared = bool(rng.integers(0, 2)) and p2nd.numel() > 0
+            if prepared:
+                _lib.set_tuning(pack_ids=int(rng.choice([0, 1, 2])))
+                _lib.prepare_graph(cid, ppd, p2nd, n, n, ps, [D] if rng.integers(0, 2) else [])
+            tag = (f"case {k}: n={n} e={e} D={D} ps={ps} mode={mode} ld_in={ld_in}+{off_in} ld_out={ld_out}+{off_out} "
+                   f"acc={acc} relu={relu} prepared={prepared} {_lib.get_tuning()}")
+            for rep in range(2):                               # the second call runs on the cached plan
+                Od.copy_(Ow)
+                _lib.agg_ld(mode, Xd[:, off_in:off_in + D], cid, ppd, p2nd, n, ps, degrees_out=degd, degrees_in=degd,
+                            epsilon=eps, out=Od[:, off_out:off_out + D], accumulate=acc, relu=relu)
+                got = Od.cpu()
+                assert_close_f64(got[:, off_out:off_out + D].numpy(), ref, scale=scale, what=f"rep {rep} " + tag)
+                keep = torch.ones(ld_out, dtype=torch.bool); keep[off_out:off_out + D] = False
+                assert torch.equal(got[:, keep], Ow[:, keep]), "columns outside the view were written: " + tag
+            if prepared:
+                _lib.release_graph(cid)
+    finally:
+        _lib.reset_tuning()
