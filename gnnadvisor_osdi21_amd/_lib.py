@@ -43,7 +43,7 @@ EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_pa
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
-           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
+           "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_sddmm_ld_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
            "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
            "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld")
@@ -120,6 +120,9 @@ def load() -> ctypes.CDLL:
     L.gnna_reorder_community_i32.argtypes = L.gnna_reorder_rcm_i32.argtypes
     L.gnna_last_num_phases.restype = ctypes.c_int
     L.gnna_last_num_launches.restype = ctypes.c_int
+    L.gnna_sddmm_ld_f32.restype = ctypes.c_int
+    L.gnna_sddmm_ld_f32.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64] + [ctypes.c_void_p] * 4 + [
+        ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
     L.gnna_sddmm_f32.restype = ctypes.c_int
     L.gnna_sddmm_f32.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64,
                                                         ctypes.c_int, ctypes.c_void_p]
@@ -525,16 +528,22 @@ def xtg(X, G, out=None):
 
 def sddmm(dst_feat, src_feat, column_index, part_pointers, part2Node, partSize=32, out=None):
     """edge_out[e] = <dst_feat[row(e)], src_feat[column_index[e]]> over the neighbor-group partition
-    (build-defined extension, see include/gnna.h)."""
+    (build-defined extension, see include/gnna.h).  Both feature matrices may be row-strided views (stride(1) == 1):
+    their stride(0) is handed over as the leading dimension (gnna_sddmm_ld_f32)."""
     if not dst_feat.is_cuda:
         raise GnnaError("sddmm needs device tensors: there is no CPU path in libgnna")
-    assert dst_feat.dtype == torch.float32 and src_feat.dtype == torch.float32
-    assert dst_feat.is_contiguous() and src_feat.is_contiguous() and dst_feat.shape[1] == src_feat.shape[1]
+    ap, n_out, dim, ld_dst = _rows_view(dst_feat, "dst_feat")
+    bp, n_in, dim_b, ld_src = _rows_view(src_feat, "src_feat")
+    assert dim == dim_b and dst_feat.device == src_feat.device
     if out is None:
         out = torch.zeros(column_index.numel(), dtype=torch.float32, device=dst_feat.device)
     with torch.cuda.device(dst_feat.device):
-        _check(load().gnna_sddmm_f32(dst_feat.data_ptr(), src_feat.data_ptr(), column_index.data_ptr(),
-                                     part_pointers.data_ptr(), part2Node.data_ptr(), out.data_ptr(),
-                                     dst_feat.shape[0], src_feat.shape[0], dst_feat.shape[1], part2Node.numel(),
-                                     int(partSize), _stream(dst_feat.device)))
+        if ld_dst == dim and ld_src == dim:
+            _check(load().gnna_sddmm_f32(ap, bp, column_index.data_ptr(), part_pointers.data_ptr(), part2Node.data_ptr(),
+                                         out.data_ptr(), n_out, n_in, dim, part2Node.numel(), int(partSize),
+                                         _stream(dst_feat.device)))
+        else:
+            _check(load().gnna_sddmm_ld_f32(ap, ld_dst, bp, ld_src, column_index.data_ptr(), part_pointers.data_ptr(),
+                                            part2Node.data_ptr(), out.data_ptr(), n_out, n_in, dim, part2Node.numel(),
+                                            int(partSize), _stream(dst_feat.device)))
     return out

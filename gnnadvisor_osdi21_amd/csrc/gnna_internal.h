@@ -119,6 +119,7 @@ struct StreamLaunch {
     const int32_t *flag; int32_t seq; int32_t trust;
     int64_t P;
     int D, ldx, G, U, S, B;
+    int lda = 0;                                   // MODE_SDDMM: row stride of A in floats (0: D)
     int ldy = 0;                                   // row stride of Y in floats (0: D)
     int win_lo = 0, win_hi = 0;                    // windowed call: the fine slices (= source windows) it covers; win_hi == S: the rest
     bool relu = false;                             // epilogue: out = max(out, 0)

@@ -21,7 +21,7 @@
 namespace gnna {
 namespace {
 
-int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *column_index,
+int launch_sddmm(const float *dst_feat, int64_t ld_dst, const float *src_feat, int64_t ld_src, const int32_t *column_index,
                  const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
                  int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
                  void *stream_v)
@@ -34,6 +34,9 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
                     (long long)num_out_rows);
     if (num_parts == 0 || dim == 0) return GNNA_OK;
     if (dim < 4) return fail(GNNA_ERR_UNSUPPORTED, "sddmm needs dim >= 4 (got %d)", dim);
+    if (ld_dst < dim || ld_src < dim)
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "leading dimensions (%lld, %lld) must be >= dim (%d)", (long long)ld_dst, (long long)ld_src, dim);
+    if (ld_dst > 0x7fffffff || ld_src > 0x7fffffff) return fail(GNNA_ERR_UNSUPPORTED, "leading dimension beyond 2^31 - 1 floats");
     if (!dst_feat || !src_feat || !column_index || !part_pointers || !part2Node || !edge_out)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "null pointer");
     DeviceState *ds = nullptr;
@@ -44,8 +47,9 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     gnna_get_tuning(&tune);
     apply_graph_hints(column_index, 0, &tune);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    const size_t b_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
-    const bool wide = b_bytes > 0xffffffffull;
+    const bool wide = (size_t)num_in_rows * (size_t)ld_src * sizeof(float) > 0xffffffffull;
+    // what the gather can touch of src_feat (whole 128-byte lines of every row): the size the slicing decision goes by
+    const size_t b_bytes = (size_t)num_in_rows * (size_t)std::min<int64_t>(ld_src, (dim * 4 + 127) / 128 * 32) * sizeof(float);
     int B = 1;
     const uint8_t *cnt = nullptr;
     int S = kMaxSlices;
@@ -70,8 +74,8 @@ int launch_sddmm(const float *dst_feat, const float *src_feat, const int32_t *co
     // the canonical-partition flag only decides between stores and atomics for shared rows; SDDMM shares nothing
     int32_t *flag = nullptr;
     a.seq = next_call_seq(ds, &flag);
-    a.flag = flag; a.trust = 1; a.P = num_parts; a.D = dim; a.ldx = dim; a.ldy = dim; a.num_out_rows = num_out_rows;
-    a.G = std::min(64, std::max(1, tune.groups_per_chunk) * B); a.U = 4; a.S = S; a.B = B;
+    a.flag = flag; a.trust = 1; a.P = num_parts; a.D = dim; a.ldx = (int)ld_src; a.lda = (int)ld_dst; a.ldy = dim; a.num_out_rows = num_out_rows;
+    a.G = std::min(64, std::max(1, tune.groups_per_chunk) * B); a.U = tune.loads_in_flight >= 8 ? 8 : 4; a.S = S; a.B = B;
     a.wide = wide; a.plain_ok = true; a.xcd_remap = tune.xcd_remap != 0; a.eps = 1.f;
     return launch_stream(a, stream);
 }
@@ -90,7 +94,16 @@ int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const int32_t *
                    void *stream)
 {
     if (partSize <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "partSize must be positive (got %d)", partSize);
-    return launch_sddmm(dst_feat, src_feat, column_index, part_pointers, part2Node, edge_out, num_out_rows,
+    return launch_sddmm(dst_feat, dim, src_feat, dim, column_index, part_pointers, part2Node, edge_out, num_out_rows,
+                        num_in_rows, dim, num_parts, partSize, stream);
+}
+
+int gnna_sddmm_ld_f32(const float *dst_feat, int64_t ld_dst, const float *src_feat, int64_t ld_src,
+                      const int32_t *column_index, const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
+                      int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize, void *stream)
+{
+    if (partSize <= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "partSize must be positive (got %d)", partSize);
+    return launch_sddmm(dst_feat, ld_dst, src_feat, ld_src, column_index, part_pointers, part2Node, edge_out, num_out_rows,
                         num_in_rows, dim, num_parts, partSize, stream);
 }
 

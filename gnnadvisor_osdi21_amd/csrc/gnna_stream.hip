@@ -86,6 +86,7 @@ struct StreamParams {
                                // 4-float-strided copy and only their first D floats are stored)
     int32_t ldx;               // row stride of X in floats
     int32_t ldy;               // row stride of Y in floats
+    int32_t lda;               // MODE_SDDMM: row stride of A in floats
     int32_t G;
     int32_t S;                 // fine slices of the plan
     int32_t B;                 // phases: phase p covers fine slices [win_lo + p*W/B, win_lo + (p+1)*W/B), W = win_hi - win_lo
@@ -503,19 +504,44 @@ stream_kernel(const StreamParams p)
             VT v[U];
             if constexpr (MODE == MODE_SDDMM) {
                 // edge_out[e] = < A[row(e), :], X[col(e), :] >: every ring slot carries the destination row's piece of its
-                // load (consecutive loads of a piece re-read the same 4 * LPR floats: L1 hits), no accumulation, no flush --
-                // every edge is written once, in the one phase that owns it
-                // (lanes past the row end read the sweep's first piece instead of running past A's last row: their
-                // value is zeroed in dot_of, the address must still be inside the tensor)
-                const float *abase = p.A + (cvalid ? dcol : (d0 + 4 <= DL ? d0 : DL - 4));
-                auto a_ptr = [&](int j) -> const MT * {
-                    return reinterpret_cast<const MT *>(abase + (size_t)__builtin_amdgcn_readlane(row_j, j) * (size_t)D);
+                // load, no accumulation, no flush -- every edge is written once, in the one phase that owns it.
+                // Rows of up to 64 floats (LPR <= 16): the wavefront fetches the destination row ONCE per load, one float per
+                // lane (256 bytes through the texture path instead of the kilobyte the RPI slots' identical 16-byte reads
+                // cost), and every lane picks its four floats up with ds_bpermute.  Wider rows: the slots (two, or one)
+                // read their piece directly.
+                // (lanes past the row end read inside the row instead of running past A's last row: their value is
+                // zeroed in dot_of, the address must still be inside the tensor)
+                constexpr bool SHARED_A = LPR <= 16;
+                typedef typename std::conditional<SHARED_A, float, VT>::type AT;
+                const int a_el = d0 + (lane & (4 * LPR - 1));
+                const float *abase = SHARED_A ? p.A + (a_el < D ? a_el : D - 1)
+                                              : p.A + (cvalid ? dcol : (d0 + 4 <= DL ? d0 : DL - 4));
+                auto a_load = [&](int j) -> AT {
+#ifdef GNNA_SDDMM_ABLATE_A    // (timing experiment, wrong results: the destination row is never fetched nor permuted)
+                    if constexpr (SHARED_A) return 1.f; else return vzero<4>() + 1.f;
+#else
+                    const float *ap = abase + (size_t)__builtin_amdgcn_readlane(row_j, j) * (size_t)p.lda;
+                    if constexpr (SHARED_A) return *ap;
+                    else return *reinterpret_cast<const MT *>(ap);
+#endif
                 };
-                VT a[U];
+                const int a_src = (cvalid ? dcol - d0 : 0) << 2;      // (byte index of the lane that holds float dcol)
+                AT a[U];
 #pragma unroll
-                for (int u = 0; u < U; u++) { a[u] = *a_ptr(u); v[u] = *row_ptr(offs[u * RPI + slot]); }
+                for (int u = 0; u < U; u++) { a[u] = a_load(u); v[u] = *row_ptr(offs[u * RPI + slot]); }
                 auto dot_of = [&](int u, int j) {
-                    VT av = a[u];
+                    VT av;
+#ifdef GNNA_SDDMM_ABLATE_A
+                    av = vzero<4>() + 1.f;
+#else
+                    if constexpr (SHARED_A) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            av[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(a_src + 4 * k, __float_as_int(a[u])));
+                    } else {
+                        av = a[u];
+                    }
+#endif
                     // components that overlap the previous piece (ragged D) and lanes past the row end do not count
 #pragma unroll
                     for (int k = 0; k < 4; k++)
@@ -535,7 +561,7 @@ stream_kernel(const StreamParams p)
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         dot_of(u, b * U + u);
-                        a[u] = *a_ptr(jn + u);
+                        a[u] = a_load(jn + u);
                         v[u] = *row_ptr(nn[u]);
                     }
                 }
@@ -544,6 +570,10 @@ stream_kernel(const StreamParams p)
                     const int j = (nb - 1) * U + u;
                     if (j < nr) dot_of(u, j);
                 }
+#ifdef GNNA_SDDMM_ABLATE_OUT  // (timing experiment, wrong results: edge_out is never written)
+                if (pend[lane] == 1.2345e30f) p.Y[lane] = 1.f;
+                continue;
+#endif
 #pragma unroll
                 for (int q = 0; q < (RL * RPI + kWave - 1) / kWave; q++) {
                     const int f = q * kWave + lane;
@@ -1163,7 +1193,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     p.X = a.X; p.col = a.col; p.pp = a.pp; p.p2n = a.p2n; p.Y = a.Y; p.cnt = a.cnt; p.row_scale = a.row_scale;
     p.deg_row = a.deg_row; p.deg_col = a.deg_col; p.A = a.A;
     p.flag = a.flag; p.P = a.P; p.seq = a.seq; p.trust = a.trust; p.D = a.D; p.ldx = a.ldx;
-    p.DL = std::max(a.D, 4); p.ldy = a.ldy > 0 ? a.ldy : a.D;
+    p.DL = std::max(a.D, 4); p.ldy = a.ldy > 0 ? a.ldy : a.D; p.lda = a.lda > 0 ? a.lda : a.D;
     p.G = std::max(1, std::min(a.G, kWave));
     p.num_chunks = (a.P + p.G - 1) / p.G;
     int64_t items = (p.num_chunks + kSWaves - 1) / kSWaves;
@@ -1186,7 +1216,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
     while (lpr < 64 && lpr < pieces) lpr <<= 1;
     StreamKernel k = a.mode == MODE_GIN ? pick_stream_lpr<MODE_GIN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
-                     : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, 4) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
+                     : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, a.U) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
     p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
     p.ids_packed = (a.mode == MODE_SDDMM || !a.packed_stale) ? nullptr : a.ids_packed; p.item_off = a.item_off;
     p.packed_stale = a.packed_stale;

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 400 /* 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
+#define GNNA_VERSION 401 /* 0.4.1: gnna_sddmm_ld_f32 (leading dimensions for both SDDMM sides); 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -228,6 +228,14 @@ GNNA_API int gnna_agg_rect_windows_f32(int mode, const float *input, int64_t num
  */
 GNNA_API int gnna_sddmm_f32(const float *dst_feat, const float *src_feat, const int32_t *column_index,
                    const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
+                   int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
+                   void *stream);
+
+/* The same with leading dimensions (floats, >= dim) for both feature matrices: row r of dst_feat starts at
+ * dst_feat + r * ld_dst, row r of src_feat at src_feat + r * ld_src -- a column block of a wider matrix (one attention
+ * head of [N, heads * dim]) or the gapped layout gnna_preferred_ld names for the gathered side (src_feat). */
+GNNA_API int gnna_sddmm_ld_f32(const float *dst_feat, int64_t ld_dst, const float *src_feat, int64_t ld_src,
+                   const int32_t *column_index, const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
                    int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
                    void *stream);
 

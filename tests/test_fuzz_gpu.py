@@ -84,12 +84,19 @@ def test_sddmm_random():
             A = torch.randn(n, D, generator=gen); B = torch.randn(n, D, generator=gen)
             pp, p2n = _lib.build_part(ps, g.row_pointers)
             _lib.set_tuning(groups_per_chunk=int(rng.integers(1, 64)))
-            out = _lib.sddmm(A.cuda(), B.cuda(), g.column_index.cuda(), pp.cuda(), p2n.cuda(), ps)
+            # either side may be a column block of a wider (poisoned) buffer: gnna_sddmm_ld_f32
+            la = int(rng.choice([D, D, D + 1, 2 * D + 4])); lb = int(rng.choice([D, D, D + 3, 128, 2 * D]))
+            lb = max(lb, D)
+            oa = int(rng.integers(0, la - D + 1)); ob = int(rng.integers(0, lb - D + 1))
+            Aw = torch.full((n, la), float("nan")); Aw[:, oa:oa + D] = A
+            Bw = torch.full((n, lb), float("nan")); Bw[:, ob:ob + D] = B
+            _lib.set_tuning(column_phases=int(rng.choice([0, 1, 1, 2, 5, 16])))
+            out = _lib.sddmm(Aw.cuda()[:, oa:oa + D], Bw.cuda()[:, ob:ob + D], g.column_index.cuda(), pp.cuda(), p2n.cuda(), ps)
             ref = oracle.np_sddmm(A.numpy(), B.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
             rows = np.repeat(np.arange(n), np.diff(g.row_pointers.numpy()))
             scale = np.einsum("ed,ed->e", np.abs(A.numpy().astype(np.float64))[rows],
                               np.abs(B.numpy().astype(np.float64))[g.column_index.numpy()])
-            assert_close_f64(out.cpu().numpy(), ref, scale=scale, rtol=1e-5, what=f"sddmm case {k}: n={n} e={e} D={D} ps={ps}")
+            assert_close_f64(out.cpu().numpy(), ref, scale=scale, rtol=1e-5, what=f"sddmm case {k}: n={n} e={e} D={D} ps={ps} la={la}+{oa} lb={lb}+{ob} {_lib.get_tuning()}")
     finally:
         _lib.reset_tuning()
 

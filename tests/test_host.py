@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gnna.h but not exported by libgnna.so"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.gnna_version() == 400
+    assert lib.gnna_version() == 401
 
 
 def test_build_part_c_abi_bit_exact_vs_oracle_and_golden(golden_dir):

@@ -667,6 +667,46 @@ def test_sddmm_extension_matches_dense_formula(dim, partSize):
     assert_close_f64(out2.cpu().numpy(), ref[: int(rp2[-1])], what="sddmm rect", scale=scale[: int(rp2[-1])], rtol=1e-5)
 
 
+@pytest.mark.parametrize("dim,heads", [(16, 4), (64, 2), (5, 3), (41, 2), (128, 2)])
+def test_sddmm_leading_dimensions_heads_of_a_wider_matrix(dim, heads):
+    """gnna_sddmm_ld_f32: both sides are column blocks of [N, heads * dim] matrices (one attention head each), and the
+    gathered side in the gapped layout gnna_preferred_ld names; the other columns are poisoned and must not be read."""
+    g = graph.powerlaw_graph(900, 40000, 300, seed=dim * heads)
+    ps = 16
+    pp, p2n = _lib.build_part(ps, g.row_pointers)
+    gen = torch.Generator().manual_seed(dim + heads)
+    Aw = torch.randn(g.num_nodes, heads * dim, generator=gen); Bw = torch.randn(g.num_nodes, heads * dim, generator=gen)
+    rows = np.repeat(np.arange(g.num_nodes), np.diff(g.row_pointers.numpy()))
+    ci, ppd, p2nd = g.column_index.cuda(), pp.cuda(), p2n.cuda()
+    Ad, Bd = Aw.cuda(), Bw.cuda()
+    for h in range(heads):
+        A, B = Aw[:, h * dim:(h + 1) * dim].contiguous(), Bw[:, h * dim:(h + 1) * dim].contiguous()
+        ref = oracle.np_sddmm(A.numpy(), B.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+        scale = np.einsum("ed,ed->e", np.abs(A.numpy().astype(np.float64))[rows],
+                          np.abs(B.numpy().astype(np.float64))[g.column_index.numpy()])
+        out = _lib.sddmm(Ad[:, h * dim:(h + 1) * dim], Bd[:, h * dim:(h + 1) * dim], ci, ppd, p2nd, ps)
+        assert_close_f64(out.cpu().numpy(), ref, what=f"sddmm head {h} of {heads} x {dim}", scale=scale, rtol=1e-5)
+    # the gathered side in the library's preferred (gapped) layout, the rest of every row poisoned
+    ld = max(_lib.preferred_ld(dim, g.num_nodes, int(g.column_index.numel())), dim + 3)
+    Bg = torch.full((g.num_nodes, ld), float("nan"))
+    Bg[:, :dim] = Bw[:, :dim]
+    Bgd = Bg.cuda()
+    A, B = Aw[:, :dim].contiguous(), Bw[:, :dim].contiguous()
+    ref = oracle.np_sddmm(A.numpy(), B.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+    scale = np.einsum("ed,ed->e", np.abs(A.numpy().astype(np.float64))[rows], np.abs(B.numpy().astype(np.float64))[g.column_index.numpy()])
+    try:
+        for phases in (1, 4):
+            _lib.set_tuning(column_phases=phases)
+            out = _lib.sddmm(Ad[:, :dim], Bgd[:, :dim], ci, ppd, p2nd, ps)
+            assert_close_f64(out.cpu().numpy(), ref, what=f"sddmm gapped ld={ld} phases={phases}", scale=scale, rtol=1e-5)
+    finally:
+        _lib.reset_tuning()
+    with pytest.raises(_lib.GnnaError):
+        _lib._check(_lib.load().gnna_sddmm_ld_f32(Ad.data_ptr(), dim - 1, Bd.data_ptr(), dim, ci.data_ptr(), ppd.data_ptr(),
+                                                  p2nd.data_ptr(), out.data_ptr(), g.num_nodes, g.num_nodes, dim,
+                                                  p2nd.numel(), ps, None))
+
+
 @pytest.mark.parametrize("phases,prescale", [(0, 0), (4, 0), (3, 1)])
 def test_hip_graph_capture_and_replay(phases, prescale):
     """The launch path never synchronises and allocates scratch only on first use, so (after one
