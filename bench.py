@@ -859,6 +859,16 @@ def other_modes(w, steps: int = 10):
         el = time.perf_counter() - t0
         pr = _lib.profile_end()
         return {"edges_per_s": g.nnz * steps / el, "ms_per_step": el * 1e3 / steps, "kernel_ms": pr["main_ms"]}
+    # SDDMM over the same partition (build-defined; north_star names it next to the aggregation): edge_out[e] = <A[row(e)], X[col(e)]>
+    try:
+        edge_out = torch.empty(g.nnz, dtype=torch.float32, device=w.Xc.device)
+        A = w.out if w.out.is_contiguous() else w.Xc
+        sd = timed(lambda: _lib.sddmm(A, w.Xc, g.column_index, w.ppd, w.p2nd, w.ps, out=edge_out))
+        res["sddmm"] = dict(edges_per_s=sd["edges_per_s"], ms_per_step=sd["ms_per_step"],
+                            what="gnna_sddmm_f32 on the bench graph, contiguous rows, same partition (wall clock, %d calls)" % steps)
+        del edge_out
+    except Exception as exc:                      # (an extra figure must never cost the headline line)
+        res["sddmm"] = {"error": repr(exc)[:200]}
     sag_contiguous = lambda: _lib.sag(w.Xc, g.row_pointers, g.column_index, g.degrees, w.ppd, w.p2nd, w.ps, 32, 4, out=w.out)
     if getattr(w, "ld", w.dim) != w.dim:
         # the reference's contiguous layout through gnna_sag_f32 (the library stages the gapped copy itself, per call)
@@ -1008,7 +1018,8 @@ def run_single(args, result_fd):
                               "contiguous_ms_per_step": (modes.get("sag_contiguous_input") or {}).get("ms_per_step"),
                               "contiguous_value": (modes.get("sag_contiguous_input") or {}).get("edges_per_s"),
                               "gcn_weighted_value": modes.get("gcn_weighted_edges_per_s"),
-                              "gin_value": modes.get("gin_eps_edges_per_s")})
+                              "gin_value": modes.get("gin_eps_edges_per_s"),
+                              "sddmm_value": (modes.get("sddmm") or {}).get("edges_per_s")})
     # the driver keeps only the contract's keys of this line: everything else rides inside `config` / `roofline`
     rec["config"]["verified"] = rec["verified"]
     rec["config"]["verification"] = rec.pop("verification")
