@@ -1,6 +1,6 @@
 """Where should a 256-byte row start?  Follow-up of probe_row_alignment.py: the bare access stream of the Reddit-like
-headline (16 source slices, ids phase-major) with row `id` placed at byte  (id * S + off) * 256 + shift  for several
-(S, off, shift).  usage: probe_row_positions.py   (build first: tools/ceiling/build.sh)"""
+headline (16 source slices, ids phase-major) with row `id` placed at byte  (id * S + off) * (4 D) + shift  for several
+(S, off, shift).  usage: probe_row_positions.py [slices] [D = 64 | 128 | 32]   (build first: tools/ceiling/build.sh)"""
 import ctypes
 import json
 import os
@@ -16,8 +16,9 @@ lib = ctypes.CDLL(os.path.join(here, "libceiling.so"))
 lib.gather_ceiling_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 dev = torch.device("cuda:0")
 g = graph.make_config_graph("reddit-like", device=dev)
-N, nnz, D = g.num_nodes, g.column_index.numel(), 64
-XB = torch.randn(16 * N + 64, D, device=dev)
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+N, nnz = g.num_nodes, g.column_index.numel()
+XB = torch.randn((16 if D <= 64 else 4) * N + 64, D, device=dev)
 col = g.column_index
 out = torch.empty((nnz // 256 + 64) * 256, device=dev)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -43,6 +44,10 @@ def floor_ms(ids, shift=0, seg=512, U=4, n=10):
 
 cases = [(1, 0, 0), (2, 0, 0), (2, 1, 0), (2, 0, 0), (2, 1, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (8, 0, 0), (8, 4, 0), (8, 2, 0), (16, 0, 0),
          (3, 0, 0), (2, 0, 128), (2, 1, 128), (1, 0, 128), (1, 0, 64), (2, 0, 64)]
+if D > 64:
+    cases = [(1, 0, 0), (2, 0, 0), (2, 1, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (1, 0, 128), (1, 0, 256), (2, 0, 256), (2, 1, 256), (1, 0, 0)]
+elif D < 64:
+    cases = [(1, 0, 0), (2, 0, 0), (2, 1, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (8, 0, 0), (8, 2, 0), (8, 4, 0), (8, 6, 0), (8, 1, 0), (1, 0, 64)]
 for S, off, shift in cases:
     ids = (ids0 * S + off).contiguous()
-    print(json.dumps(dict(B=B, S=S, off=off, shift=shift, ms=floor_ms(ids, shift))), flush=True)
+    print(json.dumps(dict(D=D, B=B, S=S, off=off, shift=shift, ms=floor_ms(ids, shift))), flush=True)
