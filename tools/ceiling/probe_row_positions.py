@@ -48,6 +48,14 @@ if D > 64:
     cases = [(1, 0, 0), (2, 0, 0), (2, 1, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (1, 0, 128), (1, 0, 256), (2, 0, 256), (2, 1, 256), (1, 0, 0)]
 elif D < 64:
     cases = [(1, 0, 0), (2, 0, 0), (2, 1, 0), (4, 0, 0), (4, 1, 0), (4, 2, 0), (4, 3, 0), (8, 0, 0), (8, 2, 0), (8, 4, 0), (8, 6, 0), (8, 1, 0), (1, 0, 64)]
+if D == 16:
+    # 64-byte rows, two per line: contiguous against layouts that leave the slow line class (the fourth line of every 512 bytes) empty
+    U16 = 2 if len(sys.argv) > 3 and sys.argv[3] == "u2" else 4
+    for name, ids in (("contiguous", ids0), ("6 of every 8 row slots (bytes 384..511 of every 512 empty)", (ids0 // 6) * 8 + ids0 % 6),
+                      ("14 of every 16 row slots (bytes 384..511 of every 1024 empty)", (ids0 // 14) * 16 + (ids0 % 14) + 2 * ((ids0 % 14) >= 6).int()),
+                      ("one row per 128-byte line", ids0 * 2), ("contiguous again", ids0)):
+        print(json.dumps(dict(D=D, B=B, layout=name, ms=floor_ms(ids.contiguous().int(), 0, U=U16))), flush=True)
+    sys.exit(0)
 for S, off, shift in cases:
     ids = (ids0 * S + off).contiguous()
     print(json.dumps(dict(D=D, B=B, S=S, off=off, shift=shift, ms=floor_ms(ids, shift))), flush=True)
