@@ -63,6 +63,11 @@ def _worker(rank, world, port, chunks, q, exchange="allgather"):
         # one training step of the sharded layers against the single-GPU op layer on the whole graph
         from gnnadvisor_osdi21_amd import ops
         l1, l2 = ShardedGCNConv(12, 8, agg), ShardedGINConv(8, 5, agg)
+        # (first use of the BLAS library on autograd's thread happens here, not inside the step that is checked: the transient
+        # described at test_two_ranks_sharing_the_gpu has only ever hit the FIRST backward pass of a process)
+        wa = torch.randn(64, 8, device="cuda", requires_grad=True)
+        torch.mm(wa, torch.randn(8, 12, device="cuda")).sum().backward()
+        torch.cuda.synchronize()
         F = torch.randn(n, 12, generator=torch.Generator().manual_seed(3))
         Fl = F[lo:hi].contiguous().cuda().requires_grad_(True)
         yl = l2(torch.relu(l1(Fl, degl)))
