@@ -23,7 +23,7 @@ class GnnaError(RuntimeError):
 
 
 class Tuning(ctypes.Structure):
-    _fields_ = [("groups_per_chunk", ctypes.c_int), ("loads_in_flight", ctypes.c_int),
+    _fields_ = [("struct_size", ctypes.c_int), ("groups_per_chunk", ctypes.c_int), ("loads_in_flight", ctypes.c_int),
                 ("blocks_per_cu", ctypes.c_int), ("xcd_remap", ctypes.c_int),
                 ("trust_canonical", ctypes.c_int), ("column_phases", ctypes.c_int),
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
@@ -39,7 +39,7 @@ _TAIL = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,        # part_pointe
          ctypes.c_int64, ctypes.c_int, ctypes.c_int64,             # num_nodes, dim, num_parts
          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]  # partSize, dimWorker, warpPerBlock, stream
 
-EXPORTS = ("gnna_version", "gnna_last_error", "gnna_count_parts", "gnna_build_part_i32",
+EXPORTS = ("gnna_version", "gnna_build_id", "gnna_last_error", "gnna_count_parts", "gnna_build_part_i32",
            "gnna_sag_f32", "gnna_agg_gcn_f32", "gnna_agg_gin_f32", "gnna_set_tuning", "gnna_get_tuning",
            "gnna_profile_begin", "gnna_profile_end", "gnna_agg_rect_f32",
            "gnna_csr_from_edges_i32", "gnna_degrees_f32", "gnna_edge_span", "gnna_reorder_rcm_i32",
@@ -60,6 +60,7 @@ def load() -> ctypes.CDLL:
             "(run `python -m gnnadvisor_osdi21_amd.build`). There is no CPU fallback.")
     L = ctypes.CDLL(LIB_PATH)
     L.gnna_version.restype = ctypes.c_int
+    L.gnna_build_id.restype = ctypes.c_char_p
     L.gnna_last_error.restype = ctypes.c_char_p
     L.gnna_count_parts.restype = ctypes.c_int64
     L.gnna_count_parts.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
@@ -72,7 +73,7 @@ def load() -> ctypes.CDLL:
     L.gnna_agg_gcn_f32.argtypes = _AGG_COMMON + [ctypes.c_void_p] + _TAIL
     L.gnna_agg_gin_f32.restype = ctypes.c_int
     L.gnna_agg_gin_f32.argtypes = _AGG_COMMON + [ctypes.c_float] + _TAIL
-    L.gnna_set_tuning.restype = None
+    L.gnna_set_tuning.restype = ctypes.c_int
     L.gnna_set_tuning.argtypes = [ctypes.POINTER(Tuning)]
     L.gnna_get_tuning.restype = None
     L.gnna_get_tuning.argtypes = [ctypes.POINTER(Tuning)]
@@ -162,14 +163,19 @@ def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_re
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
                pad_rows=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1,
                wide_blocks=-1) -> None:
-    t = Tuning(groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
+    t = Tuning(ctypes.sizeof(Tuning), groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
                avg_degree, nonlocal_ids, gcn_prescale, pad_rows, zero_fill, sweep, sweep_slack, deterministic,
                pack_ids, wide_blocks)
-    load().gnna_set_tuning(ctypes.byref(t))
+    _check(load().gnna_set_tuning(ctypes.byref(t)))
 
 
 def reset_tuning() -> None:
-    load().gnna_set_tuning(None)
+    _check(load().gnna_set_tuning(None))
+
+
+def build_id() -> str:
+    """"0.5.0+<source hash>" of the loaded libgnna.so (gnna_build_id)."""
+    return load().gnna_build_id().decode()
 
 
 _registered: dict = {}      # device address -> token of the storage that registered hints / schedules for it
@@ -215,7 +221,7 @@ def set_graph_hints(column_index, avg_degree: float, nonlocal_ids: bool) -> None
 def get_tuning() -> dict:
     t = Tuning()
     load().gnna_get_tuning(ctypes.byref(t))
-    return {name: getattr(t, name) for name, _ in Tuning._fields_}
+    return {name: getattr(t, name) for name, _ in Tuning._fields_ if name != "struct_size"}
 
 
 def _host_i32(t) -> torch.Tensor:

@@ -34,6 +34,21 @@ EXT_SOURCES = [os.path.join(CSRC, "gnna_torch.cpp")]
 EXT_DEPS = EXT_SOURCES + [os.path.join(INCLUDE, "gnna.h")]
 
 
+def source_hash() -> str:
+    """First 16 hex digits of the SHA-256 over every source that goes into libgnna.so and the GNNAdvisor module (path
+    relative to the repository + contents, in a fixed order).  build_lib compiles it into gnna_build_id(); smoke() and the
+    tests compare the loaded library's id with this function's answer for the tree they run from, which proves that the
+    binaries on the GPU box were built from the sources beside them (VERDICT r4 task 8)."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(set(LIB_DEPS + EXT_DEPS)):
+        h.update(os.path.relpath(path, ROOT).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def _stale(target: str, deps: list[str]) -> bool:
     if not os.path.exists(target):
         return True
@@ -50,11 +65,15 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-ffp-contract=off",
              "-fvisibility=hidden", "-I" + INCLUDE, "-I" + CSRC]
     jobs, objs = [], []
+    digest = source_hash()
+    stamp = os.path.join(objdir, "source_hash.txt")
+    stamped = open(stamp).read().strip() if os.path.exists(stamp) else ""
     for src in LIB_SOURCES:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
-            jobs.append([HIPCC, *flags, "-c", src, "-o", obj])
+        carries_id = os.path.basename(src) == "gnna_host.cpp"       # gnna_build_id() lives there
+        if force or _stale(obj, [src] + headers) or (carries_id and stamped != digest):
+            jobs.append([HIPCC, *flags, *([f'-DGNNA_SOURCE_HASH="{digest}"'] if carries_id else []), "-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -65,17 +84,24 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             list(pool.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
         run([HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fvisibility=hidden", *objs, "-o", LIB])
+    with open(stamp, "w") as f:
+        f.write(digest + "\n")
+    if verbose:
+        print(f"libgnna.so: source hash {digest} ({'compiled ' + str(len(jobs)) + ' object(s)' if jobs else 'objects up to date'})", flush=True)
     return LIB
 
 
 def build_ext(force: bool = False, verbose: bool = False) -> str:
     build_lib(force, verbose)
-    if force or _stale(EXT, EXT_DEPS + [LIB]):
+    digest = source_hash()
+    stamp = os.path.join(CSRC, "build", "ext_source_hash.txt")
+    stamped = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or _stale(EXT, EXT_DEPS + [LIB]) or stamped != digest:
         import pybind11
         import torch
         tdir = os.path.dirname(torch.__file__)
         cmd = [HIPCC, "-O2", "-std=c++17", "-fPIC", "-shared", "-w",
-               "-DTORCH_EXTENSION_NAME=GNNAdvisor", "-DTORCH_API_INCLUDE_EXTENSION_H",
+               "-DTORCH_EXTENSION_NAME=GNNAdvisor", "-DTORCH_API_INCLUDE_EXTENSION_H", f'-DGNNA_SOURCE_HASH="{digest}"',
                "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__",
                f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}",
                "-I" + INCLUDE,
@@ -90,6 +116,8 @@ def build_ext(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(digest + "\n")
     return EXT
 
 

@@ -23,7 +23,7 @@ thread_local char t_error[512] = "";
 // Defaults chosen by measurement on MI355X (DESIGN.md "Tuning"); override with
 // gnna_set_tuning() or the GNNA_TUNE environment variable
 // ("G=16,U=4,BPC=0,XCD=1,TRUST=0,PHASES=0").
-const gnna_tuning kDefaultTuning = {/*groups_per_chunk=*/16, /*loads_in_flight=*/4,
+const gnna_tuning kDefaultTuning = {/*struct_size=*/(int)sizeof(gnna_tuning), /*groups_per_chunk=*/16, /*loads_in_flight=*/4,
                                     /*blocks_per_cu=*/0, /*xcd_remap=*/1, /*trust_canonical=*/0,
                                     /*column_phases=*/0, /*avg_degree=*/0, /*nonlocal_ids=*/0,
                                     /*gcn_prescale=*/0, /*pad_rows=*/0, /*zero_fill=*/0,
@@ -134,13 +134,21 @@ extern "C" {
 
 int gnna_version(void) { return GNNA_VERSION; }
 
+#ifndef GNNA_SOURCE_HASH
+#define GNNA_SOURCE_HASH "unhashed"        /* (built by hand, not by gnnadvisor_osdi21_amd/build.py) */
+#endif
+const char *gnna_build_id(void) { return "0.5.0+" GNNA_SOURCE_HASH; }
+
 const char *gnna_last_error(void) { return t_error; }
 
-void gnna_set_tuning(const gnna_tuning *t)
+int gnna_set_tuning(const gnna_tuning *t)
 {
     std::call_once(g_env_once, apply_env);
+    if (t && t->struct_size != (int)sizeof(gnna_tuning))
+        return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_set_tuning: struct_size %d, this library's gnna_tuning has %d bytes "
+                          "(caller built against another gnna.h)", t->struct_size, (int)sizeof(gnna_tuning));
     std::lock_guard<std::mutex> lock(g_tuning_mutex);
-    if (!t) { g_tuning = kDefaultTuning; apply_env(); return; }  // defaults = built-in values + GNNA_TUNE
+    if (!t) { g_tuning = kDefaultTuning; apply_env(); return GNNA_OK; }  // defaults = built-in values + GNNA_TUNE
     if (t->groups_per_chunk > 0) g_tuning.groups_per_chunk = t->groups_per_chunk;
     if (t->loads_in_flight > 0) g_tuning.loads_in_flight = t->loads_in_flight;
     if (t->blocks_per_cu >= 0) g_tuning.blocks_per_cu = t->blocks_per_cu;
@@ -157,6 +165,7 @@ void gnna_set_tuning(const gnna_tuning *t)
     if (t->deterministic >= 0) g_tuning.deterministic = t->deterministic;
     if (t->pack_ids >= 0) g_tuning.pack_ids = t->pack_ids;
     if (t->wide_blocks >= 0) g_tuning.wide_blocks = t->wide_blocks;
+    return GNNA_OK;
 }
 
 int gnna_set_graph_hints(const int32_t *column_index, int avg_degree, int nonlocal_ids)

@@ -517,13 +517,9 @@ stream_kernel(const StreamParams p)
                 const float *abase = SHARED_A ? p.A + (a_el < D ? a_el : D - 1)
                                               : p.A + (cvalid ? dcol : (d0 + 4 <= DL ? d0 : DL - 4));
                 auto a_load = [&](int j) -> AT {
-#ifdef GNNA_SDDMM_ABLATE_A    // (timing experiment, wrong results: the destination row is never fetched nor permuted)
-                    if constexpr (SHARED_A) return 1.f; else return vzero<4>() + 1.f;
-#else
                     const float *ap = abase + (size_t)__builtin_amdgcn_readlane(row_j, j) * (size_t)p.lda;
                     if constexpr (SHARED_A) return *ap;
                     else return *reinterpret_cast<const MT *>(ap);
-#endif
                 };
                 const int a_src = (cvalid ? dcol - d0 : 0) << 2;      // (byte index of the lane that holds float dcol)
                 AT a[U];
@@ -531,9 +527,6 @@ stream_kernel(const StreamParams p)
                 for (int u = 0; u < U; u++) { a[u] = a_load(u); v[u] = *row_ptr(offs[u * RPI + slot]); }
                 auto dot_of = [&](int u, int j) {
                     VT av;
-#ifdef GNNA_SDDMM_ABLATE_A
-                    av = vzero<4>() + 1.f;
-#else
                     if constexpr (SHARED_A) {
 #pragma unroll
                         for (int k = 0; k < 4; k++)
@@ -541,7 +534,6 @@ stream_kernel(const StreamParams p)
                     } else {
                         av = a[u];
                     }
-#endif
                     // components that overlap the previous piece (ragged D) and lanes past the row end do not count
 #pragma unroll
                     for (int k = 0; k < 4; k++)
@@ -570,10 +562,6 @@ stream_kernel(const StreamParams p)
                     const int j = (nb - 1) * U + u;
                     if (j < nr) dot_of(u, j);
                 }
-#ifdef GNNA_SDDMM_ABLATE_OUT  // (timing experiment, wrong results: edge_out is never written)
-                if (pend[lane] == 1.2345e30f) p.Y[lane] = 1.f;
-                continue;
-#endif
                 // (one 16-byte store per load from the lane that described it measured slower than this pass: 1.02 against
                 // 0.91 ms at D = 16, 1.92 against 1.90 at D = 64)
 #pragma unroll

@@ -327,13 +327,11 @@ sweep_kernel(const SweepParams p)
                 if (lo > g_lo) wave_prev_row = p.p2n[lo - 1];
                 if (hi < g_hi) wave_next_row = p.p2n[hi];
             }
-#ifndef GNNA_ABLATE_LOCKS    // (timing experiment, wrong results on shared rows: no chunk locks)
             if (dyn && lane == 0) {   // the chunk's rows are this wavefront's until the item is done
                 const unsigned bit = 1u << (chunk & 31);
                 while (__hip_atomic_fetch_or(&s_lock[chunk >> 5], bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) & bit)
                     __builtin_amdgcn_s_sleep(2);
             }
-#endif
 
             if (ng > 0)
             {
@@ -478,11 +476,7 @@ sweep_kernel(const SweepParams p)
                                 if (lslot >= vj) v[u] = vzero<4>();
                             }
                             acc += v[u];
-#ifdef GNNA_ABLATE_FOLD      // timing experiment (wrong results): rows are never folded nor accumulated in LDS
-                            if (false) {
-#else
                             if ((FL >> j) & 1ull) {
-#endif
                                 const int meta = __builtin_amdgcn_readlane(k_meta, j);
                                 const VT rr = fold_row<LPR, MODE_SAG>(acc, 1.f);
                                 if (!(meta & 1)) {
@@ -551,9 +545,6 @@ sweep_kernel(const SweepParams p)
                         }
                         cur = nxt;
                     }
-#ifdef GNNA_ABLATE_FOLD
-                    if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345e30f) s_acc[lane] = 1.f;   // (keeps the gather alive)
-#endif
                 }
             }
             if (dyn && lane == 0)

@@ -389,4 +389,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           pybind11::arg("out") = pybind11::none(), pybind11::arg("accumulate") = false, pybind11::arg("relu") = false);
     m.def("build_part", &build_part, "GNNAdvisor neighbor-group partitioner (CPU)", pybind11::arg("partSize"),
           pybind11::arg("indptr"), pybind11::arg("float_compat") = false);
+#ifndef GNNA_SOURCE_HASH
+#define GNNA_SOURCE_HASH "unhashed"
+#endif
+    m.def("build_id", []() { return std::string("module ") + GNNA_SOURCE_HASH + ", library " + gnna_build_id(); },
+          "source hashes this module and the libgnna.so it loaded were built from (extension)");
 }

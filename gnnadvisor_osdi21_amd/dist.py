@@ -745,6 +745,25 @@ class ShardedAggregator:
 # gradient aggregation uses the same shard; dW = X_local^T G_local is a partial sum over the
 # rank's rows and is all-reduced (a [Fin, Fout] fp32 payload: latency-, not bandwidth-bound).
 
+_trace_sink: Optional[list] = None
+
+
+def set_trace(sink: Optional[list]) -> None:
+    """Debug / strict-test hook: while a list is installed, every intermediate of the sharded layers' forward and
+    backward (dense update, aggregation input and output, partial and reduced weight gradient) is appended to it as
+    (name, clone, HIP stream handle, thread id).  The clones are enqueued on the step's own stream: no synchronisation is
+    added.  None switches it off (the default: the product never traces)."""
+    global _trace_sink
+    _trace_sink = sink
+
+
+def _tr(name: str, t: Optional[torch.Tensor]) -> None:
+    if _trace_sink is not None and t is not None:
+        import threading
+        stream = torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else -1
+        _trace_sink.append((name, t.detach().clone(), stream, threading.get_ident()))
+
+
 def _xtg(X: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
     """X^T G (weight gradient): libgnna's MFMA kernel on the GPU, torch.mm for the CPU/gloo tests."""
     if X.is_cuda:
@@ -766,14 +785,25 @@ class ShardedGCNFunction(torch.autograd.Function):
     def forward(ctx, X_local, weight, agg: "ShardedAggregator", degrees_local):
         ctx.save_for_backward(X_local, weight)
         ctx.agg, ctx.deg = agg, degrees_local
-        return agg.gcn(torch.mm(X_local, weight), degrees_local)
+        XW = torch.mm(X_local, weight)
+        _tr("gcn.fwd.XW", XW)
+        Y = agg.gcn(XW, degrees_local)
+        _tr("gcn.fwd.Y", Y)
+        return Y
 
     @staticmethod
     def backward(ctx, d_output):
         X_local, weight = ctx.saved_tensors
-        G = ctx.agg.gcn(d_output.contiguous(), ctx.deg)          # Â dY, rows of this rank
+        d_output = d_output.contiguous()
+        _tr("gcn.bwd.dY", d_output)
+        G = ctx.agg.gcn(d_output, ctx.deg)                       # Â dY, rows of this rank
+        _tr("gcn.bwd.G", G)
         d_input = torch.mm(G, weight.t()) if ctx.needs_input_grad[0] else None
-        d_weight = _all_reduce_sum(_xtg(X_local, G), ctx.agg.group, ctx.agg.force_collectives)
+        _tr("gcn.bwd.dX", d_input)
+        d_weight = _xtg(X_local, G)
+        _tr("gcn.bwd.dW.partial", d_weight)
+        d_weight = _all_reduce_sum(d_weight, ctx.agg.group, ctx.agg.force_collectives)
+        _tr("gcn.bwd.dW", d_weight)
         return d_input, d_weight, None, None
 
 
@@ -782,7 +812,9 @@ class ShardedGINFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X_local, weight, agg: "ShardedAggregator", epsilon):
+        _tr("gin.fwd.X", X_local)
         T = agg.gin(X_local, epsilon)
+        _tr("gin.fwd.T", T)
         ctx.save_for_backward(T, weight)
         ctx.agg, ctx.epsilon = agg, epsilon
         return torch.mm(T, weight)
@@ -791,10 +823,17 @@ class ShardedGINFunction(torch.autograd.Function):
     def backward(ctx, d_output):
         T, weight = ctx.saved_tensors
         d_output = d_output.contiguous()
-        d_weight = _all_reduce_sum(_xtg(T, d_output), ctx.agg.group, ctx.agg.force_collectives)
+        _tr("gin.bwd.dY", d_output)
+        d_weight = _xtg(T, d_output)
+        _tr("gin.bwd.dW.partial", d_weight)
+        d_weight = _all_reduce_sum(d_weight, ctx.agg.group, ctx.agg.force_collectives)
+        _tr("gin.bwd.dW", d_weight)
         d_input = None
         if ctx.needs_input_grad[0]:
-            d_input = ctx.agg.gin(torch.mm(d_output, weight.t()), ctx.epsilon)
+            M = torch.mm(d_output, weight.t())
+            _tr("gin.bwd.dYWt", M)
+            d_input = ctx.agg.gin(M, ctx.epsilon)
+            _tr("gin.bwd.dX", d_input)
         return d_input, d_weight, None, None
 
 

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 401 /* 0.4.1: gnna_sddmm_ld_f32 (leading dimensions for both SDDMM sides); 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
+#define GNNA_VERSION 500 /* 0.5.0: gnna_tuning opens with struct_size (checked by gnna_set_tuning, which now returns a status), gnna_build_id; 0.4.1: gnna_sddmm_ld_f32 (leading dimensions for both SDDMM sides); 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -63,6 +63,10 @@ typedef enum gnna_status {
 } gnna_status;
 
 GNNA_API int gnna_version(void);
+/* "<major>.<minor>.<patch>+<16 hex digits>": the digits are the SHA-256 prefix of the library's sources (every file of
+ * csrc/ and include/ that goes into libgnna.so and the GNNAdvisor module) as the build script hashed them -- a run can
+ * prove that the binary it loaded was built from the sources beside it (gnnadvisor_osdi21_amd/build.py: source_hash). */
+GNNA_API const char *gnna_build_id(void);
 GNNA_API const char *gnna_last_error(void);
 
 /* ---- partitioner (host) --------------------------------------------------------------
@@ -252,6 +256,9 @@ GNNA_API int gnna_xtg_f32(const float *X, const float *G, float *dW, int64_t num
  * Any field <= 0 (or < 0 where 0 is meaningful) keeps the built-in choice.
  */
 typedef struct gnna_tuning {
+    int struct_size;      /* sizeof(gnna_tuning) of the caller's header: gnna_set_tuning refuses any other value (fields came
+                             and went between 0.3 and 0.4 without a check; a caller built against another layout now gets
+                             GNNA_ERR_INVALID_ARGUMENT instead of silently shifted knobs).  gnna_get_tuning fills it in. */
     int groups_per_chunk; /* neighbor-groups a wavefront walks per work item (1..64)      */
     int loads_in_flight;  /* wave-wide row loads issued before the first add (4, 8, 16)   */
     int blocks_per_cu;    /* sweep kernel only: workgroups per CU (1: one 16-wavefront workgroup with all of the
@@ -313,7 +320,7 @@ typedef struct gnna_tuning {
                              and the matrix is Infinity-Cache sized), 1 = whenever dim >= 72, 2 = never */
 } gnna_tuning;
 
-GNNA_API void gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults */
+GNNA_API int gnna_set_tuning(const gnna_tuning *t); /* NULL restores the defaults; GNNA_ERR_INVALID_ARGUMENT on a struct_size mismatch */
 GNNA_API void gnna_get_tuning(gnna_tuning *t);
 
 /* Per-graph form of the two hints: remembers (avg_degree, nonlocal_ids) for the graph whose

@@ -60,34 +60,56 @@ def _worker(rank, world, port, chunks, q, exchange="allgather"):
                 if err > 1e-4:
                     bad.append(("aggregate rep %d mode %d" % (rep, mode), err, int((e_rows > 1e-4).sum()),
                                 np.nonzero(e_rows > 1e-4)[0][:8].tolist()))
-        # one training step of the sharded layers against the single-GPU op layer on the whole graph
-        from gnnadvisor_osdi21_amd import ops
+        # one training step of the sharded layers against the fp64 network on the whole graph.  STRICT: every intermediate of
+        # the step is traced (dist.set_trace: clones + stream / thread ids), a mismatch dumps the lot under
+        # gpurun_out/dist_dump/ and fails -- no second attempt (the re-run of rounds 3-4 hid a defect of the CHECKER: the fp64
+        # ReLU mask against the fp32 sign of a pre-activation that cancels to ~0, see util.gcn_gin_reference)
+        from gnnadvisor_osdi21_amd import dist as gdist
+        trace = []
+        gdist.set_trace(trace)
+        if os.environ.get("GNNA_TEST_MAIN_THREAD_BACKWARD", "0") == "1":
+            torch.autograd.set_multithreading_enabled(False)
         l1, l2 = ShardedGCNConv(12, 8, agg), ShardedGINConv(8, 5, agg)
-        # (first use of the BLAS library on autograd's thread happens here, not inside the step that is checked: the transient
-        # described at test_two_ranks_sharing_the_gpu has only ever hit the FIRST backward pass of a process)
-        wa = torch.randn(64, 8, device="cuda", requires_grad=True)
-        torch.mm(wa, torch.randn(8, 12, device="cuda")).sum().backward()
-        torch.cuda.synchronize()
         F = torch.randn(n, 12, generator=torch.Generator().manual_seed(3))
         Fl = F[lo:hi].contiguous().cuda().requires_grad_(True)
-        yl = l2(torch.relu(l1(Fl, degl)))
+        h1 = l1(Fl, degl)
+        yl = l2(torch.relu(h1))
         wgt = torch.linspace(0.5, 1.5, 5, device="cuda")
         (yl * wgt).sum().backward()
+        gdist.set_trace(None)
 
-        # against the fp64 network on the whole graph, within 1e-4 of the sum of |terms| (north_star's bound); the
-        # replicated weight gradients are complete on every rank (all-reduced), dF is this rank's block
+        # within 1e-4 of the sum of |terms| (north_star's bound); the replicated weight gradients are complete on every
+        # rank (all-reduced), out / H1 / dF are this rank's block.  The reference's ReLU mask follows the computed sign where
+        # the pre-activation is inside that bound of zero, so it needs the H1 blocks of ALL ranks.
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
         from util import gcn_gin_reference
-        ref = gcn_gin_reference(g, F, l1.weights, l2.weights, wgt)
-        for what, got, (want, scale), sl in (("layers out", yl, ref["out"], slice(lo, hi)), ("layers dF", Fl.grad, ref["dF"], slice(lo, hi)),
+        blocks = [None] * world
+        dist.all_gather_object(blocks, (lo, h1.detach().cpu()))
+        H1_all = torch.cat([b[1] for b in sorted(blocks, key=lambda b: b[0])])
+        ref = gcn_gin_reference(g, F, l1.weights, l2.weights, wgt, H1_got=H1_all)
+        assert ref["ambiguous"] <= 16 + 1e-3 * H1_all.numel(), ref["ambiguous"]   # (about one element per 30,000 cancels that far)
+        for what, got, (want, scale), sl in (("layers out", yl, ref["out"], slice(lo, hi)), ("layers H1", h1, ref["H1"], slice(lo, hi)),
+                                             ("layers dF", Fl.grad, ref["dF"], slice(lo, hi)),
                                              ("layers dW1", l1.weights.grad, ref["dW1"], slice(None)),
                                              ("layers dW2", l2.weights.grad, ref["dW2"], slice(None))):
             err = np.abs(got.detach().double().cpu().numpy() - want[sl]) / np.maximum(1.0, scale[sl])
             worst = max(worst, float(err.max()))
             ok &= bool(err.max() <= 1e-4)
-            if err.max() > 1e-4:
+            if not err.max() <= 1e-4:
                 bad.append((what, float(err.max()), int((err > 1e-4).sum())))
-        q.put((rank, bool(ok), (worst, bad)))
+        info = dict(ambiguous=ref["ambiguous"], min_ratio=ref["min_ratio"], sign_flips=ref["sign_flips"])
+        if not ok:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            ddir = os.path.join(root, "gpurun_out", "dist_dump")
+            os.makedirs(ddir, exist_ok=True)
+            path = os.path.join(ddir, "two_ranks_%s_k%d_port%d_rank%d.pt" % (exchange, chunks, port, rank))
+            torch.save(dict(exchange=exchange, chunks=chunks, rank=rank, lo=lo, hi=hi, bad=bad, info=info, F=F, wgt=wgt.cpu(),
+                            W1=l1.weights.detach().cpu(), W2=l2.weights.detach().cpu(), H1_all=H1_all, out=yl.detach().cpu(),
+                            dF=Fl.grad.cpu(), dW1=l1.weights.grad.cpu(), dW2=l2.weights.grad.cpu(),
+                            trace=[(name, t.cpu(), stream, thread) for name, t, stream, thread in trace],
+                            env={k: v for k, v in os.environ.items() if k.startswith(("GNNA", "AMD_", "HIP", "TORCH_BLAS", "HSA"))}), path)
+            info["dump"] = path
+        q.put((rank, bool(ok), (worst, bad, info)))
     except Exception as exc:                                   # surface the failure instead of a queue timeout
         import traceback
         q.put((rank, False, traceback.format_exc()))
@@ -113,16 +135,12 @@ def _two_ranks_once(chunks, exchange):
 
 @pytest.mark.parametrize("chunks,exchange", [(1, "allgather"), (3, "allgather"), (1, "halo"), (3, "halo")])
 def test_two_ranks_sharing_the_gpu(chunks, exchange):
-    """KNOWN TRANSIENT ("two processes on one GPU"): in 4 of ~270 sessions on MI355X boxes one rank's input
-    gradient of the layer step came back with a few rows off (the standalone aggregations, the layer outputs and the weight
-    gradients never did); 6 diagnostic loops (255 sessions, 8 extra backward passes each) did not reproduce it, no
-    single-process or RCCL test has ever shown it.  A mismatch is therefore re-run ONCE in fresh processes: a deterministic
-    defect fails twice, and the first failure is reported as a warning either way."""
+    """One attempt, strict.  (Rounds 3-4 re-ran a mismatch of the input gradient once: 4 of ~270 sessions had 3-15 rows of one
+    rank's dF off while out / dW1 / dW2 were fine.  Cause, named in round 5: the checker's fp64 ReLU mask against the fp32
+    sign of a layer-1 pre-activation that cancels to within rounding of zero -- the sign then depends on the order float
+    atomics land in; tests/test_relu_mask.py reproduces it deterministically.  The reference now takes the computed sign for
+    the elements inside the bound, and a mismatch dumps every intermediate of the step.)"""
     res, codes = _two_ranks_once(chunks, exchange)
-    if codes == [0, 0] and not all(ok for _, ok, _ in res):
-        import warnings
-        warnings.warn(f"two ranks sharing the GPU ({chunks}, {exchange}): first attempt off, re-running once: {res}")
-        res, codes = _two_ranks_once(chunks, exchange)
     assert codes == [0, 0], (codes, res)
     assert all(ok for _, ok, _ in res), res
 
@@ -141,12 +159,11 @@ def test_sharded_training_driver_two_ranks(model):
            "--dim", "40", "--hidden", "16", "--classes", "5", "--model", model, "--num_epoches", "3",
            "--backend", "gloo", "--share_gpu", "--pipeline_chunks", "2", "--verbose_mode", "True"]
     res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
-    if res.returncode != 0:
-        # (seen once in ~90 runs: one rank of the pair sharing the GPU aborted; re-run once, keep the evidence in the warning)
-        import warnings
-        warnings.warn(f"sharded driver ({model}): first attempt exited {res.returncode}, re-running once: {res.stderr[-1500:]}")
-        cmd[cmd.index("--master-port") + 1] = str(_free_port())
-        res = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=600)
+    if res.returncode != 0:                                     # one attempt; keep the whole evidence of a failure
+        ddir = os.path.join(root, "gpurun_out", "dist_dump")
+        os.makedirs(ddir, exist_ok=True)
+        with open(os.path.join(ddir, "driver_%s_rc%d_pid%d.log" % (model, res.returncode, os.getpid())), "w") as f:
+            f.write(" ".join(cmd) + "\n--- stdout\n" + res.stdout + "\n--- stderr\n" + res.stderr)
     assert res.returncode == 0, res.stderr[-2000:]
     out = res.stdout
     assert re.search(r"Time \(ms\): \d+\.\d{3}", out), out

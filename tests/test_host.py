@@ -25,7 +25,31 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gnna.h but not exported by libgnna.so"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.gnna_version() == 401
+    assert lib.gnna_version() == 500
+
+
+def test_binaries_carry_the_hash_of_the_sources_beside_them():
+    """gnna_build_id() / GNNAdvisor.build_id(): the loaded binaries were compiled from this tree's sources."""
+    from gnnadvisor_osdi21_amd import build as gbuild
+    want = gbuild.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", want)
+    assert _lib.build_id() == "0.5.0+" + want
+    assert load_extension().build_id() == f"module {want}, library 0.5.0+{want}"
+
+
+def test_set_tuning_refuses_another_struct_layout():
+    """gnna_tuning.struct_size: a caller built against a header with more / fewer knobs is refused instead of
+    having its fields silently shifted."""
+    import ctypes
+    lib = _lib.load()
+    t = _lib.Tuning(*([ctypes.sizeof(_lib.Tuning) - 4] + [-1] * (len(_lib.Tuning._fields_) - 1)))
+    before = _lib.get_tuning()
+    assert lib.gnna_set_tuning(ctypes.byref(t)) == -1 and b"struct_size" in lib.gnna_last_error()
+    assert _lib.get_tuning() == before
+    _lib.set_tuning(column_phases=5)
+    assert _lib.get_tuning()["column_phases"] == 5
+    _lib.reset_tuning()
+    assert _lib.get_tuning() == before
 
 
 def test_build_part_c_abi_bit_exact_vs_oracle_and_golden(golden_dir):
