@@ -857,6 +857,10 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
     int rc = get_device_state(&ds);
     if (rc != GNNA_OK) return rc;
     drain_dead_buffers();       // (this call may synchronise and allocate: the place to free what finalizers left behind)
+    // counted like a launch from here on: get_slice_plan's allocation path frees deferred buffers when "only the caller"
+    // is in flight (drain_dead_locked(1)) -- without the guard another thread between its plan lookup and its kernel
+    // launch would have been that one
+    LaunchGuard in_flight;
     SlicePlan plan;
     rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, true, &plan);
     if (rc != GNNA_OK) return rc;

@@ -25,6 +25,8 @@
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "gnna.h"
@@ -38,6 +40,82 @@
 namespace {
 
 enum AggKind { AGG_SAG, AGG_GCN, AGG_GIN };
+
+// ---- automatic graph lifecycle for callers of the six reference functions ------------------------------------------
+// The reference API has no "this graph is immutable" call, so a drop-in caller (GNNA_main.py, unitest.py) never reaches
+// gnna_prepare_graph and its aggregations read the column ids one cache line per neighbor-group and phase instead of
+// from the packed copy (1.442 against 1.36 ms on the Reddit-like headline).  This module knows more
+// than a raw-pointer caller can tell the C ABI: a torch tensor carries a VERSION COUNTER that every in-place write
+// through torch bumps, and a storage that outlives or dies with it.  A graph -- the (column_index, part_pointers,
+// part2Node) triple -- that is seen a SECOND time with the same storages, data pointers, sizes and version counters is
+// the same immutable graph the first call saw, and is prepared then (one stream synchronisation + the packed copy, nnz x
+// 4 bytes, per width; never inside a stream capture).  Any change -- a version bump, a new storage at the old address,
+// another size or partSize -- forgets the library's plan for that address first (gnna_forget_graph) and starts over.  The
+// packed copy's own sample checksum stays as a second guard (writes that bypass torch).  GNNA_AUTO_PREPARE=0 turns it off.
+struct SeenGraph {
+    const void *ci = nullptr, *pp = nullptr, *p2n = nullptr;
+    c10::weak_intrusive_ptr<c10::StorageImpl> s_ci{c10::intrusive_ptr<c10::StorageImpl>()},
+        s_pp{c10::intrusive_ptr<c10::StorageImpl>()}, s_p2n{c10::intrusive_ptr<c10::StorageImpl>()};
+    uint32_t v_ci = 0, v_pp = 0, v_p2n = 0;
+    int64_t nnz = 0, parts = 0, rows = 0;
+    int partSize = 0, device = -1;
+    int sightings = 0;
+    uint64_t stamp = 0;
+    std::vector<int> dims_done;       // widths gnna_prepare_graph has been called for (successfully or not: one attempt each)
+};
+constexpr int kSeenGraphs = 16;
+SeenGraph g_seen[kSeenGraphs];
+std::mutex g_seen_mutex;
+uint64_t g_seen_clock = 0;
+std::atomic<long long> g_auto_prepared{0};
+
+bool same_storage(const c10::weak_intrusive_ptr<c10::StorageImpl> &w, const torch::Tensor &t)
+{
+    return !w.expired() && w._unsafe_get_target() == t.storage().unsafeGetStorageImpl();
+}
+
+void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_pointers, const torch::Tensor &part2Node,
+                int64_t rows, int partSize, int dim, void *stream)
+{
+    static const bool enabled = !(std::getenv("GNNA_AUTO_PREPARE") && std::atoi(std::getenv("GNNA_AUTO_PREPARE")) == 0);
+    if (!enabled || part2Node.size(0) == 0 || column_index.numel() == 0 || dim <= 0) return;
+    if (column_index.is_inference() || part_pointers.is_inference() || part2Node.is_inference()) return;   // (no version counter)
+    const void *ci = column_index.data_ptr();
+    const int device = column_index.get_device();
+    std::lock_guard<std::mutex> lock(g_seen_mutex);
+    SeenGraph *e = nullptr, *victim = &g_seen[0];
+    for (auto &g : g_seen) {
+        if (g.ci == ci && g.device == device) { e = &g; break; }
+        if (g.stamp < victim->stamp) victim = &g;
+    }
+    const bool same = e && e->pp == part_pointers.data_ptr() && e->p2n == part2Node.data_ptr() &&
+                      same_storage(e->s_ci, column_index) && same_storage(e->s_pp, part_pointers) &&
+                      same_storage(e->s_p2n, part2Node) && e->v_ci == column_index._version() &&
+                      e->v_pp == part_pointers._version() && e->v_p2n == part2Node._version() &&
+                      e->nnz == column_index.numel() && e->parts == part2Node.size(0) && e->rows == rows &&
+                      e->partSize == partSize;
+    if (!same) {
+        if (e) (void)gnna_forget_graph(static_cast<const int32_t *>(ci));     // another graph lives at this address now
+        else e = victim;
+        *e = SeenGraph();
+        e->ci = ci; e->pp = part_pointers.data_ptr(); e->p2n = part2Node.data_ptr();
+        e->s_ci = column_index.storage().getWeakStorageImpl();
+        e->s_pp = part_pointers.storage().getWeakStorageImpl();
+        e->s_p2n = part2Node.storage().getWeakStorageImpl();
+        e->v_ci = column_index._version(); e->v_pp = part_pointers._version(); e->v_p2n = part2Node._version();
+        e->nnz = column_index.numel(); e->parts = part2Node.size(0); e->rows = rows; e->partSize = partSize; e->device = device;
+    }
+    e->sightings++;
+    e->stamp = ++g_seen_clock;
+    if (e->sightings < 2) return;
+    for (int d : e->dims_done) if (d == dim) return;
+    int phases = 0;
+    const int rc = gnna_prepare_graph(static_cast<const int32_t *>(ci), part_pointers.data_ptr<int32_t>(),
+                                      part2Node.data_ptr<int32_t>(), e->parts, rows, rows, partSize, &dim, 1, &phases, stream);
+    if (rc == GNNA_ERR_UNSUPPORTED) return;        // inside a stream capture: try again at the next eager call
+    e->dims_done.push_back(dim);                   // (a failed attempt -- no memory for the copy -- is not repeated per call)
+    if (rc == GNNA_OK) g_auto_prepared.fetch_add(1);
+}
 
 // Runs one aggregation of `input` ([N, dim]) into a fresh tensor on input's device/stream.
 torch::Tensor aggregate(AggKind kind, const torch::Tensor &input, const torch::Tensor &row_pointers,
@@ -72,6 +150,7 @@ torch::Tensor aggregate(AggKind kind, const torch::Tensor &input, const torch::T
     float *y = out.data_ptr<float>();
     const int64_t n = input.size(0);
     const int dim = (int)input.size(1);
+    note_graph(column_index, part_pointers, part2Node, n, partSize, dim, stream);
 
     int rc = GNNA_OK;
     switch (kind) {
@@ -392,6 +471,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 #ifndef GNNA_SOURCE_HASH
 #define GNNA_SOURCE_HASH "unhashed"
 #endif
+    m.def("auto_prepared_graphs", []() { return (long long)g_auto_prepared.load(); },
+          "how many (graph, width) pairs the module prepared by itself on their second sighting (extension; see note_graph)");
     m.def("build_id", []() { return std::string("module ") + GNNA_SOURCE_HASH + ", library " + gnna_build_id(); },
           "source hashes this module and the libgnna.so it loaded were built from (extension)");
 }

@@ -20,10 +20,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, chunks, q, exchange="allgather"):
+def _worker(rank, world, port, chunks, q, exchange="allgather", backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    device_index = rank if backend == "nccl" else 0          # RCCL: one GPU per rank; gloo: both ranks share the box's GPU
+    if backend == "nccl":
+        torch.cuda.set_device(device_index)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import sys
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,7 +36,7 @@ def _worker(rank, world, port, chunks, q, exchange="allgather"):
         from gnnadvisor_osdi21_amd import _lib, graph
         from gnnadvisor_osdi21_amd.dist import (ShardedAggregator, ShardedGCNConv, ShardedGINConv,
                                                 balanced_row_splits, shard_csr)
-        torch.cuda.set_device(0)
+        torch.cuda.set_device(device_index)
         n, e, D, ps = 5000, 400000, 64, 32
         if exchange == "halo":      # low degree, id-local: few of the peer's rows are referenced at all
             n, e = 20000, 200000
@@ -118,11 +123,11 @@ def _worker(rank, world, port, chunks, q, exchange="allgather"):
         dist.destroy_process_group()
 
 
-def _two_ranks_once(chunks, exchange):
+def _two_ranks_once(chunks, exchange, backend="gloo"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunks, q, exchange)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunks, q, exchange, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]
@@ -141,6 +146,18 @@ def test_two_ranks_sharing_the_gpu(chunks, exchange):
     atomics land in; tests/test_relu_mask.py reproduces it deterministically.  The reference now takes the computed sign for
     the elements inside the bound, and a mismatch dumps every intermediate of the step.)"""
     res, codes = _two_ranks_once(chunks, exchange)
+    assert codes == [0, 0], (codes, res)
+    assert all(ok for _, ok, _ in res), res
+
+
+@pytest.mark.parametrize("chunks,exchange", [(1, "allgather"), (3, "allgather"), (1, "halo"), (3, "halo")])
+def test_two_ranks_over_rccl_on_two_gpus(chunks, exchange):
+    """The same strict step with a REAL two-rank RCCL group, one GPU per rank (all_gather_into_tensor / all_to_all_single
+    over xGMI, dW all-reduced, weights broadcast).  Skipped on a one-GPU box: it executes the moment the suite runs on a
+    multi-GPU node (VERDICT r4 task 6a)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL takes one device per rank)")
+    res, codes = _two_ranks_once(chunks, exchange, backend="nccl")
     assert codes == [0, 0], (codes, res)
     assert all(ok for _, ok, _ in res), res
 

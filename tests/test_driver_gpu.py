@@ -126,6 +126,10 @@ def test_bench_launches_its_own_ranks():
     assert legs["strong"]["row_bounds"][0] == 0 and legs["strong"]["row_bounds"][-1] == legs["strong"]["graph_nodes"]
     assert legs["config5"]["dim"] == 128 and legs["config5"]["bytes_received_per_rank_per_step"] > 0
     assert len(rec["config"]["ranks"]) == 2 and "stream_kernel" in rec["roofline"]["kernel"]
+    # the run checks itself: the communicator counted its ranks, and the two halves of a step are reported per rank
+    assert rec["config"]["communicator_ranks_counted"] == 2
+    assert len(rec["config"]["exchange_only_ms_per_rank"]) == 2 and len(rec["config"]["aggregate_only_ms_per_rank"]) == 2
+    assert rec["roofline"]["frac"] == rec["roofline"]["achieved"] / rec["roofline"]["peak"]
     assert set(rec["roofline"]["per_leg_kernels"]) == {"weak", "strong", "config5"}
 
 

@@ -82,7 +82,7 @@ def gcn_gin_reference(g, F, W1, W2, wgt, eps=0.5, H1_got=None, amb_tol=1e-5):
     H1_ref = Ahat @ (Fd @ W1d)
     mask_ref = H1_ref > 0
     ratio = np.abs(H1_ref) / np.maximum(H1_abs, 1e-300)
-    ambiguous = np.abs(H1_ref) <= amb_tol * H1_abs
+    ambiguous = (np.abs(H1_ref) <= amb_tol * H1_abs) & (H1_abs > 0)      # (an isolated node's exact zero is not a cancellation)
     if H1_got is not None:
         got = np.asarray(H1_got.detach().cpu().numpy() if hasattr(H1_got, "detach") else H1_got, dtype=np.float64)
         assert got.shape == H1_ref.shape, (got.shape, H1_ref.shape)
