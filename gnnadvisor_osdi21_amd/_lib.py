@@ -397,7 +397,9 @@ def agg_rect(mode, X, column_index, part_pointers, part2Node, num_out_rows, part
     """Destination-shard aggregation: X is [num_in_rows, dim] (all sources), out is
     [num_out_rows, dim]; column_index indexes X.  ``windows=(K, begin, end)`` aggregates only the
     edges whose source lies in windows [begin, end) of K equal source windows
-    (gnna_agg_rect_windows_f32: calls in increasing window order on one stream)."""
+    (gnna_agg_rect_windows_f32: stateless; the column ids of every neighbor-group must be in increasing order -- the
+    loader's CSR has them sorted -- else the call returns GNNA_ERR_UNSUPPORTED; the first call on a partition counts
+    the ids per window and synchronises the stream once)."""
     if not X.is_cuda:
         raise GnnaError("aggregation needs device tensors: there is no CPU path in libgnna")
     assert X.dtype == torch.float32 and X.is_contiguous() and X.dim() == 2

@@ -250,6 +250,14 @@ scale_rows_kernel(const float *__restrict__ X, int64_t ld_in, const float *__res
 
 // ---- host side ------------------------------------------------------------------------------
 
+// What a gather can touch of a source matrix of `num_in_rows` rows stored `ldx` floats apart: whole 128-byte lines of every
+// row (a gapped copy's gaps never enter a cache) -- the size every slicing decision goes by.  ONE formula for the launch and
+// for gnna_prepare_graph, so that the (phases, groups per chunk) pair prepared is the pair the launch looks up.
+static size_t gather_footprint_bytes(int64_t num_in_rows, int ldx, int dim)
+{
+    return (size_t)num_in_rows * (size_t)std::min(ldx, (std::max(dim, 4) * 4 + 127) / 128 * 32) * sizeof(float);
+}
+
 thread_local int t_last_phases = 1;
 thread_local int t_last_launches = 1;   // aggregation kernel launches of the calling thread's last call
 
@@ -595,7 +603,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
     const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);
     // what the gather can touch of it (whole 128-byte lines of every row; a gapped copy's gaps never enter a cache):
     // the size the slicing decisions go by
-    const size_t foot_bytes = (size_t)num_in_rows * (size_t)std::min(ldx, (std::max(dim, 4) * 4 + 127) / 128 * 32) * sizeof(float);
+    const size_t foot_bytes = gather_footprint_bytes(num_in_rows, ldx, dim);
     const bool wide = x_bytes > 0xffffffffull;
     if (!direct) {
         void *xs = nullptr;
@@ -888,7 +896,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
         const bool hot_rows = hot && raw <= ((size_t)1 << 30);
         const int ldx = pick_row_stride(t, dim, hot_rows, num_in_rows, true);
         const size_t x_bytes = (size_t)num_in_rows * (size_t)ldx * sizeof(float);
-        const size_t foot_bytes = (size_t)num_in_rows * (size_t)std::min(ldx, (dim * 4 + 127) / 128 * 32) * sizeof(float);
+        const size_t foot_bytes = gather_footprint_bytes(num_in_rows, ldx, dim);     // (the launch's own formula: same (B, G) pair looked up)
         if (hot_rows || t.gcn_prescale == 1 || ldx != dim) staged = std::max(staged, x_bytes);   // (GCN pre-scaling stages too)
         int B = 1;
         const bool can_slice = num_parts >= 1024 && num_in_rows >= 64 && foot_bytes >= ((size_t)2 << 20);
@@ -898,7 +906,9 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
                 B = choose_slices(plan.stats, foot_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,
                                   t.nonlocal_ids == 1);
         }
-        if (phases_out) phases_out[i] = std::max(1, B);
+        // (a width that runs in column blocks reports the largest phase count among its blocks, not the last block's)
+        const bool first_of_width = &wd == &widths.front() || (&wd - 1)->first != i;
+        if (phases_out) phases_out[i] = first_of_width ? std::max(1, B) : std::max(phases_out[i], std::max(1, B));
         if (B >= 2 && t.pack_ids != 2 && plan.handle) {   // (the plan is pinned here)
             const int32_t *ids = nullptr; const uint32_t *off = nullptr;
             // the kernel that will run at this width: the sweep (its own phase count, 64 groups per chunk) for the unweighted
@@ -914,7 +924,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
             if (rc == GNNA_OK && (!swept || t.gcn_prescale == 2))
                 rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(kWave, t.groups_per_chunk * B)), true, true, &ids, &off);
             if (rc != GNNA_OK) return rc;
-            if (phases_out && Bs >= 2) phases_out[i] = Bs;
+            if (phases_out && Bs >= 2) phases_out[i] = first_of_width ? Bs : std::max(phases_out[i], Bs);
         }
         if (t.deterministic == 1 && dim >= 4) {   // the deterministic schedule parks partial rows in the stream's scratch (slot 2)
             const int G_eff = std::max(1, std::min(kWave, t.groups_per_chunk * std::max(1, B)));

@@ -21,10 +21,11 @@ backend "nccl" == RCCL over xGMI):
 
 * pipelined exchange (``pipeline_chunks = K``): the blocks are cut into K sub-blocks, the gather buffer is
   sub-block-major, K asynchronous all-gathers are in flight at once and the part of the remote CSR whose
-  sources travel in piece k is aggregated as soon as piece k has arrived.  (Round 1 used one CSR and the
-  windowed entry ``gnna_agg_rect_windows_f32``, whose per-run cursors live in library scratch between the K
-  calls; the remote part is now split into K small CSRs at construction, each an ordinary stateless
-  aggregation on the streaming kernel whose column ids index the piece's own window of the receive buffer.)
+  sources travel in piece k is aggregated as soon as piece k has arrived: the remote part is split into K small
+  CSRs at construction, each an ordinary stateless aggregation whose column ids index the piece's own window of
+  the receive buffer.  (The library's windowed entry ``gnna_agg_rect_windows_f32`` is the alternative for ONE CSR
+  over K windows; since 0.4.0 it is stateless too -- per-window id counts instead of per-run cursors -- and
+  refuses groups whose ids are not in increasing order, because a window call takes id POSITIONS.)
   ``pipeline_chunks = 0`` decides K from a time model of the exchange (``exposed_exchange_us``).
 * halo exchange (``exchange="halo"``; ``"auto"`` picks it when it moves clearly fewer bytes): instead of
   whole blocks, every rank receives only the remote source rows its shard actually references.  The

@@ -57,7 +57,8 @@ def _worker(rank, world, port, chunks, q, exchange="allgather", backend="gloo"):
             for mode, eps in ((0, 1.0), (1, 1.0), (2, 0.5)):
                 y = agg.aggregate(Xl, mode, degrees_local=degl, epsilon=eps)
                 ref = oracle.csr_f64(mode, Xn, rpn, cin, degn, eps)[lo:hi]
-                scale = np.maximum(1.0, oracle.csr_f64(mode, np.abs(Xn), rpn, cin, degn, eps)[lo:hi])
+                # SAG / GIN: strict |err| <= 1e-4 * max(1, |ref|); the degree-weighted form: 1e-4 of the sum of |terms|
+                scale = np.maximum(1.0, oracle.csr_f64(mode, np.abs(Xn), rpn, cin, degn, eps)[lo:hi] if mode == 1 else np.abs(ref))
                 e_rows = (np.abs(y.cpu().numpy() - ref) / scale).max(axis=1)
                 err = float(e_rows.max())
                 worst = max(worst, err)

@@ -386,3 +386,56 @@ def test_reference_module_names_resolve_to_this_package():
             else:
                 sys.modules[k] = v
         importlib.invalidate_caches()
+
+
+def test_module_prepares_a_graph_by_itself_on_its_second_sighting():
+    """Callers of the six reference functions have no lifecycle call to make (GNNAdvisor.cpp:253-263), so the module keeps
+    track itself (gnna_torch.cpp: note_graph): the same (column_index, part_pointers, part2Node) tensors -- same storages,
+    data pointers, sizes and torch VERSION COUNTERS -- seen a second time are prepared (packed ids); an in-place write
+    through torch bumps the version, the plan is forgotten and the next calls see the new contents."""
+    import os
+    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
+        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    GNNA = load_extension()
+    g = graph.powerlaw_graph(40000, 6000000, 4000, seed=23, device="cuda")
+    ps, D = 64, 64
+    pp, p2n = GNNA.build_part(ps, g.row_pointers.cpu())
+    rp, ci, deg, ppd, p2nd = g.row_pointers, g.column_index.clone(), g.degrees, pp.cuda(), p2n.cuda()
+    X = torch.randn(g.num_nodes, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+
+    def ref_rows(rows, col):
+        out = []
+        for i in rows:
+            b, e = int(rp[i]), int(rp[i + 1])
+            out.append(X[col[b:e].long()].double().sum(0))
+        return torch.stack(out)
+    rows = [0, 1, 17, 12345, 39999, int(torch.argmax(rp[1:] - rp[:-1]))]
+    before = GNNA.auto_prepared_graphs()
+    packed0 = _lib.runtime_counters()["packed_launches"]
+    y1 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    assert GNNA.auto_prepared_graphs() == before                          # first sighting: nothing yet
+    y2 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    assert GNNA.auto_prepared_graphs() == before + 1                      # second sighting: prepared for this width
+    y3 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    assert GNNA.auto_prepared_graphs() == before + 1
+    if _lib.last_num_phases() > 1:
+        assert _lib.runtime_counters()["packed_launches"] > packed0       # the sliced schedule now reads the packed copy
+    want = ref_rows(rows, ci)
+    for y in (y1, y2, y3):
+        err = (y[rows].double() - want).abs() / want.abs().clamp_min(1.0)
+        assert float(err.max()) <= 1e-4
+    # an in-place write through torch: row 17's first neighbour becomes node 3 -> version bump -> plan forgotten, new contents used
+    b17 = int(rp[17])
+    old = int(ci[b17])
+    ci[b17] = 3 if old != 3 else 4
+    y4 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    want4 = ref_rows(rows, ci)
+    assert float(((y4[rows].double() - want4).abs() / want4.abs().clamp_min(1.0)).max()) <= 1e-4
+    assert float((y4[17] - y3[17]).abs().max()) > 0                       # (the change is visible)
+    y5 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)
+    assert GNNA.auto_prepared_graphs() == before + 2                      # the modified graph, seen twice, is prepared anew
+    assert float(((y5[rows].double() - want4).abs() / want4.abs().clamp_min(1.0)).max()) <= 1e-4
+    # another width on the same graph is prepared at its own second call
+    X16 = X[:, :16].contiguous()
+    GNNA.SAG(X16, rp, ci, deg, ppd, p2nd, ps, 16, 4)
+    assert GNNA.auto_prepared_graphs() == before + 3                      # (the graph itself is already known: third sighting)

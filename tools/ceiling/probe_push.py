@@ -17,7 +17,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
 from gnnadvisor_osdi21_amd import _lib, graph  # noqa: E402
 
-lib = ctypes.CDLL(os.path.join(here, "libpush.so"))
+lib = ctypes.CDLL(os.path.join(here, os.environ.get("PUSH_SO", "libpush.so")))
 lib.push_launch.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int]
 R = lib.push_rows_per_wave()
 WAVES, BLOCK = 16, 256
@@ -76,11 +76,13 @@ def pack(g, S):
     g_sorted, p2 = torch.sort(grp, stable=True)
     cnt = torch.bincount(g_sorted, minlength=nblocks * WAVES)
     padded = (cnt + 7) // 8 * 8
-    ent_off = torch.zeros(nblocks * WAVES + 1, dtype=torch.long, device=dev)
-    ent_off[1:] = torch.cumsum(padded, 0)
+    ent_off = torch.zeros(nblocks * WAVES + 1 + 2 * WAVES, dtype=torch.long, device=dev)
+    ent_off[1:nblocks * WAVES + 1] = torch.cumsum(padded, 0)
+    ent_off[nblocks * WAVES + 1:] = ent_off[nblocks * WAVES]       # (the kernels look one block past a set's last)
     gstart = torch.cumsum(cnt, 0) - cnt
     within = torch.arange(nnz, device=dev) - gstart[g_sorted]
     total = int(ent_off[-1])
+    per_block_entries = padded.view(nblocks, WAVES).sum(1)
     ent = torch.full((total + 16,), R, dtype=torch.int16, device=dev)                 # dummy: slot 0, register R
     val = (slot[p2] << 8 | reg_of_row[e_dst[p2]]).to(torch.int32)
     val = torch.where(val >= 32768, val - 65536, val).to(torch.int16)                 # (16-bit pattern)
@@ -88,7 +90,7 @@ def pack(g, S):
     per_blk = cnt.view(nblocks, WAVES).float()
     stats = dict(sets=S, max_rows_per_set=int(rows_per_set.max()), distinct_per_edge=round(uniq.numel() / nnz, 4),
                  blocks=nblocks, entries_padded_over_edges=round(total / nnz, 4),
-                 mean_edges_per_block_wave=round(float(per_blk.mean()), 2),
+                 mean_edges_per_block_wave=round(float(per_blk.mean()), 2), max_entries_per_block=int(per_block_entries.max()),
                  mean_of_block_max_over_mean=round(float((per_blk.max(1).values / per_blk.mean(1).clamp_min(1e-9)).mean()), 3),
                  packed_MB=round((src_ids.numel() * 4 + ent.numel() * 2 + ent_off.numel() * 4 + store_row.numel() * 4) / 1e6, 1))
     return dict(src_ids=src_ids, blk_off=blk_off.to(torch.int32), ent_off=ent_off.to(torch.int32).contiguous(),
@@ -191,3 +193,17 @@ res["library_prepared_ms"] = timed(lambda: _lib.agg_ld(0, X, g.column_index, ppd
 res["library_phases"] = _lib.last_num_phases()
 res["push_G_edges_per_s"] = round(nnz / res["push_ms"] / 1e6, 2)
 print(json.dumps(res), flush=True)
+
+# timing-only variants of the kernel (push_probe.hip built with -DPUSH_ABLATE=..., WRONG results): which part costs what
+for name in [v for v in os.environ.get("PUSH_VARIANTS", "").split(",") if v]:
+    so = os.path.join(here, f"libpush_{name}.so")
+    if not os.path.exists(so):
+        continue
+    vlib = ctypes.CDLL(so)
+    vlib.push_launch.argtypes = lib.push_launch.argtypes
+
+    def vpush():
+        rc = vlib.push_launch(X.data_ptr(), Y.data_ptr(), P["src_ids"].data_ptr(), P["blk_off"].data_ptr(), P["ent_off"].data_ptr(),
+                              P["entries"].data_ptr(), P["store_row"].data_ptr(), X.stride(0), S)
+        assert rc == 0, rc
+    print(json.dumps({"variant": name, "ms": timed(vpush)}), flush=True)

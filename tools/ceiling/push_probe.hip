@@ -9,6 +9,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// PUSH_ABLATE (timing experiments of this probe only, WRONG results): 1 = rows are not read from LDS (constants added),
+// 2 = every add goes to register 0 (no s_set_gpr_idx_idx), 4 = the entries are not re-read (one group reused), 8 = no row
+// stream (no global loads, no parking), 16 = no barrier per block
+#ifndef PUSH_ABLATE
+#define PUSH_ABLATE 0
+#endif
 #ifndef PUSH_R
 #define PUSH_R 72                       // accumulator rows per wavefront: v[128 - R .. 127]
 #endif
@@ -86,8 +92,10 @@ void push_kernel(const PushParams p)
     fetch_ids(1);
     __syncthreads();
     for (int b = 0; b < nblk; b++) {
+        if (!(PUSH_ABLATE & 8)) {
         fetch_rows();                                   // rows of block b + 1 (their ids arrived during block b - 1)
         fetch_ids(b + 2);
+        }
         const float *buf = stage + (b & 1) * (kBlockRows * 64) + lane;
         const size_t eo = (size_t)(b0 + b) * kWaves + wave;
         const uint32_t e_lo = ent_off[eo], e_hi = ent_off[eo + 1];
@@ -96,12 +104,25 @@ void push_kernel(const PushParams p)
         uint32_t n0 = ep[0], n1 = ep[1], n2 = ep[2], n3 = ep[3];
         for (uint32_t e = e_lo; e < e_hi; e += 8) {
             const uint32_t w0 = n0, w1 = n1, w2 = n2, w3 = n3;
+            if (!(PUSH_ABLATE & 4)) {
             ep += 4;
             n0 = ep[0]; n1 = ep[1]; n2 = ep[2]; n3 = ep[3];        // (reads up to 16 bytes past the last group: the array is padded)
+            }
+#if PUSH_ABLATE & 1
+            const float t0 = __int_as_float(w0 + lane), t1 = __int_as_float(w0 * 3 + lane), t2 = __int_as_float(w1 + lane), t3 = __int_as_float(w1 * 3 + lane),
+                        t4 = __int_as_float(w2 + lane), t5 = __int_as_float(w2 * 3 + lane), t6 = __int_as_float(w3 + lane), t7 = __int_as_float(w3 * 3 + lane);
+#else
             const float t0 = buf[(w0 >> 8 & 0xff) * 64], t1 = buf[(w0 >> 24) * 64];
             const float t2 = buf[(w1 >> 8 & 0xff) * 64], t3 = buf[(w1 >> 24) * 64];
             const float t4 = buf[(w2 >> 8 & 0xff) * 64], t5 = buf[(w2 >> 24) * 64];
             const float t6 = buf[(w3 >> 8 & 0xff) * 64], t7 = buf[(w3 >> 24) * 64];
+#endif
+#if PUSH_ABLATE & 2
+            asm volatile("v_add_f32 " ACC0 ", " ACC0 ", %0\n\tv_add_f32 " ACC0 ", " ACC0 ", %1\n\tv_add_f32 " ACC0 ", " ACC0 ", %2\n\t"
+                         "v_add_f32 " ACC0 ", " ACC0 ", %3\n\tv_add_f32 " ACC0 ", " ACC0 ", %4\n\tv_add_f32 " ACC0 ", " ACC0 ", %5\n\t"
+                         "v_add_f32 " ACC0 ", " ACC0 ", %6\n\tv_add_f32 " ACC0 ", " ACC0 ", %7"
+                         :: "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7) : ACC_CLOBBERS);
+#else
             asm volatile("s_set_gpr_idx_on %8, gpr_idx(SRC0,DST)\n\tv_add_f32 " ACC0 ", " ACC0 ", %0\n\t"
                          "s_set_gpr_idx_idx %9\n\tv_add_f32 " ACC0 ", " ACC0 ", %1\n\t"
                          "s_set_gpr_idx_idx %10\n\tv_add_f32 " ACC0 ", " ACC0 ", %2\n\t"
@@ -113,9 +134,10 @@ void push_kernel(const PushParams p)
                          :: "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7),
                             "s"(w0 & 0xff), "s"(w0 >> 16 & 0xff), "s"(w1 & 0xff), "s"(w1 >> 16 & 0xff),
                             "s"(w2 & 0xff), "s"(w2 >> 16 & 0xff), "s"(w3 & 0xff), "s"(w3 >> 16 & 0xff) : ACC_CLOBBERS);
+#endif
         }
-        park((b + 1) & 1);
-        __syncthreads();
+        if (!(PUSH_ABLATE & 8)) park((b + 1) & 1);
+        if (!(PUSH_ABLATE & 16)) __syncthreads();
     }
     const int32_t *rows = p.store_row + ((size_t)s * kWaves + wave) * kR;
     for (int i = 0; i < kR; i++) {

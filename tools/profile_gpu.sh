@@ -10,7 +10,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 BENCH="python $R/bench.py --steps 20 --warmup 5 --headline-only $*"
-PBENCH="python $R/bench.py --steps 3 --warmup 1 --headline-only $*"
+PBENCH="python $R/bench.py --steps 3 --warmup 4 --headline-only $*"   # (a drop-in graph is prepared at its second call: steady from call 3)
 rocprofv3 --kernel-trace --stats -T -d $OUT/trace -o bench -f csv -- $BENCH > $OUT/trace_stdout.log 2>&1
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM" \
