@@ -109,14 +109,41 @@ int fail(int code, const char *fmt, ...)
     va_end(ap);
     return code;
 }
+
+int host_thread_budget(int cap)
+{
+    static const int granted = [] {
+        unsigned hw = std::thread::hardware_concurrency();
+        int n = (int)(hw ? hw : 1u);
+        double quota = 0.0;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2: "<quota|max> <period>"
+            char q[64] = {0};
+            double period = 0.0;
+            if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) quota = std::atof(q) / period;
+            std::fclose(f);
+        } else if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            double q = 0.0, period = 0.0;
+            if (std::fscanf(fq, "%lf", &q) != 1) q = 0.0;
+            std::fclose(fq);
+            if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(fp, "%lf", &period) != 1) period = 0.0;
+                std::fclose(fp);
+            }
+            if (q > 0 && period > 0) quota = q / period;
+        }
+        if (quota >= 1.0) n = std::min(n, (int)quota);
+        if (const char *e = std::getenv("GNNA_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n = v; }
+        return std::max(1, n);
+    }();
+    return std::max(1, std::min(granted, cap));
+}
 }  // namespace gnna
 
 namespace {
 template <typename F>
 void parallel_rows(int64_t n, F &&fn)
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    int64_t nt = std::max<int64_t>(1, std::min<int64_t>(hw ? hw : 1, std::min<int64_t>(64, n / 4096 + 1)));
+    int64_t nt = std::max<int64_t>(1, std::min<int64_t>(gnna::host_thread_budget(64), n / 4096 + 1));
     if (nt == 1) { fn(0, n); return; }
     std::vector<std::thread> th;
     const int64_t step = (n + nt - 1) / nt;
@@ -325,8 +352,7 @@ int gnna_row_counts_i64(const int32_t *rows, int64_t num_edges, int64_t num_node
         return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad row count arguments");
     // slabs of the edge list counted in parallel with atomic increments into the ONE counts array (an edge list of > 2^31
     // entries is fine): no per-thread histogram -- 16 of them were 14 GB of transient memory at papers100M's 111 M rows
-    unsigned hw = std::thread::hardware_concurrency();
-    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(hw ? hw : 1, 32), num_edges / (1 << 22) + 1));
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(gnna::host_thread_budget(32), num_edges / (1 << 22) + 1));
     std::vector<int64_t> bad((size_t)nt, -1);
     std::vector<std::thread> th;
     const int64_t step = (num_edges + nt - 1) / nt;

@@ -17,6 +17,12 @@ namespace gnna {
 // Records a formatted message for gnna_last_error() on this thread and returns `code`.
 int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+// Host worker threads the library's CPU passes (CSR builder, renumbering) should start: the hardware threads, capped by the
+// CPUs the container is actually GRANTED (cgroup v2 cpu.max / v1 cfs quota) and by GNNA_HOST_THREADS.  The GPU boxes show
+// 256 hardware threads and grant 16 CPUs: 64 threads there spend most of every scheduling period throttled (round 5: the
+// community renumbering of the Reddit-like graph took 90 s with 64 threads on a 16-CPU quota).
+int host_thread_budget(int cap);
+
 // Per-graph hints registered with gnna_set_graph_hints(), keyed by the column_index pointer of the
 // call; overrides tune->avg_degree / nonlocal_ids when there is an entry, and tune->column_phases when a
 // measured schedule for this feature width was registered with gnna_set_graph_phases().  (gnna_host.cpp)

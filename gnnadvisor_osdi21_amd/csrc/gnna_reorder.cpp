@@ -53,11 +53,7 @@ void parallel_nodes(int64_t n, int threads, F &&fn)
     for (auto &t : th) t.join();
 }
 
-int host_threads()
-{
-    unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(hw ? hw : 1u, 64u));
-}
+int host_threads() { return gnna::host_thread_budget(64); }      // (the CPUs the container is granted, not the ones it sees)
 
 }  // namespace
 
@@ -154,24 +150,36 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     std::vector<int32_t> bci;
     {
         std::vector<uint8_t> keep(ci.size(), 0);
+        // Every undirected pair once (u < v), from u's side: u's neighbours are marked in a per-thread bitmap (n bits: cache
+        // resident), v's list is then a sequential scan that stops at `need` marked entries, and the answer is written to
+        // both directions (the reverse entry by binary search in v's sorted list).  Same result as merging the two sorted
+        // lists per directed edge -- the support and `need` are symmetric -- at about a fifth of the time on graphs with rows
+        // of hundreds of edges (round 5: the merge made the Reddit-like graph's renumbering the longest leg of bench.py).
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            std::vector<uint64_t> mark((size_t)((n + 63) / 64), 0);
             for (int64_t u = lo; u < hi; u++) {
                 const int64_t ub = rp[(size_t)u], ue = rp[(size_t)u + 1];
                 if (ue - ub > hub) continue;
+                for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] |= 1ull << (ci[(size_t)k] & 63);
                 for (int64_t k = ub; k < ue; k++) {
                     const int32_t v = ci[(size_t)k];
+                    if (v <= u) continue;
                     const int64_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
-                    if (ve - vb > hub || v == u) continue;
+                    if (ve - vb > hub) continue;
                     const int32_t need = std::max<int32_t>(T, (int32_t)std::ceil(3.0 * chance * (double)(ue - ub) * (double)(ve - vb)));
-                    int64_t i = ub, j = vb; int32_t common = 0;
-                    while (i < ue && j < ve && common < need) {
-                        const int32_t a = ci[(size_t)i], b2 = ci[(size_t)j];
-                        common += a == b2;
-                        i += a <= b2;
-                        j += b2 <= a;
+                    int32_t common = 0;
+                    for (int64_t j = vb; j < ve && common < need; j++) {
+                        const int32_t x = ci[(size_t)j];
+                        common += (int32_t)((mark[(size_t)x >> 6] >> (x & 63)) & 1ull);
                     }
-                    keep[(size_t)k] = common >= need;
+                    if (common >= need) {
+                        keep[(size_t)k] = 1;
+                        const int32_t *vl = ci.data() + vb, *vend = ci.data() + ve;
+                        const int64_t back = std::lower_bound(vl, vend, (int32_t)u) - vl;    // (u is in v's list: the adjacency is symmetric)
+                        keep[(size_t)(vb + back)] = 1;
+                    }
                 }
+                for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] = 0;
             }
         });
         for (int64_t u = 0; u < n; u++) {
