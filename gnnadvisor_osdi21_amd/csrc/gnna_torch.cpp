@@ -83,6 +83,12 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
     const void *ci = column_index.data_ptr();
     const int device = column_index.get_device();
     std::lock_guard<std::mutex> lock(g_seen_mutex);
+    // graphs whose tensors are gone: their plans (and packed copies: nnz x 4 bytes each) must not stay pinned in the library
+    for (auto &g : g_seen)
+        if (g.ci && (g.s_ci.expired() || g.s_pp.expired() || g.s_p2n.expired())) {
+            if (!g.dims_done.empty()) (void)gnna_forget_graph(static_cast<const int32_t *>(g.ci));
+            g = SeenGraph();
+        }
     SeenGraph *e = nullptr, *victim = &g_seen[0];
     for (auto &g : g_seen) {
         if (g.ci == ci && g.device == device) { e = &g; break; }
@@ -95,8 +101,12 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
                       e->nnz == column_index.numel() && e->parts == part2Node.size(0) && e->rows == rows &&
                       e->partSize == partSize;
     if (!same) {
-        if (e) (void)gnna_forget_graph(static_cast<const int32_t *>(ci));     // another graph lives at this address now
-        else e = victim;
+        if (e) {
+            (void)gnna_forget_graph(static_cast<const int32_t *>(ci));     // another graph lives at this address now
+        } else {
+            e = victim;                                                    // (the least recently seen entry makes room:
+            if (e->ci && !e->dims_done.empty()) (void)gnna_forget_graph(static_cast<const int32_t *>(e->ci));   // unpin what it pinned)
+        }
         *e = SeenGraph();
         e->ci = ci; e->pp = part_pointers.data_ptr(); e->p2n = part2Node.data_ptr();
         e->s_ci = column_index.storage().getWeakStorageImpl();
