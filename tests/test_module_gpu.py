@@ -469,3 +469,44 @@ def test_a_new_graph_at_a_reused_address_is_a_new_graph():
         gc.collect()
     # (informational: with the caching allocator the three graphs usually share their addresses)
     print("column_index addresses:", [hex(p) for p in seen_ptrs])
+
+
+def test_second_sighting_inside_a_stream_capture_is_deferred():
+    """The module must neither synchronise nor allocate while a stream is being captured: a graph whose SECOND sighting
+    happens inside a capture is not prepared there (gnna_prepare_graph refuses, the module carries on), the captured call
+    runs on the plan the first, eager call built, and the next eager call prepares; a replay of the captured graph stays
+    correct before and after that."""
+    import os
+    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
+        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    GNNA = load_extension()
+    g = graph.powerlaw_graph(40000, 6000000, 4000, seed=29, device="cuda")
+    ps, D = 64, 64
+    pp, p2n = GNNA.build_part(ps, g.row_pointers.cpu())
+    rp, ci, deg, ppd, p2nd = g.row_pointers, g.column_index, g.degrees, pp.cuda(), p2n.cuda()
+    X = torch.randn(g.num_nodes, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    rows = [0, 9, 4321, g.num_nodes - 1, int(torch.argmax(rp[1:] - rp[:-1]))]
+    want = torch.stack([X[ci[int(rp[i]):int(rp[i + 1])].long()].double().sum(0) for i in rows])
+
+    def close(y):
+        return float(((y[rows].double() - want).abs() / want.abs().clamp_min(1.0)).max()) <= 1e-4
+    side = torch.cuda.Stream()
+    before = GNNA.auto_prepared_graphs()
+    with torch.cuda.stream(side):
+        y0 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)             # first sighting, eager: the library counts the partition
+    side.synchronize()
+    assert close(y0)
+    hg = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(hg, stream=side):
+            yc = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)          # second sighting: inside the capture
+    assert GNNA.auto_prepared_graphs() == before                         # ... nothing was prepared there
+    hg.replay()
+    torch.cuda.synchronize()
+    assert close(yc)
+    y2 = GNNA.SAG(X, rp, ci, deg, ppd, p2nd, ps, 32, 4)                  # eager again: now it is prepared
+    assert GNNA.auto_prepared_graphs() == before + 1 and close(y2)
+    yc.fill_(float("nan"))
+    hg.replay()                                                          # the captured launch still reads valid buffers
+    torch.cuda.synchronize()
+    assert close(yc)
