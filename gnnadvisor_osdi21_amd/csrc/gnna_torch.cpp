@@ -90,12 +90,13 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
             g = SeenGraph();
         }
     SeenGraph *e = nullptr, *victim = &g_seen[0];
+    // (an entry is one PARTITION of a graph -- the three arrays together: two partitions over one column_index, e.g. two
+    // neighbor-group sizes, are two entries and do not evict each other call by call)
     for (auto &g : g_seen) {
-        if (g.ci == ci && g.device == device) { e = &g; break; }
+        if (g.ci == ci && g.pp == part_pointers.data_ptr() && g.p2n == part2Node.data_ptr() && g.device == device) { e = &g; break; }
         if (g.stamp < victim->stamp) victim = &g;
     }
-    const bool same = e && e->pp == part_pointers.data_ptr() && e->p2n == part2Node.data_ptr() &&
-                      same_storage(e->s_ci, column_index) && same_storage(e->s_pp, part_pointers) &&
+    const bool same = e && same_storage(e->s_ci, column_index) && same_storage(e->s_pp, part_pointers) &&
                       same_storage(e->s_p2n, part2Node) && e->v_ci == column_index._version() &&
                       e->v_pp == part_pointers._version() && e->v_p2n == part2Node._version() &&
                       e->nnz == column_index.numel() && e->parts == part2Node.size(0) && e->rows == rows &&

@@ -510,3 +510,32 @@ def test_second_sighting_inside_a_stream_capture_is_deferred():
     hg.replay()                                                          # the captured launch still reads valid buffers
     torch.cuda.synchronize()
     assert close(yc)
+
+
+def test_two_partitions_over_one_column_index_do_not_evict_each_other():
+    """A graph aggregated with two neighbor-group sizes in turn (two `build_part` results over the same column_index): each
+    partition is its own entry of the module's memory, each is prepared at ITS second sighting, neither forgets the other."""
+    import os
+    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
+        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    GNNA = load_extension()
+    g = graph.powerlaw_graph(40000, 6000000, 4000, seed=37, device="cuda")
+    rp, ci, deg = g.row_pointers, g.column_index, g.degrees
+    parts = {}
+    for ps in (32, 64):
+        pp, p2n = GNNA.build_part(ps, rp.cpu())
+        parts[ps] = (pp.cuda(), p2n.cuda())
+    X = torch.randn(g.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
+    rows = [0, 3, 999, g.num_nodes - 1, int(torch.argmax(rp[1:] - rp[:-1]))]
+    want = torch.stack([X[ci[int(rp[i]):int(rp[i + 1])].long()].double().sum(0) for i in rows])
+    before = GNNA.auto_prepared_graphs()
+    builds0 = _lib.runtime_counters()["plan_builds"]
+    for trip in range(4):
+        for ps in (32, 64):
+            y = GNNA.SAG(X, rp, ci, deg, parts[ps][0], parts[ps][1], ps, 32, 4)
+            assert float(((y[rows].double() - want).abs() / want.abs().clamp_min(1.0)).max()) <= 1e-4, (trip, ps)
+        if trip == 0:
+            assert GNNA.auto_prepared_graphs() == before                  # one sighting each
+        else:
+            assert GNNA.auto_prepared_graphs() == before + 2              # both prepared at their second sighting, once
+    assert _lib.runtime_counters()["plan_builds"] - builds0 <= 2          # one counting pass per partition, not one per call
