@@ -7,3 +7,4 @@ cd "$(dirname "$0")"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared push_probe.hip -o libpush.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared push_probe2.hip -o libpush2.so
 for r in 72 64; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DPUSH_R=$r push_probe3.hip -o libpush3_r$r.so; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared push_probe4.hip -o libpush4.so

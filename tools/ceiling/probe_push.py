@@ -20,7 +20,8 @@ from gnnadvisor_osdi21_amd import _lib, graph  # noqa: E402
 lib = ctypes.CDLL(os.path.join(here, os.environ.get("PUSH_SO", "libpush.so")))
 lib.push_launch.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_int, ctypes.c_int]
 R = lib.push_rows_per_wave()
-WAVES, BLOCK = 16, 256
+WAVES = 16
+BLOCK = lib.push_block_rows() if hasattr(lib, "push_block_rows") else 256
 dev = torch.device("cuda:0")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "reddit-like"
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 256
