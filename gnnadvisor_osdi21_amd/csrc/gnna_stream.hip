@@ -522,23 +522,38 @@ stream_kernel(const StreamParams p)
                     else return *reinterpret_cast<const MT *>(ap);
                 };
                 const int a_src = (cvalid ? dcol - d0 : 0) << 2;      // (byte index of the lane that holds float dcol)
+                // Round 5: consecutive loads of one destination row share its piece.  The loads of a row segment are adjacent
+                // in the list (the pieces of a row's groups are merged), so the row is fetched -- and, for rows of <= 64 floats,
+                // permuted into place -- at the segment's FIRST load only (and at the first load of a round); `fresh` is a
+                // scalar comparison of two lanes' rows, the branch is wave-uniform.  On the Reddit-like graph a segment is
+                // ~8 loads: seven of eight fetches and permute groups are gone.
+                auto fresh = [&](int j) -> bool {
+                    return j == 0 || __builtin_amdgcn_readlane(row_j, j) != __builtin_amdgcn_readlane(row_j, j - 1);
+                };
                 AT a[U];
+                VT av_keep = vzero<4>();
 #pragma unroll
-                for (int u = 0; u < U; u++) { a[u] = a_load(u); v[u] = *row_ptr(offs[u * RPI + slot]); }
+                for (int u = 0; u < U; u++) {
+                    if (fresh(u)) a[u] = a_load(u);
+                    v[u] = *row_ptr(offs[u * RPI + slot]);
+                }
                 auto dot_of = [&](int u, int j) {
-                    VT av;
-                    if constexpr (SHARED_A) {
+                    if (fresh(j)) {
+                        VT av;
+                        if constexpr (SHARED_A) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                av[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(a_src + 4 * k, __float_as_int(a[u])));
+                        } else {
+                            av = a[u];
+                        }
+                        // components that overlap the previous piece (ragged D) and lanes past the row end do not count
 #pragma unroll
                         for (int k = 0; k < 4; k++)
-                            av[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(a_src + 4 * k, __float_as_int(a[u])));
-                    } else {
-                        av = a[u];
+                            if (!cvalid || k < shift) av[k] = 0.f;
+                        av_keep = av;
                     }
-                    // components that overlap the previous piece (ragged D) and lanes past the row end do not count
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (!cvalid || k < shift) av[k] = 0.f;
-                    const VT prod = v[u] * av;
+                    const VT prod = v[u] * av_keep;
                     float dot = lane_group_sum<LPR>((prod[0] + prod[1]) + (prod[2] + prod[3]));
                     // parked in LDS (the round's list slot of the edge) and written out after the round: a
                     // 16-byte store per load in the middle of the stream would sit in the ring's vmcnt queue
@@ -553,7 +568,7 @@ stream_kernel(const StreamParams p)
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         dot_of(u, b * U + u);
-                        a[u] = a_load(jn + u);
+                        if (fresh(jn + u)) a[u] = a_load(jn + u);
                         v[u] = *row_ptr(nn[u]);
                     }
                 }
