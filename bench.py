@@ -1214,6 +1214,14 @@ def run_single(args, result_fd):
             "roofline": roofline_record(w5, p5["main_ms"], p5["prologue_ms"], traffic.get(id(w5))),
         }
     if others:
+        # the legs repeat long constant strings of the headline's records: say them once (the line stays well under the
+        # size of a pipe buffer)
+        for leg in others.values():
+            for key in ("frac_definition", "traffic_detail", "traffic_source"):
+                leg["roofline"].pop(key, None)
+            leg["verification"].pop("bound_form", None)
+            if "hbm_read_rate_note" in leg["roofline"] and leg["roofline"].get("ceiling") != "hbm":
+                leg["roofline"].pop("hbm_read_rate_note")
         rec["roofline"]["other_workloads"] = others
     if extras and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.Xc.cpu(), w.pp, w.p2n, args.dim)
