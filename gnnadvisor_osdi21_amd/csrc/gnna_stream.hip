@@ -941,7 +941,8 @@ int get_slice_plan(DeviceState *ds, hipStream_t stream, const int32_t *column_in
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(stream, &cap);
         if (cap != hipStreamCaptureStatusNone) return GNNA_OK;   // no allocation / sync while capturing
-        if (!hit && !pin && want_stats && g_skip_builds > 0) {   // partitions keep changing: do not count this one
+        // (never for the windowed entry: its window counts are not an optimisation, the call cannot run without them)
+        if (!hit && !pin && want_stats && window_rows == 0 && g_skip_builds > 0) {   // partitions keep changing: do not count this one
             g_skip_builds--;
             count_event(CTR_BACKOFF_SKIPS);
             return GNNA_OK;

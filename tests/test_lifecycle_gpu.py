@@ -184,3 +184,30 @@ def test_deterministic_schedule_is_bit_reproducible(dim, phases, prescale):
         assert torch.equal(y1, (rp[1:] - rp[:-1]).float()[:, None].expand(-1, dim))
     finally:
         _lib.reset_tuning()
+
+
+def test_windowed_aggregation_is_not_refused_by_the_plan_backoff():
+    """The library stops building automatic plans for a while when partitions never come back (eight plans in a row evicted
+    unused).  The windowed entry's per-window id counts are not such an optimisation -- the call cannot run without them
+    -- and must be built regardless (round 5: a fuzz run under GNNA_TUNE=PHASES=32 got 'cannot be built inside a stream
+    capture' from a windowed call that was merely inside the back-off)."""
+    try:
+        _lib.set_tuning(column_phases=4)
+        for i in range(45):                                              # 45 one-shot partitions: the table holds 32
+            g, X, pp, p2n = make_case(600, 20000, 16, 8, seed=900 + i, kind="powerlaw")
+            Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+            _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 8, 32, 4)
+        torch.cuda.synchronize()
+        _lib.reset_tuning()
+        assert _lib.runtime_counters()["plan_builds"] > 0
+        g, X, pp, p2n = make_case(3000, 90000, 32, 16, seed=990, kind="powerlaw")
+        Xd, ci, ppd, p2nd = dev(X, g.column_index, pp, p2n)
+        out = torch.zeros(g.num_nodes, 32, device="cuda")
+        K = 3
+        for k in range(K):                                               # windows in order, accumulating
+            _lib.agg_rect(0, Xd, ci, ppd, p2nd, g.num_nodes, 16, out=out, accumulate=k > 0, windows=(K, k, k + 1))
+        torch.cuda.synchronize()
+        ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+        assert_close_f64(out.cpu().numpy(), ref, what="windowed after the back-off")
+    finally:
+        _lib.reset_tuning()
