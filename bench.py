@@ -1017,6 +1017,7 @@ def leg_record(w, elapsed, prof, steps, check, traffic, what):
            "partSize": w.ps, "num_parts": w.P, "column_phases_used": w.phases,
            "aggregation": {"sag": "SAG (unweighted sum)", "gin": "GIN (eps = 0.5 scaled sum)"}.get(getattr(w, "kind", "sag")),
            "lifecycle": getattr(w, "lifecycle", None), "node_order": getattr(w, "order", None),
+           "avg_edge_span": float(getattr(g, "avg_edgeSpan", float("nan"))),      # mean |src - dst| (dataset.py:99-100, the Decider's reorder rule)
            "verified": check["verified"], "verification": check,
            "roofline": roofline_record(w, prof["main_ms"], prof["prologue_ms"], traffic)}
     if getattr(w, "reorder_seconds", None) is not None:
@@ -1078,7 +1079,7 @@ def run_single(args, result_fd):
         class _G:
             pass
         gg = _G()
-        gg.nnz, gg.num_nodes = wl.g.nnz, wl.g.num_nodes
+        gg.nnz, gg.num_nodes, gg.avg_edgeSpan = wl.g.nnz, wl.g.num_nodes, wl.g.avg_edgeSpan
         wl.g, wl.Xc, wl.X, wl.out, wl.ppd, wl.p2nd, wl.pp, wl.p2n = gg, None, None, None, None, None, None, None
         free()
 
@@ -1116,6 +1117,10 @@ def run_single(args, result_fd):
                     8, 3, config=cfg_name, dim=64, locality=0.9, order="scrambled")
             run_leg(f"{tag}_hidden_locality_renumbered", f"the same graph after gnna_reorder_community_i32 (locality-friendly order), SAG D = 64",
                     8, 3, config=cfg_name, dim=64, locality=0.9, order="renumbered", perm_file=pf)
+            # the order the generator planted the communities in: what a perfect renumbering of this graph would find (Rabbit Order
+            # itself cannot be built here -- boost / numa / tcmalloc -- so this is the yardstick the native renumbering is held to)
+            run_leg(f"{tag}_hidden_locality_planted", f"the same graph in the generator's own community order (yardstick for the renumbering), SAG D = 64",
+                    8, 3, config=cfg_name, dim=64, locality=0.9, order="generator")
     # BASELINE config 5 in its true per-rank shape (rank 0 of 8; the 56.9 GB all-gather buffer, then the compact halo
     # buffer the automatic exchange takes): one after the other -- each keeps the global features resident
     fives = []
@@ -1190,6 +1195,7 @@ def run_single(args, result_fd):
         others[name] = leg_record(wl, e, p, k, chk, traffic.get(id(wl)), what)
     for tag in ("config3", "config4"):
         a_, b_ = others.get(f"{tag}_hidden_locality_scrambled"), others.get(f"{tag}_hidden_locality_renumbered")
+        c_ = others.get(f"{tag}_hidden_locality_planted")
         if a_ and b_:
             ra, rb = a_["roofline"], b_["roofline"]
             rec["config"][f"{tag}_renumbering"] = {
@@ -1197,7 +1203,14 @@ def run_single(args, result_fd):
                 "reorder_seconds": b_.get("reorder_seconds"),
                 "l2_hit_before": ra.get("l2_hit_rate"), "l2_hit_after": rb.get("l2_hit_rate"),
                 "traffic_over_compulsory_before": ra.get("traffic_over_compulsory"),
-                "traffic_over_compulsory_after": rb.get("traffic_over_compulsory")}
+                "traffic_over_compulsory_after": rb.get("traffic_over_compulsory"),
+                "avg_edge_span_scrambled": a_.get("avg_edge_span"), "avg_edge_span_renumbered": b_.get("avg_edge_span")}
+            if c_:
+                rec["config"][f"{tag}_renumbering"].update({
+                    "ms_planted_order": c_["ms_per_step"], "avg_edge_span_planted": c_.get("avg_edge_span"),
+                    "planted_over_renumbered_ms": c_["ms_per_step"] / b_["ms_per_step"],
+                    "l2_hit_planted": c_["roofline"].get("l2_hit_rate"),
+                    "traffic_over_compulsory_planted": c_["roofline"].get("traffic_over_compulsory")})
     for w5, e5, p5, k5, chk5, desc5 in fives:
         key = "config5_rank_of_8" if w5.form == "allgather-one-call" else "config5_rank_of_8_" + w5.form.replace("-", "_")
         others[key] = {

@@ -36,8 +36,10 @@ __global__ void __launch_bounds__(kBlock)
 prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, int ldy, const int32_t *__restrict__ p2n,
                 const int32_t *__restrict__ pp, int64_t P, int32_t *flag, int32_t seq, int validate, int zero_fill,
                 const int32_t *__restrict__ chk_ids, int64_t chk_n, const unsigned long long *__restrict__ chk_sum,
-                int32_t *stale_flag)
+                int32_t *stale_flag, uint32_t *__restrict__ clear_words, int n_clear)
 {
+    // the step counters of the sweep kernel behind this launch (<= kBlock words): cleared here instead of by a launch of their own
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_clear) clear_words[threadIdx.x] = 0u;
     // packed ids of a prepared graph: does column_index still look like the array the copy was made from?  (1024 samples:
     // catches a buffer that was rewritten, which is what happens when a promise of immutability is broken by accident.)
     // The launcher adds one block for it, so that the zero-fill does not wait behind the sampled loads.
@@ -535,7 +537,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
     const unsigned long long *chk_sum = nullptr;
     int64_t chk_n = 0;
     int32_t *stale_flag = flag + kFlagSlots;          // the second ring, same slot
-    auto run_prologue = [&](int sparse_G) -> int {
+    auto run_prologue = [&](int sparse_G, uint32_t *clear_words = nullptr, int n_clear = 0) -> int {
         const int validate = (num_parts > 0 && !tune.trust_canonical) ? 1 : 0;
         const int zero_fill = (accumulate_into_out || win_begin > 0) ? 0 : 1;
         if (sparse_G > 0 && zero_fill && num_parts > 0) {
@@ -554,7 +556,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
             blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
             hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks + (chk_sum ? 1u : 0u)), dim3(kBlock), 0, stream, out, n_floats,
                                dim, ldy, part2Node, part_pointers, num_parts, flag, seq, validate, zero_fill,
-                               chk_sum ? column_index : nullptr, chk_n, chk_sum, stale_flag);
+                               chk_sum ? column_index : nullptr, chk_n, chk_sum, stale_flag, clear_words, n_clear);
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "prologue launch: %s", hipGetErrorString(e));
@@ -687,11 +689,10 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
             if (rc != GNNA_OK) return rc;
             if (sw_ids) count_event(CTR_PACKED_LAUNCHES);
         }
-        rc = run_prologue(0);
-        if (rc != GNNA_OK) return rc;
         uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * kSweepSlotWords;
-        hipError_t em = hipMemsetAsync(sync, 0, (kXcds * 16 + 2) * sizeof(uint32_t), stream);
-        if (em != hipSuccess) return fail(GNNA_ERR_HIP, "sweep counters: %s", hipGetErrorString(em));
+        static_assert(kXcds * 16 + 2 <= kBlock, "the prologue clears the sweep counters with one block");
+        rc = run_prologue(0, sync, kXcds * 16 + 2);       // (dense prologue: it also zeroes the call's step counters and list header)
+        if (rc != GNNA_OK) return rc;
         SweepLaunch w;
         w.mode = mode; w.X = X; w.col = column_index; w.pp = part_pointers; w.p2n = part2Node; w.Y = out;
         w.cnt = cnt; w.row_scale = row_scale; w.flag = flag; w.seq = seq; w.trust = tune.trust_canonical ? 1 : 0; w.sync = sync;
