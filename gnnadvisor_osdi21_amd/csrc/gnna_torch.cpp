@@ -74,6 +74,15 @@ bool same_storage(const c10::weak_intrusive_ptr<c10::StorageImpl> &w, const torc
     return !w.expired() && w._unsafe_get_target() == t.storage().unsafeGetStorageImpl();
 }
 
+// gnna_forget_graph() drops every plan keyed by this column_index -- those of the other partitions over the same array too:
+// their entries must prepare again (at their next call) instead of believing their plans are still pinned.  Caller holds the mutex.
+void forget_plans_of(const void *ci)
+{
+    (void)gnna_forget_graph(static_cast<const int32_t *>(ci));
+    for (auto &g : g_seen)
+        if (g.ci == ci) g.dims_done.clear();
+}
+
 void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_pointers, const torch::Tensor &part2Node,
                 int64_t rows, int partSize, int dim, void *stream)
 {
@@ -86,8 +95,10 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
     // graphs whose tensors are gone: their plans (and packed copies: nnz x 4 bytes each) must not stay pinned in the library
     for (auto &g : g_seen)
         if (g.ci && (g.s_ci.expired() || g.s_pp.expired() || g.s_p2n.expired())) {
-            if (!g.dims_done.empty()) (void)gnna_forget_graph(static_cast<const int32_t *>(g.ci));
+            const void *gone = g.ci;
+            const bool pinned = !g.dims_done.empty();
             g = SeenGraph();
+            if (pinned) forget_plans_of(gone);
         }
     SeenGraph *e = nullptr, *victim = &g_seen[0];
     // (an entry is one PARTITION of a graph -- the three arrays together: two partitions over one column_index, e.g. two
@@ -103,10 +114,10 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
                       e->partSize == partSize;
     if (!same) {
         if (e) {
-            (void)gnna_forget_graph(static_cast<const int32_t *>(ci));     // another graph lives at this address now
+            forget_plans_of(ci);                                           // another graph lives at this address now
         } else {
             e = victim;                                                    // (the least recently seen entry makes room:
-            if (e->ci && !e->dims_done.empty()) (void)gnna_forget_graph(static_cast<const int32_t *>(e->ci));   // unpin what it pinned)
+            if (e->ci && !e->dims_done.empty()) forget_plans_of(e->ci);    // unpin what it pinned)
         }
         *e = SeenGraph();
         e->ci = ci; e->pp = part_pointers.data_ptr(); e->p2n = part2Node.data_ptr();

@@ -539,3 +539,36 @@ def test_two_partitions_over_one_column_index_do_not_evict_each_other():
         else:
             assert GNNA.auto_prepared_graphs() == before + 2              # both prepared at their second sighting, once
     assert _lib.runtime_counters()["plan_builds"] - builds0 <= 2          # one counting pass per partition, not one per call
+
+
+@pytest.mark.gpu
+def test_dropping_one_partition_lets_the_other_prepare_again():
+    """gnna_forget_graph() is keyed by column_index: when the tensors of one partition are freed, the module forgets the
+    plans of EVERY partition over that array -- the surviving partition's entry must notice and prepare again at its next
+    call, not go on believing its plan is pinned (results are the same either way; this pins the bookkeeping)."""
+    import gc
+    import os
+    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
+        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    GNNA = load_extension()
+    g = graph.powerlaw_graph(30000, 4000000, 3000, seed=41, device="cuda")
+    rp, ci, deg = g.row_pointers, g.column_index, g.degrees
+    pp_a, p2n_a = [t.cuda() for t in GNNA.build_part(32, rp.cpu())]
+    pp_b, p2n_b = [t.cuda() for t in GNNA.build_part(64, rp.cpu())]
+    X = torch.randn(g.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+    ref = GNNA.SAG(X, rp, ci, deg, pp_a, p2n_a, 32, 32, 4).clone()
+    before = GNNA.auto_prepared_graphs()
+    for _ in range(2):
+        GNNA.SAG(X, rp, ci, deg, pp_a, p2n_a, 32, 32, 4)
+        GNNA.SAG(X, rp, ci, deg, pp_b, p2n_b, 64, 32, 4)
+    assert GNNA.auto_prepared_graphs() >= before + 2
+    mid = GNNA.auto_prepared_graphs()
+    del pp_b, p2n_b
+    gc.collect()
+    torch.cuda.synchronize()
+    y = GNNA.SAG(X, rp, ci, deg, pp_a, p2n_a, 32, 32, 4)      # the expiry scan runs here and drops the plans of `ci`
+    assert GNNA.auto_prepared_graphs() == mid + 1               # ... and partition A prepared again in the same call
+    assert float(((y - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-4
+    y = GNNA.SAG(X, rp, ci, deg, pp_a, p2n_a, 32, 32, 4)
+    assert GNNA.auto_prepared_graphs() == mid + 1
+    assert float(((y - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-4
