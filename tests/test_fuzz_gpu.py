@@ -207,3 +207,43 @@ def test_leading_dimensions_and_flags_random():
                 _lib.release_graph(cid)
     finally:
         _lib.reset_tuning()
+
+
+def test_module_repeated_calls_medium_graphs_random():
+    """The reference caller's path on graphs large enough for the library's own schedule choices (sliced schedule, the sweep
+    kernel, packed ids): GNNA.SAG / aggregate_gin three times on the same tensors -- the first call counts the partition, the
+    second makes the module prepare the graph by itself, the third reads what was prepared -- every call against the fp64
+    oracle, no knob forced.  Then the column ids are rewritten in place (version counter bumps): the module must forget the
+    plan and the next call must follow the new ids."""
+    GNNA = load_extension()
+    rng = np.random.default_rng(SEED + 5)
+    for k in range(max(3, CASES // 3)):
+        n = int(rng.integers(2000, 40000)); deg = float(rng.choice([4, 20, 80, 350, 600]))
+        e = int(min(n * deg, 0.2 * n * n)); D = int(rng.choice([8, 16, 32, 41, 64, 100]))
+        ps = int(rng.choice([8, 32, 64, 128])); kind = int(rng.integers(0, 2))
+        loc = float(rng.choice([0.0, 0.0, 0.9]))
+        g = graph.powerlaw_graph(n, e, int(min(n - 1, max(8, 40 * deg))), seed=SEED * 7000 + k, locality=loc, device="cuda")
+        rp, ci, degs = g.row_pointers, g.column_index, g.degrees
+        pp, p2n = [t.cuda() for t in GNNA.build_part(ps, rp.cpu())]
+        X = torch.randn(n, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(k))
+        rp_h, X_h = rp.cpu().numpy(), X.cpu().numpy()
+
+        def check(what):
+            ci_h = ci.cpu().numpy()
+            mode, eps = (0, 1.0) if kind == 0 else (2, 0.5)
+            ref = oracle.csr_f64(mode, X_h, rp_h, ci_h, None, eps)
+            scale = oracle.csr_f64(mode, np.abs(X_h), rp_h, ci_h, None, abs(eps))
+            before = GNNA.auto_prepared_graphs()
+            for call in range(3):
+                y = (GNNA.SAG(X, rp, ci, degs, pp, p2n, ps, 32, 4) if kind == 0
+                     else GNNA.aggregate_gin(X, rp, ci, 0.5, pp, p2n, ps, 32, 4))
+                assert_close_f64(y.cpu().numpy(), ref, scale=scale,
+                                 what=f"case {k} {what} call {call}: n={n} nnz={g.nnz} D={D} ps={ps} kind={kind} locality={loc} "
+                                      f"phases={_lib.last_num_phases()}")
+            if os.environ.get("GNNA_AUTO_PREPARE", "1") != "0" and not os.environ.get("GNNA_TUNE"):
+                assert GNNA.auto_prepared_graphs() == before + 1, f"case {k} {what}: prepared once, at the second sighting"
+        check("as built")
+        # the same tensors, other ids: every row's ids reversed in place (still a valid CSR of another graph)
+        ci.copy_((n - 1) - ci)
+        check("ids rewritten in place")
+        del X, pp, p2n, g, rp, ci, degs
