@@ -543,7 +543,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
         if (sparse_G > 0 && zero_fill && num_parts > 0) {
             int64_t blocks = (num_parts + kBlock - 1) / kBlock;
             blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)ds->num_cus * 8));
-            unsigned long long *gaps = ds->gap_lists + (size_t)((uint32_t)seq % kGapSlots) * kGapWords;
+            unsigned long long *gaps = ds->gap_lists + (size_t)call_block_of(ds, stream, seq) * kGapWords;
             (void)hipMemsetAsync(gaps, 0, sizeof(unsigned long long), stream);
             const int64_t big_rows = std::max<int64_t>(64, ((int64_t)1 << 20) / std::max(1, dim * 4));   // >= 1 MiB of zeros
             hipLaunchKernelGGL(sparse_prologue_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, out, num_nodes, dim, ldy,
@@ -689,7 +689,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
             if (rc != GNNA_OK) return rc;
             if (sw_ids) count_event(CTR_PACKED_LAUNCHES);
         }
-        uint32_t *sync = ds->sweep_sync + (size_t)((uint32_t)seq % kSweepSyncSlots) * kSweepSlotWords;
+        uint32_t *sync = ds->sweep_sync + (size_t)call_block_of(ds, stream, seq) * kSweepSlotWords;
         static_assert(kXcds * 16 + 2 <= kBlock, "the prologue clears the sweep counters with one block");
         rc = run_prologue(0, sync, kXcds * 16 + 2);       // (dense prologue: it also zeroes the call's step counters and list header)
         if (rc != GNNA_OK) return rc;

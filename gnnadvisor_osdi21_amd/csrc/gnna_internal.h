@@ -38,14 +38,21 @@ struct DeviceState {
     int num_cus = 256;
     int32_t *flags = nullptr;  // two rings of kFlagSlots ints, zero-initialised: [slot] "partition is not canonical",
                                // [kFlagSlots + slot] "the packed ids are stale" of the call with that sequence number
-    unsigned long long *gap_lists = nullptr;   // ring of kGapSlots lists of kGapWords words
-    uint32_t *sweep_sync = nullptr;  // ring of kSweepSyncSlots counter blocks for the sweep kernel's soft barrier
+    unsigned long long *gap_lists = nullptr;   // kCallBlocks lists of kGapWords words (call_block_of)
+    uint32_t *sweep_sync = nullptr;  // kCallBlocks counter blocks for the sweep kernel's soft barrier (call_block_of)
+    std::map<hipStream_t, int> stream_block;   // streams that own one of the first kStreamBlocks call blocks
     std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 1 staged / pre-scaled X, slot 2 partial rows of the
                                                           // deterministic schedule / slabs of the weight-gradient kernel
 };
 constexpr int kFlagSlots = 1024;
 // per-call lists of long runs of rows without edges that the sparse prologue leaves to a grid-wide pass
-constexpr int kGapSlots = 64, kGapEntries = 63, kGapWords = 2 + 2 * kGapEntries;   // word 0: count, pairs (first row, rows)
+constexpr int kGapEntries = 63, kGapWords = 2 + 2 * kGapEntries;   // word 0: count, pairs (first row, rows)
+// Per-call device scratch that is NOT tagged with the call's sequence number (the gap list of the sparse prologue, the sweep
+// kernel's step counters and ReLU list) lives in "call blocks".  Work on one stream is ordered, so a stream needs one block:
+// the first kStreamBlocks streams that call the library get a block of their own (no allocation: capture-safe), calls on any
+// further stream share a ring of kCallBlocks - kStreamBlocks blocks by sequence number.  (A ring alone, shared by all
+// streams, lets a call on one stream clear the block of a call 64 sequence numbers earlier that is still running on another.)
+constexpr int kStreamBlocks = 64, kCallBlocks = 128;
 
 // State of the current device (lazily created: CU count, flag ring).
 int get_device_state(DeviceState **out);
@@ -53,6 +60,8 @@ int get_device_state(DeviceState **out);
 int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out);
 // Fresh non-zero sequence number of an aggregation call and its slot in the flag ring.
 int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
+// Index of the call block (see kCallBlocks) of a call with sequence number `seq` on `stream`.
+int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq);
 
 // ---- streaming kernel + sliced schedule (gnna_stream.hip) ----------------------------------------------
 constexpr int kMaxSlices = 32;    // fine source slices of a slice plan (one byte of cumulative count per group and boundary)
@@ -170,7 +179,7 @@ int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream);
 // Phases of the sweep kernel when the library picks it on its own (gnna_tuning.sweep = 0) for this call, else 0 (gnna_agg.hip).
 int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
                       double edges, int B, int num_cus, bool deterministic, int part_size);
-constexpr int kSweepSyncSlots = 64;    // ring of per-call blocks: kXcds step counters 64 bytes apart, then the ReLU epilogue's
+// a call block of the sweep kernel: kXcds step counters 64 bytes apart, then the ReLU epilogue's
 constexpr int kSweepListCap = 1023;    // list of row ranges the kernel did not store once: [count][overflow][(first, rows) ...]
 constexpr int kSweepSlotWords = 8 * 16 + 2 + 2 * kSweepListCap;
 

@@ -39,12 +39,12 @@ int get_device_state(DeviceState **out)
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(flags): %s", hipGetErrorString(e));
             e = hipMemset(s.flags, 0, 2 * kFlagSlots * sizeof(int32_t));
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMemset(flags): %s", hipGetErrorString(e));
-            const size_t gap_bytes = (size_t)kGapSlots * kGapWords * sizeof(unsigned long long);
+            const size_t gap_bytes = (size_t)kCallBlocks * kGapWords * sizeof(unsigned long long);
             e = hipMalloc(reinterpret_cast<void **>(&s.gap_lists), gap_bytes);
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(gap lists): %s", hipGetErrorString(e));
             e = hipMemset(s.gap_lists, 0, gap_bytes);
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMemset(gap lists): %s", hipGetErrorString(e));
-            const size_t sync_bytes = (size_t)kSweepSyncSlots * kSweepSlotWords * sizeof(uint32_t);
+            const size_t sync_bytes = (size_t)kCallBlocks * kSweepSlotWords * sizeof(uint32_t);
             e = hipMalloc(reinterpret_cast<void **>(&s.sweep_sync), sync_bytes);
             if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(sweep counters): %s", hipGetErrorString(e));
             e = hipMemset(s.sweep_sync, 0, sync_bytes);
@@ -88,6 +88,19 @@ int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot)
     const uint32_t seq_u = g_seq.fetch_add(1) + 1;
     *flag_slot = ds->flags + (seq_u % kFlagSlots);
     return (int32_t)(seq_u & 0x7fffffff) | 1;  // never 0
+}
+
+int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
+{
+    std::lock_guard<std::mutex> lock(g_dev_mutex);
+    auto it = ds->stream_block.find(stream);
+    if (it != ds->stream_block.end()) return it->second;
+    if ((int)ds->stream_block.size() < kStreamBlocks) {
+        const int b = (int)ds->stream_block.size();
+        ds->stream_block.emplace(stream, b);
+        return b;
+    }
+    return kStreamBlocks + (int)((uint32_t)seq % (uint32_t)(kCallBlocks - kStreamBlocks));
 }
 
 namespace {

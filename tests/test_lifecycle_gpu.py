@@ -211,3 +211,48 @@ def test_windowed_aggregation_is_not_refused_by_the_plan_backoff():
         assert_close_f64(out.cpu().numpy(), ref, what="windowed after the back-off")
     finally:
         _lib.reset_tuning()
+
+
+@pytest.mark.gpu
+def test_two_streams_with_deep_queues_do_not_share_per_call_scratch():
+    """Hundreds of aggregations queued on each of two streams at once (a fast graph and a slow one, so that one queue runs
+    ahead of the other by any number of calls): the per-call device scratch that carries no sequence tag -- the sweep kernel's
+    step counters and its ReLU list, the sparse prologue's gap list -- belongs to the STREAM (gnna_internal.h, kCallBlocks),
+    so a call on one stream can never clear what a call still running on the other one reads.  Every call's output starts as
+    NaN and is compared with the result of the same call made alone."""
+    # (calls long enough -- ~0.7 and ~0.15 ms -- for the queues to build up behind the Python loop that fills them)
+    big = graph.powerlaw_graph(150000, 60000000, 15000, seed=5, device="cuda")
+    small = graph.powerlaw_graph(30000, 10000000, 6000, seed=6, device="cuda")
+    # rows 2,000 .. 8,999 of the small graph lose their edges: one long run of empty rows for the sparse prologue's gap list
+    rows = torch.repeat_interleave(torch.arange(small.num_nodes, device="cuda"), (small.row_pointers[1:] - small.row_pointers[:-1]).long())
+    keep = ~((rows >= 2000) & (rows < 9000))
+    small = graph.graph_from_edges(rows[keep], small.column_index.long()[keep], small.num_nodes)
+    assert int(small.row_pointers[9000] - small.row_pointers[2000]) == 0
+    work = []
+    for g, ps in ((big, 64), (small, 32)):
+        pp, p2n = _lib.build_part(ps, g.row_pointers.cpu())
+        X = torch.randn(g.num_nodes, 64, device="cuda", generator=torch.Generator(device="cuda").manual_seed(g.num_nodes))
+        work.append(dict(g=g, ps=ps, pp=pp.cuda(), p2n=p2n.cuda(), X=X))
+    try:
+        for tune, relu in ((dict(sweep=1, column_phases=8), True), (dict(column_phases=1), False)):
+            _lib.reset_tuning()
+            _lib.set_tuning(**tune)
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+            for w in work:
+                w["ref"] = _lib.agg_ld(0, w["X"], w["g"].column_index, w["pp"], w["p2n"], w["g"].num_nodes, w["ps"], relu=relu).clone()
+                w["out"] = torch.empty_like(w["ref"])
+                w["worst"] = torch.zeros((), device="cuda")
+            torch.cuda.synchronize()
+            for w, s, calls in zip(work, streams, (100, 400)):
+                with torch.cuda.stream(s):
+                    for _ in range(calls):
+                        w["out"].fill_(float("nan"))
+                        _lib.agg_ld(0, w["X"], w["g"].column_index, w["pp"], w["p2n"], w["g"].num_nodes, w["ps"], out=w["out"], relu=relu)
+                        err = ((w["out"] - w["ref"]).abs() / w["ref"].abs().clamp_min(1.0)).max()
+                        w["worst"] = torch.maximum(w["worst"], err)        # (NaN propagates: an unwritten element cannot hide)
+            torch.cuda.synchronize()
+            for w in work:
+                worst = float(w["worst"])
+                assert worst <= 1e-4, (tune, w["g"].num_nodes, worst)
+    finally:
+        _lib.reset_tuning()
