@@ -525,7 +525,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
                                       part2Node, out, ld_out, num_nodes, dim, num_parts, partSize, dimWorker, warpPerBlock, stream_v, flags);
     }
     int32_t *flag = nullptr;
-    const int32_t seq = next_call_seq(ds, &flag);
+    const int32_t seq = next_call_seq(ds, stream, &flag);
     const int prof_call = profiled ? profile_acquire_call(num_parts > 0) : -1;
     profile_record(prof_call, 0, stream);
     const int ldy = (int)ld_out;

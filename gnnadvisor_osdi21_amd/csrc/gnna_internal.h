@@ -36,8 +36,9 @@ struct Workspace {
 struct DeviceState {
     std::atomic<bool> init{false};
     int num_cus = 256;
-    int32_t *flags = nullptr;  // two rings of kFlagSlots ints, zero-initialised: [slot] "partition is not canonical",
-                               // [kFlagSlots + slot] "the packed ids are stale" of the call with that sequence number
+    int32_t *flags = nullptr;  // two arrays of kFlagSlots ints, zero-initialised: [slot] "partition is not canonical",
+                               // [kFlagSlots + slot] "the packed ids are stale" -- each holds the sequence number of the call
+                               // that raised it; slot = the call's block (call_block_of)
     unsigned long long *gap_lists = nullptr;   // kCallBlocks lists of kGapWords words (call_block_of)
     uint32_t *sweep_sync = nullptr;  // kCallBlocks counter blocks for the sweep kernel's soft barrier (call_block_of)
     std::map<hipStream_t, int> stream_block;   // streams that own one of the first kStreamBlocks call blocks
@@ -58,8 +59,8 @@ constexpr int kStreamBlocks = 64, kCallBlocks = 128;
 int get_device_state(DeviceState **out);
 // Grow-only scratch buffer `slot` of `stream`.
 int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, void **out);
-// Fresh non-zero sequence number of an aggregation call and its slot in the flag ring.
-int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot);
+// Fresh non-zero sequence number of an aggregation call on `stream` and its slot among the flags (the call block's index).
+int32_t next_call_seq(DeviceState *ds, hipStream_t stream, int32_t **flag_slot);
 // Index of the call block (see kCallBlocks) of a call with sequence number `seq` on `stream`.
 int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq);
 

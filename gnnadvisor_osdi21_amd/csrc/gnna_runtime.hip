@@ -83,13 +83,6 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
     return GNNA_OK;
 }
 
-int32_t next_call_seq(DeviceState *ds, int32_t **flag_slot)
-{
-    const uint32_t seq_u = g_seq.fetch_add(1) + 1;
-    *flag_slot = ds->flags + (seq_u % kFlagSlots);
-    return (int32_t)(seq_u & 0x7fffffff) | 1;  // never 0
-}
-
 int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
 {
     std::lock_guard<std::mutex> lock(g_dev_mutex);
@@ -101,6 +94,16 @@ int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
         return b;
     }
     return kStreamBlocks + (int)((uint32_t)seq % (uint32_t)(kCallBlocks - kStreamBlocks));
+}
+
+int32_t next_call_seq(DeviceState *ds, hipStream_t stream, int32_t **flag_slot)
+{
+    const uint32_t seq_u = g_seq.fetch_add(1) + 1;
+    const int32_t seq = (int32_t)(seq_u & 0x7fffffff) | 1;  // never 0
+    // the flags are compared with the call's own sequence number, so a slot can be shared by calls that follow each other on one
+    // stream; calls on different streams use different slots (call_block_of), so none can overwrite the flag of another in flight
+    *flag_slot = ds->flags + call_block_of(ds, stream, seq);
+    return seq;
 }
 
 namespace {

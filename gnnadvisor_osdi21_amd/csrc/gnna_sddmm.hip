@@ -73,7 +73,7 @@ int launch_sddmm(const float *dst_feat, int64_t ld_dst, const float *src_feat, i
     a.Y = edge_out; a.cnt = cnt; a.row_scale = nullptr; a.deg_row = nullptr; a.deg_col = nullptr;
     // the canonical-partition flag only decides between stores and atomics for shared rows; SDDMM shares nothing
     int32_t *flag = nullptr;
-    a.seq = next_call_seq(ds, &flag);
+    a.seq = next_call_seq(ds, stream, &flag);
     a.flag = flag; a.trust = 1; a.P = num_parts; a.D = dim; a.ldx = (int)ld_src; a.lda = (int)ld_dst; a.ldy = dim; a.num_out_rows = num_out_rows;
     a.G = std::min(64, std::max(1, tune.groups_per_chunk) * B); a.U = tune.loads_in_flight >= 8 ? 8 : 4; a.S = S; a.B = B;
     a.wide = wide; a.plain_ok = true; a.xcd_remap = tune.xcd_remap != 0; a.eps = 1.f;
