@@ -150,11 +150,13 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     std::vector<int32_t> bci;
     {
         std::vector<uint8_t> keep(ci.size(), 0);
-        // Every undirected pair once (u < v), from u's side: u's neighbours are marked in a per-thread bitmap (n bits: cache
-        // resident), v's list is then a sequential scan that stops at `need` marked entries, and the answer is written to
-        // both directions (the reverse entry by binary search in v's sorted list).  Same result as merging the two sorted
-        // lists per directed edge -- the support and `need` are symmetric -- at about a fifth of the time on graphs with rows
-        // of hundreds of edges (round 5: the merge made the Reddit-like graph's renumbering the longest leg of bench.py).
+        // Every undirected pair once, from the side of its end point u of HIGHER degree (ties: higher id): u's neighbours are
+        // marked in a per-thread bitmap (n bits: cache resident), the SHORTER list -- v's -- is then a sequential scan that
+        // stops at `need` marked entries, and the answer is written to both directions (the reverse entry by binary search in
+        // v's sorted list).  Same result as merging the two sorted lists per directed edge -- the support and `need` are
+        // symmetric -- at a fraction of the time on graphs with rows of hundreds of edges (round 5: the merge made the
+        // Reddit-like graph's renumbering the longest leg of bench.py; scanning the shorter list of a pair instead of the
+        // list of the higher id halves what is left: a pair that is NOT kept costs min(du, dv) instead of dv).
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
             std::vector<uint64_t> mark((size_t)((n + 63) / 64), 0);
             for (int64_t u = lo; u < hi; u++) {
@@ -163,9 +165,8 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                 for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] |= 1ull << (ci[(size_t)k] & 63);
                 for (int64_t k = ub; k < ue; k++) {
                     const int32_t v = ci[(size_t)k];
-                    if (v <= u) continue;
                     const int64_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
-                    if (ve - vb > hub) continue;
+                    if (ve - vb > ue - ub || (ve - vb == ue - ub && v >= u)) continue;     // (the pair is v's to count)
                     const int32_t need = std::max<int32_t>(T, (int32_t)std::ceil(3.0 * chance * (double)(ue - ub) * (double)(ve - vb)));
                     int32_t common = 0;
                     for (int64_t j = vb; j < ve && common < need; j++) {
