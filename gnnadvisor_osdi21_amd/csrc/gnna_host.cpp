@@ -311,20 +311,35 @@ int64_t gnna_csr_from_edges_i32(const int32_t *src, const int32_t *dst, int64_t 
     if (num_edges < 0 || num_nodes < 0 || !row_pointers || (num_edges > 0 && (!src || !dst || !column_index)))
         return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "bad edge list arguments");
     if (num_edges > 0x7fffffffLL) return gnna::fail(GNNA_ERR_UNSUPPORTED, "more than 2^31-1 edges: shard the graph");
-    // counting sort by source row
+    // counting sort by source row, the edge list cut into slabs that are counted and scattered in parallel (atomic counts and
+    // cursors into ONE array: the order inside a row does not matter, every row is sorted below)
     std::vector<int64_t> start((size_t)num_nodes + 1, 0);
-    for (int64_t e = 0; e < num_edges; e++) {
-        const int32_t s = src[e], d = dst[e];
-        if (s < 0 || s >= num_nodes || d < 0 || d >= num_nodes)
-            return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)e, s, d,
+    {
+        std::atomic<int64_t> bad{-1};
+        parallel_rows(num_edges, [&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++) {
+                const int32_t s = src[e], d = dst[e];
+                if (s < 0 || s >= num_nodes || d < 0 || d >= num_nodes) {
+                    int64_t none = -1;
+                    (void)bad.compare_exchange_strong(none, e);      // (any offending edge will do for the message)
+                    return;
+                }
+                __atomic_fetch_add(&start[(size_t)s + 1], (int64_t)1, __ATOMIC_RELAXED);
+            }
+        });
+        const int64_t e = bad.load();
+        if (e >= 0)
+            return gnna::fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)e, src[e], dst[e],
                               (long long)num_nodes);
-        start[(size_t)s + 1]++;
     }
     for (int64_t i = 0; i < num_nodes; i++) start[(size_t)i + 1] += start[(size_t)i];
     std::vector<int32_t> bucket((size_t)num_edges);
     {
         std::vector<int64_t> cursor(start.begin(), start.end() - 1);
-        for (int64_t e = 0; e < num_edges; e++) bucket[(size_t)cursor[(size_t)src[e]]++] = dst[e];
+        parallel_rows(num_edges, [&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++)
+                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)src[e]], (int64_t)1, __ATOMIC_RELAXED)] = dst[e];
+        });
     }
     // per-row sort + unique (parallel over row ranges)
     std::vector<int32_t> uniq((size_t)num_nodes, 0);
@@ -338,10 +353,13 @@ int64_t gnna_csr_from_edges_i32(const int32_t *src, const int32_t *dst, int64_t 
     int64_t nnz = 0;
     row_pointers[0] = 0;
     for (int64_t i = 0; i < num_nodes; i++) {
-        std::copy_n(bucket.data() + start[(size_t)i], uniq[(size_t)i], column_index + nnz);
         nnz += uniq[(size_t)i];
         row_pointers[i + 1] = (int32_t)nnz;
     }
+    parallel_rows(num_nodes, [&](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; i++)
+            std::copy_n(bucket.data() + start[(size_t)i], uniq[(size_t)i], column_index + row_pointers[i]);
+    });
     return nnz;
 }
 
