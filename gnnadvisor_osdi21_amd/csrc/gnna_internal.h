@@ -50,8 +50,9 @@ constexpr int kFlagSlots = 1024;
 constexpr int kGapEntries = 63, kGapWords = 2 + 2 * kGapEntries;   // word 0: count, pairs (first row, rows)
 // Per-call device scratch that is NOT tagged with the call's sequence number (the gap list of the sparse prologue, the sweep
 // kernel's step counters and ReLU list) lives in "call blocks".  Work on one stream is ordered, so a stream needs one block:
-// the first kStreamBlocks streams that call the library get a block of their own (no allocation: capture-safe), calls on any
-// further stream share a ring of kCallBlocks - kStreamBlocks blocks by sequence number.  (A ring alone, shared by all
+// the first kStreamBlocks streams that call the library get a block of their own (no allocation), calls on any further stream
+// -- and calls that are being captured into a graph, which run in the order of their replays, not of the capture stream --
+// share a ring of kCallBlocks - kStreamBlocks blocks by sequence number.  (A ring alone, shared by all
 // streams, lets a call on one stream clear the block of a call 64 sequence numbers earlier that is still running on another.)
 constexpr int kStreamBlocks = 64, kCallBlocks = 128;
 

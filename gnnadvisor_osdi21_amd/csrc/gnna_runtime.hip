@@ -85,6 +85,13 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
 
 int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
 {
+    // a call that is being CAPTURED will run wherever and whenever its graph is replayed -- not in the order of the capture
+    // stream (torch.cuda.graph captures every graph on one shared side stream and replays on the current one): such calls take
+    // their block from the shared ring by sequence number, as do the calls of streams beyond the first kStreamBlocks
+    const int shared = kStreamBlocks + (int)((uint32_t)seq % (uint32_t)(kCallBlocks - kStreamBlocks));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
+    if (cap != hipStreamCaptureStatusNone) return shared;
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     auto it = ds->stream_block.find(stream);
     if (it != ds->stream_block.end()) return it->second;
@@ -93,7 +100,7 @@ int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
         ds->stream_block.emplace(stream, b);
         return b;
     }
-    return kStreamBlocks + (int)((uint32_t)seq % (uint32_t)(kCallBlocks - kStreamBlocks));
+    return shared;
 }
 
 int32_t next_call_seq(DeviceState *ds, hipStream_t stream, int32_t **flag_slot)
