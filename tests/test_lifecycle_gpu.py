@@ -253,6 +253,9 @@ def test_two_streams_with_deep_queues_do_not_share_per_call_scratch():
             torch.cuda.synchronize()
             for w in work:
                 worst = float(w["worst"])
-                assert worst <= 1e-4, (tune, w["g"].num_nodes, worst)
+                # (two fp32 runs of the same call: rows of up to 15,000 edges flushed with atomics in another order differ by
+                # rounding -- 1.3e-4 of max(1, |ref|) seen under GNNA_TUNE=ZERO=1,G=1; what this test looks for -- a row that
+                # was not cleared, not clamped or not written -- is NaN or O(1))
+                assert worst <= 1e-3, (tune, w["g"].num_nodes, worst)
     finally:
         _lib.reset_tuning()
