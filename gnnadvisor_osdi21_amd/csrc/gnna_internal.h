@@ -32,6 +32,7 @@ void apply_graph_hints(const void *column_index, int dim, gnna_tuning *tune);
 struct Workspace {
     void *ptr = nullptr;
     size_t bytes = 0;
+    bool captured = false;     // handed to a call that was being captured: a graph points at it, it is never freed
 };
 struct DeviceState {
     std::atomic<bool> init{false};

@@ -63,22 +63,25 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
 {
     std::lock_guard<std::mutex> lock(g_dev_mutex);
     Workspace &w = ds->ws[std::make_pair(stream, slot)];
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (w.bytes < bytes) {
-        // growing means hipFree + hipMalloc: illegal inside a stream capture, and it would leave dangling
-        // pointers in a graph captured earlier on this stream -- refuse instead (warm the path up before capturing)
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(stream, &cap);
+        // growing means hipFree + hipMalloc: illegal inside a stream capture -- refuse instead (warm the path up before
+        // capturing on this stream)
         if (cap != hipStreamCaptureStatusNone)
             return fail(GNNA_ERR_UNSUPPORTED, "library scratch (%zu B) would have to grow during stream capture: "
-                        "run the same call once before capturing", bytes);
-        if (w.ptr) (void)hipFree(w.ptr);
+                        "run the same call once on this stream before capturing", bytes);
+        // a buffer some captured graph points at stays allocated for good (the graph may be replayed at any time)
+        if (w.ptr && !w.captured) (void)hipFree(w.ptr);
         w.ptr = nullptr;
         w.bytes = 0;
+        w.captured = false;
         const size_t want = bytes + bytes / 4;
         hipError_t e = hipMalloc(&w.ptr, want);
         if (e != hipSuccess) return fail(GNNA_ERR_HIP, "hipMalloc(workspace %zu B): %s", want, hipGetErrorString(e));
         w.bytes = want;
     }
+    if (cap != hipStreamCaptureStatusNone) w.captured = true;
     *out = w.ptr;
     return GNNA_OK;
 }

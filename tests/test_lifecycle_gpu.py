@@ -259,3 +259,42 @@ def test_two_streams_with_deep_queues_do_not_share_per_call_scratch():
                 assert worst <= 1e-3, (tune, w["g"].num_nodes, worst)
     finally:
         _lib.reset_tuning()
+
+
+@pytest.mark.gpu
+def test_a_captured_call_keeps_its_scratch_when_a_larger_call_follows_on_that_stream():
+    """A call captured into a graph points at the capture stream's scratch buffer (here: the staged, padded copy of X).  A later
+    eager call on the same stream that needs MORE scratch must not free that buffer -- the graph may be replayed at any time."""
+    small = graph.powerlaw_graph(20000, 3000000, 3000, seed=11, device="cuda")
+    large = graph.powerlaw_graph(90000, 8000000, 5000, seed=12, device="cuda")
+    s = torch.cuda.Stream()
+    try:
+        _lib.set_tuning(pad_rows=1)                     # (every call stages X with a padded row stride: 41 -> 48 floats)
+        parts = {}
+        for name, g in (("small", small), ("large", large)):
+            pp, p2n = _lib.build_part(32, g.row_pointers.cpu())
+            X = torch.randn(g.num_nodes, 41, device="cuda", generator=torch.Generator(device="cuda").manual_seed(g.num_nodes))
+            parts[name] = (g, pp.cuda(), p2n.cuda(), X)
+        g, pp, p2n, X = parts["small"]
+        out = torch.empty_like(X)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s):
+            want = _lib.agg_ld(0, X, g.column_index, pp, p2n, g.num_nodes, 32).clone()       # warm-up on the capture stream
+        s.synchronize()
+        cg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(cg, stream=s):
+            _lib.agg_ld(0, X, g.column_index, pp, p2n, g.num_nodes, 32, out=out)
+        gl, ppl, p2nl, Xl = parts["large"]
+        with torch.cuda.stream(s):
+            big = _lib.agg_ld(0, Xl, gl.column_index, ppl, p2nl, gl.num_nodes, 32)           # 4.5 x the scratch: it grows
+            # (something else takes the memory a freed buffer would have left)
+            filler = [torch.full((20000 * 48,), float("nan"), device="cuda") for _ in range(8)]
+        s.synchronize()
+        for _ in range(3):
+            out.fill_(float("nan"))
+            cg.replay()
+            torch.cuda.synchronize()
+            assert float(((out - want).abs() / want.abs().clamp_min(1.0)).max()) <= 1e-3
+        del filler, big
+    finally:
+        _lib.reset_tuning()
