@@ -25,6 +25,7 @@ def _built_native():
     """Build (no-op when fresh) the oracle and the HIP extension once per session."""
     import oracle
     oracle.build()
+    oracle.build_rabbit()
     from gnnadvisor_osdi21_amd import build as gbuild
     gbuild.build_all()
     yield
