@@ -57,7 +57,17 @@ def agg_ms(src, dst, n):
     from gnnadvisor_osdi21_amd import load_extension
     GNNA = load_extension()
     g = graph.graph_from_edges(src.to(dev), dst.to(dev), n)
-    ps = 128 if g.avg_degree >= 256 else 32          # (what inputProperty.decider() picks for these degrees)
+    from gnnadvisor_osdi21_amd.decider import inputProperty
+
+    class _Profile:
+        pass
+    prof = _Profile()
+    prof.num_nodes, prof.avg_degree, prof.avg_edgeSpan = g.num_nodes, g.avg_degree, g.avg_edgeSpan
+    prof.num_features, prof.reorder_flag = D, False
+    prof.rabbit_reorder = lambda: None
+    info = inputProperty(None, None, None, 32, 32, 4, 100, hiddenDim=D, dataset_obj=prof, enable_rabbit=False, manual_mode=False)
+    info.decider()
+    ps = info.partSize
     pp, p2n = GNNA.build_part(ps, g.row_pointers.cpu())
     ppd, p2nd = pp.to(dev), p2n.to(dev)
     X = torch.randn(n, D, device=dev)

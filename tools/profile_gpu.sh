@@ -12,6 +12,8 @@ cd /tmp
 BENCH="python $R/bench.py --steps 20 --warmup 5 --headline-only $*"
 PBENCH="python $R/bench.py --steps 3 --warmup 4 --headline-only $*"   # (a drop-in graph is prepared at its second call: steady from call 3)
 rocprofv3 --kernel-trace --stats -T -d $OUT/trace -o bench -f csv -- $BENCH > $OUT/trace_stdout.log 2>&1
+# PMC=0 skips the counter passes (kernel trace only)
+if [ "${PMC:-1}" != "0" ]; then
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM" \
            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_sum" \
@@ -22,6 +24,7 @@ done
 # FETCH_SIZE / WRITE_SIZE calibration on a known 1 GiB device copy
 rocprofv3 --pmc FETCH_SIZE -T -d $OUT/calib_fetch -o pmc -f csv -- python $R/tools/calib_copy.py > $OUT/calib_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -T -d $OUT/calib_write -o pmc -f csv -- python $R/tools/calib_copy.py > $OUT/calib_write.log 2>&1
+fi
 cd $R
 python tools/summarize_prof.py $OUT > $OUT/SUMMARY.md 2> $OUT/summarize.err
 cat $OUT/SUMMARY.md
