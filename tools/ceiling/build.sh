@@ -8,3 +8,4 @@ cd "$(dirname "$0")"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared push_probe2.hip -o libpush2.so
 for r in 72 64; do /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DPUSH_R=$r push_probe3.hip -o libpush3_r$r.so; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared push_probe4.hip -o libpush4.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared l1_policy_probe.hip -o libl1policy.so
