@@ -337,17 +337,38 @@ int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in
 // fits the accumulators in at most two sets (Reddit-like: 233 K rows of 492 edges; products-like needs 21 sets and loses
 // 15 %, the 65-edge rows of an 8-rank shard's local part lose 40 %), (c) sources and destinations are the same node set
 // and the source matrix is Infinity-Cache sized (the multi-GPU shapes -- 8 x the source rows, 32 phases -- lose 10 %),
-// and (d) the schedule is sliced anyway.  It takes twice the streaming kernel's phase count (no flush per piece), at most 16
+// (d) the schedule is sliced anyway, and (e) the column ids are scattered (see below).  It takes twice the streaming kernel's phase count (no flush per piece), at most 16
 // and at most partSize / 4.
-int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
-                      double edges, int B, int num_cus, bool deterministic, int part_size)
+// Share of the edges whose source lies within `half_rows` rows of the destination row (log-linear between the half-octave
+// thresholds of the counting pass' histogram).
+static double near_share(const SlicePlanStats &st, double half_rows)
 {
+    if (st.edges <= 0 || half_rows < 256.0) return 0.0;
+    const double pos = std::min(23.0, 2.0 * std::log2(half_rows / 256.0));
+    const int k = (int)pos;
+    const double lo = st.near[k], hi = st.near[std::min(23, k + 1)];
+    return (lo + (hi - lo) * (pos - k)) / st.edges;
+}
+
+int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
+                      const SlicePlanStats &st, int B, int num_cus, bool deterministic, int part_size)
+{
+    const double edges = st.edges;
     if (t.sweep != 0 || deterministic || B < 2) return 0;
     if (dim <= 32 || dim > 64 || !sweep_supports(mode, dim, x_bytes)) return 0;
     if (num_in_rows != num_out_rows || x_bytes > ((size_t)160 << 20)) return 0;
     if (edges < 300.0 * (double)std::max<int64_t>(1, num_out_rows)) return 0;
     const double cap = (double)sweep_acc_rows(dim, 1) * 0.9 * (double)std::max(8, num_cus);
     if ((double)num_out_rows > 2.0 * cap) return 0;
+    // (e) the ids are SCATTERED: every destination row has about the same share of its edges in every source slice.  In a
+    // locality order (a renumbered graph, a dataset that ships community-ordered) a set's edges sit in the one or two slices
+    // around its own rows: the workgroups of an XCD -- whose sets are neighbours -- then all run their heavy items in the same
+    // steps on 2 slices' worth of rows, and the lock-step walk that keeps ONE slice in the L2 is what hurts.  Measured, round 5
+    // (profiles/r5/sweep_vs_stream_on_locality_orders_before_fix.log, Reddit-like with hidden locality, D = 64): ids scrambled
+    // sweep 1.33 ms / streaming 1.42; Rabbit order 1.94 / 1.34; the library's own renumbering and the planted order 1.91-1.94
+    // against 1.16-1.19 single pass.  Share of the edges within one sweep slice (1/16 of the rows) of their destination: 0.13
+    // scrambled (uniform: 1/8), 0.75-0.89 for the three locality orders.
+    if (near_share(st, (double)num_in_rows / 16.0) > 0.30) return 0;
     if (t.column_phases >= 2) return B;                 // a forced / measured phase count is taken as it is
     // a work item is 64 groups of one phase: keep it at >= ~256 edges (partSize 32: 8 phases 1.45 ms, 16 phases 1.64)
     return std::max(2, std::min(std::min(16, 2 * B), std::max(2, part_size / 4)));
@@ -365,14 +386,13 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
             // ~0.75 (after gnna_reorder_community_i32) run fastest single pass; a random labelling has ~0.06.
             const double row_bytes = (double)x_bytes / ((double)slice_rows * S);
             const double half_rows = 1.75 * 1048576.0 / row_bytes;
-            double share = 0.0;
-            if (half_rows >= 256.0) {
-                const double pos = std::min(23.0, 2.0 * std::log2(half_rows / 256.0));
-                const int k = (int)pos;
-                const double lo = st.near[k], hi = st.near[std::min(23, k + 1)];
-                share = (lo + (hi - lo) * (pos - k)) / st.edges;
-            }
-            if (share >= 0.6) return 1;
+            // Round 5 (profiles/r5/sweep_and_stream_over_locality.log): long rows over an Infinity-Cache-resident matrix
+            // (Reddit-like, 492 edges per row, 60 MB) keep paying for slices up to a share of ~0.77 -- share 0.67: single pass
+            // 1.60 ms, 8 slices 1.39; share 0.81: 1.23 against 1.32 -- because a long row's flush per slice is cheap and a
+            // miss of the L2 still costs a trip to the Infinity Cache; short rows over an HBM-resident matrix (products-like,
+            // 49 edges per row, 627 MB) at a share of 0.62 run 2.06 ms single pass against 2.40 with two slices.
+            const bool long_rows_cached = st.edges >= 200.0 * (double)std::max<int64_t>(1, num_out_rows) && x_bytes <= (size_t)250000000;
+            if (near_share(st, half_rows) >= (long_rows_cached ? 0.75 : 0.6)) return 1;
         }
         if (st.cells[0] <= 1.15 * st.groups) return 1;       // every group inside one slice
     }
@@ -674,7 +694,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
     // ---- destination-blocked sweep (gnna_sweep.hip): the sliced schedule with the partial rows kept in LDS across
     // the slices -- no flush per (row, slice) piece, so it takes finer slices than the streaming kernel's rule.
     const int auto_Bs = (cnt && !windowed && plan.stats.valid)
-                            ? sweep_auto_phases(tune, mode, dim, foot_bytes, num_nodes, num_in_rows, plan.stats.edges, B, ds->num_cus,
+                            ? sweep_auto_phases(tune, mode, dim, foot_bytes, num_nodes, num_in_rows, plan.stats, B, ds->num_cus,
                                                 tune.deterministic == 1, partSize) : 0;
     if (cnt && !windowed && dim >= 4 && (tune.sweep == 1 || auto_Bs > 0) && tune.deterministic != 1 && sweep_supports(mode, dim, x_bytes)) {
         int Bs = B;
@@ -915,7 +935,7 @@ int gnna_prepare_graph(const int32_t *column_index, const int32_t *part_pointers
             // the kernel that will run at this width: the sweep (its own phase count, 64 groups per chunk) for the unweighted
             // and pre-scaled calls where the library picks it, the streaming kernel for everything else -- and for the
             // per-edge GCN form (gcn_prescale = 2) at any width, which the sweep does not run
-            int Bs = sweep_auto_phases(t, MODE_SAG, dim, foot_bytes, num_out_rows, num_in_rows, plan.stats.edges, B, ds->num_cus,
+            int Bs = sweep_auto_phases(t, MODE_SAG, dim, foot_bytes, num_out_rows, num_in_rows, plan.stats, B, ds->num_cus,
                                        t.deterministic == 1, partSize);
             if (t.sweep == 1 && t.deterministic != 1 && sweep_supports(MODE_SAG, dim, x_bytes))
                 Bs = t.column_phases >= 2 ? B : std::max(2, std::min(std::min(16, 2 * B), std::max(2, partSize / 4)));

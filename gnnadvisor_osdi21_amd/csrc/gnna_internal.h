@@ -181,7 +181,7 @@ int sweep_acc_rows(int dim, int wgs_per_cu);   // destination rows a workgroup's
 int launch_sweep(DeviceState *ds, const SweepLaunch &a, hipStream_t stream);
 // Phases of the sweep kernel when the library picks it on its own (gnna_tuning.sweep = 0) for this call, else 0 (gnna_agg.hip).
 int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
-                      double edges, int B, int num_cus, bool deterministic, int part_size);
+                      const SlicePlanStats &st, int B, int num_cus, bool deterministic, int part_size);
 // a call block of the sweep kernel: kXcds step counters 64 bytes apart, then the ReLU epilogue's
 constexpr int kSweepListCap = 1023;    // list of row ranges the kernel did not store once: [count][overflow][(first, rows) ...]
 constexpr int kSweepSlotWords = 8 * 16 + 2 + 2 * kSweepListCap;

@@ -187,6 +187,43 @@ def test_the_library_picks_the_sweep_kernel_only_where_it_wins():
     _lib.release_graph(None)
 
 
+def test_the_library_keeps_locality_ordered_graphs_off_the_sweep_kernel():
+    """Round 5: the lock-step walk of the sweep kernel pays only for SCATTERED ids.  A long-row graph with half of its
+    edges within a window of the destination's id (what a community order -- Rabbit-ordered data, a renumbered graph -- looks
+    like to the kernel) ran 1.72 ms on the sweep kernel against 1.42 on the streaming kernel's sliced schedule at Reddit size
+    (profiles/r5/sweep_and_stream_over_locality.log; the Rabbit-ordered graph itself 1.94 against 1.34): sweep_auto_phases
+    now reads the share of the edges within one sweep slice (1/16 of the rows) of their destination and stays out above 0.3.
+    Such a graph still runs SLICED (its share inside an L2-sized window is below the single-pass threshold), on stream_kernel;
+    the same graph with scrambled ids takes the sweep kernel as before.  Both give the exact known answer."""
+    t = _lib.get_tuning()
+    if t["column_phases"] != 0 or t["sweep"] != 0 or t["deterministic"] != 0 or t["wide_blocks"] != 0:
+        pytest.skip("GNNA_TUNE forces the schedule: the automatic choice is not under test")
+    n = 80000
+    g = graph.powerlaw_graph(n, 32000000, 8000, seed=5, device="cuda", locality=0.5, window=2048)      # ~400 edges per row
+    rows = torch.repeat_interleave(torch.arange(n, device="cuda"), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+    share = float(((rows - g.column_index.long()).abs() < n / 16).float().mean())
+    assert 0.45 < share < 0.7, share
+    perm = torch.randperm(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    g_scr = graph.graph_from_edges(perm[rows], perm[g.column_index.long()], n)
+    X = torch.ones(n, 64, device="cuda")
+    _lib.reset_tuning()
+    try:
+        for name, gg, swept in (("half of the edges local", g, 0), ("scrambled", g_scr, 1)):
+            pp, p2n = _lib.build_part(64, gg.row_pointers.cpu())
+            ppd, p2nd = pp.cuda(), p2n.cuda()
+            before = _lib.runtime_counters()["sweep_launches"]
+            y = _lib.sag(X, gg.row_pointers, gg.column_index, gg.degrees, ppd, p2nd, 64, 32, 4)
+            torch.cuda.synchronize()
+            k = _lib.runtime_counters()["sweep_launches"] - before
+            assert k == swept, (name, k, _lib.last_num_phases())
+            assert _lib.last_num_phases() >= 2, (name, _lib.last_num_phases())
+            deg = (gg.row_pointers[1:] - gg.row_pointers[:-1]).to(torch.float32)
+            assert torch.equal(y, deg[:, None].expand(n, 64)), name
+    finally:
+        _lib.reset_tuning()
+        _lib.release_graph(None)
+
+
 def test_sweep_rows_beyond_the_accumulators_take_the_atomic_path():
     """Low-degree rows: a set (1/256 of the edges with one set per workgroup) spans more destination rows than the
     CU's LDS holds (256 rows of 128 floats, 512 of 64) -- the rows beyond are flushed per slice with atomics."""

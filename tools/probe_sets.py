@@ -17,7 +17,8 @@ from gnnadvisor_osdi21_amd import _lib, graph  # noqa: E402
 dev = torch.device("cuda:0")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "reddit-like"
 orders = (sys.argv[2] if len(sys.argv) > 2 else "scrambled,product,rabbit,planted").split(",")
-D, ps = 64, 128
+D, ps = 64, int(os.environ.get("PROBE_PS", "128"))
+RS = [int(v) for v in os.environ.get("PROBE_RS", "2,3,4,6,8").split(",") if v]
 g0 = graph.make_config_graph(cfg, device="cpu", locality=0.9, scale=1.0)
 n = g0.num_nodes
 rows = torch.repeat_interleave(torch.arange(n), (g0.row_pointers[1:] - g0.row_pointers[:-1]).long())
@@ -69,12 +70,12 @@ for order in orders:
     before = _lib.runtime_counters()["sweep_launches"]
     rec["library_choice_ms"] = timeit()
     rec["library_choice"] = dict(phases=_lib.last_num_phases(), sweep=_lib.runtime_counters()["sweep_launches"] > before, exact=exact())
-    for R in (2, 3, 4, 6, 8):
+    for R in RS:
         _lib.reset_tuning()
         _lib.set_tuning(pack_ids=1, sweep=1, column_phases=16, groups_per_chunk=64 * R)
         rec[f"sweep_R{R}_ms"] = timeit()
         rec[f"sweep_R{R}_exact"] = exact()
-    for B in (8, 16):
+    for B in (1, 2, 4, 8, 16):
         _lib.reset_tuning()
         _lib.set_tuning(pack_ids=1, sweep=2, column_phases=B)
         rec[f"stream_{B}_phases_ms"] = timeit()
