@@ -43,6 +43,10 @@ CASES = [
     ("reddit-like", lambda: graph.make_config_graph("reddit-like", device="cuda"), (41, 100)),
     ("products-like-half", lambda: graph.make_config_graph("products-like", device="cuda", scale=0.5), (64,)),
     ("amazon0505-like", lambda: graph.make_config_graph("amazon0505-like", device="cuda"), (64,)),
+    # round 5: long rows whose ids are partly local (what a community order looks like to the kernel): the sweep kernel's
+    # lock-step walk loses there, and single pass only wins once ~3/4 of the edges sit inside an L2-sized window
+    ("reddit-like-half-local", lambda: graph.make_config_graph("reddit-like", device="cuda", locality=0.5), (64,)),
+    ("reddit-like-two-thirds-local", lambda: graph.make_config_graph("reddit-like", device="cuda", locality=0.65), (64, 48)),
 ]
 FORCED = [("stream-1", dict(column_phases=1, sweep=2)), ("stream-4", dict(column_phases=4, sweep=2)),
           ("stream-8", dict(column_phases=8, sweep=2)), ("stream-16", dict(column_phases=16, sweep=2)),
