@@ -2,7 +2,7 @@
 with a share `locality` of their edges within +-4,096 ids of the destination (planted order, not scrambled): kernel ms of the
 sweep kernel forced (16 phases), the streaming kernel at its own phase count and single pass, and of the library's own
 choice -- beside the statistic the choice goes by (share of the edges within 1/16 of the rows of their destination).
-usage: probe_locality_threshold.py [localities]"""
+usage: probe_locality_threshold.py [localities]      (PROBE_D = row width, default 64)"""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ from gnnadvisor_osdi21_amd import _lib, graph  # noqa: E402
 
 dev = torch.device("cuda:0")
 locs = [float(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "0,0.15,0.25,0.35,0.5,0.65,0.8").split(",")]
-D, ps = 64, 128
+D, ps = int(os.environ.get("PROBE_D", "64")), 128
 for loc in locs:
     g = graph.make_config_graph("reddit-like", device=dev, locality=loc)
     n = g.num_nodes
@@ -37,7 +37,7 @@ for loc in locs:
         torch.cuda.synchronize()
         return round(_lib.profile_end()["main_ms"], 4)
 
-    rec = dict(locality=loc, nnz=int(g.column_index.numel()), share_within_a_sixteenth_of_the_rows=round(share, 3))
+    rec = dict(D=D, locality=loc, nnz=int(g.column_index.numel()), share_within_a_sixteenth_of_the_rows=round(share, 3))
     _lib.reset_tuning(); _lib.set_tuning(pack_ids=1)
     before = _lib.runtime_counters()["sweep_launches"]
     rec["library_choice_ms"] = timeit()
