@@ -391,8 +391,12 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
             // 1.60 ms, 8 slices 1.39; share 0.81: 1.23 against 1.32 -- because a long row's flush per slice is cheap and a
             // miss of the L2 still costs a trip to the Infinity Cache; short rows over an HBM-resident matrix (products-like,
             // 49 edges per row, 627 MB) at a share of 0.62 run 2.06 ms single pass against 2.40 with two slices.
+            // Not for rows of exactly one 128-byte line (D = 17 .. 32): at a share of 0.69 they run 0.699 ms single pass against
+            // 0.740 with four slices (one line per edge to save, a whole line to flush per piece), while D = 16 (half a line
+            // to flush) gains 4 % from the slices and D = 128 (two 64-float blocks) 9 % (`…/locality_threshold_other_widths.log`).
             const bool long_rows_cached = st.edges >= 200.0 * (double)std::max<int64_t>(1, num_out_rows) && x_bytes <= (size_t)250000000;
-            if (near_share(st, half_rows) >= (long_rows_cached ? 0.75 : 0.6)) return 1;
+            const bool one_line_rows = row_bytes > 64.0 && row_bytes <= 128.0;
+            if (near_share(st, half_rows) >= (long_rows_cached && !one_line_rows ? 0.75 : 0.6)) return 1;
         }
         if (st.cells[0] <= 1.15 * st.groups) return 1;       // every group inside one slice
     }

@@ -46,7 +46,7 @@ CASES = [
     # round 5: long rows whose ids are partly local (what a community order looks like to the kernel): the sweep kernel's
     # lock-step walk loses there, and single pass only wins once ~3/4 of the edges sit inside an L2-sized window
     ("reddit-like-half-local", lambda: graph.make_config_graph("reddit-like", device="cuda", locality=0.5), (64,)),
-    ("reddit-like-two-thirds-local", lambda: graph.make_config_graph("reddit-like", device="cuda", locality=0.65), (64, 48)),
+    ("reddit-like-two-thirds-local", lambda: graph.make_config_graph("reddit-like", device="cuda", locality=0.65), (64, 48, 32, 16)),
 ]
 FORCED = [("stream-1", dict(column_phases=1, sweep=2)), ("stream-4", dict(column_phases=4, sweep=2)),
           ("stream-8", dict(column_phases=8, sweep=2)), ("stream-16", dict(column_phases=16, sweep=2)),
