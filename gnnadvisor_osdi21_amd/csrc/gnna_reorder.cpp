@@ -54,6 +54,18 @@ void parallel_nodes(int64_t n, int threads, F &&fn)
     for (auto &t : th) t.join();
 }
 
+// a few coarse tasks (chunks of a sort, pairs of a merge round), one thread each up to `threads`
+template <typename F>
+void parallel_tasks(int64_t count, int threads, F &&fn)
+{
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(threads, count));
+    if (nt == 1) { for (int64_t i = 0; i < count; i++) fn(i); return; }
+    std::vector<std::thread> th;
+    for (int64_t t = 0; t < nt; t++)
+        th.emplace_back([&fn, t, nt, count] { for (int64_t i = t; i < count; i += nt) fn(i); });
+    for (auto &t : th) t.join();
+}
+
 int host_threads() { return gnna::host_thread_budget(64); }      // (the CPUs the container is granted, not the ones it sees)
 
 }  // namespace
@@ -393,11 +405,28 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     // ---- 3. barycentre refinement ----------------------------------------------------------------------------
     std::vector<int32_t> perm((size_t)n);
     // positions -> ranks, so that the arrangement does not contract (ties: by node id); returns how far a node moved on average
+    // (the order is total -- position, then node id -- so the result does not depend on how the sort is split: the chunks are
+    // sorted by the threads and merged pairwise; up to 17 of these per call since the sweeps run until settled)
+    std::vector<std::pair<double, int32_t>> keyed((size_t)n), merged((size_t)n);
     auto respread = [&]() -> double {
-        std::iota(perm.begin(), perm.end(), 0);
-        std::sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b2) {
-            return nxt[(size_t)a] < nxt[(size_t)b2] || (nxt[(size_t)a] == nxt[(size_t)b2] && a < b2);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t v = lo; v < hi; v++) keyed[(size_t)v] = std::make_pair(nxt[(size_t)v], (int32_t)v);
         });
+        const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(threads, n / 65536 + 1));
+        const int64_t step = (n + chunks - 1) / chunks;
+        parallel_tasks(chunks, threads, [&](int64_t c) {
+            std::sort(keyed.begin() + std::min(n, c * step), keyed.begin() + std::min(n, (c + 1) * step));
+        });
+        auto *from = &keyed, *to = &merged;
+        for (int64_t width = step; width < n; width *= 2) {
+            const int64_t pairs = (n + 2 * width - 1) / (2 * width);
+            parallel_tasks(pairs, threads, [&](int64_t p) {
+                const int64_t a = p * 2 * width, m = std::min(n, a + width), z = std::min(n, a + 2 * width);
+                std::merge(from->begin() + a, from->begin() + m, from->begin() + m, from->begin() + z, to->begin() + a);
+            });
+            std::swap(from, to);
+        }
+        for (int64_t r = 0; r < n; r++) perm[(size_t)r] = (*from)[(size_t)r].second;
         double moved = 0.0;
         for (int64_t r = 0; r < n; r++) {
             double &p = pos[(size_t)perm[(size_t)r]];
