@@ -120,6 +120,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                 __atomic_fetch_add(&cursor[(size_t)dst[e] + 1], 1, __ATOMIC_RELAXED);
             }
         });
+        lap("  adjacency: counted");
         for (int64_t v = 0; v < n; v++) cursor[(size_t)v + 1] += cursor[(size_t)v];
         std::vector<int64_t> start(cursor.begin(), cursor.end());
         std::vector<int32_t> bucket((size_t)(2 * num_edges));
@@ -129,6 +130,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                 bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)dst[e]], 1, __ATOMIC_RELAXED)] = src[e];
             }
         });
+        lap("  adjacency: scattered");
         std::vector<int32_t> uniq((size_t)n, 0);
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
             for (int64_t v = lo; v < hi; v++) {
@@ -137,6 +139,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                 uniq[(size_t)v] = (int32_t)(std::unique(b, e) - b);
             }
         });
+        lap("  adjacency: rows sorted");
         for (int64_t v = 0; v < n; v++) rp[(size_t)v + 1] = rp[(size_t)v] + uniq[(size_t)v];
         ci.resize((size_t)rp[(size_t)n]);
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
@@ -182,9 +185,21 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                     if (ve - vb > ue - ub || (ve - vb == ue - ub && v >= u)) continue;     // (the pair is v's to count)
                     const int32_t need = std::max<int32_t>(T, (int32_t)std::ceil(3.0 * chance * (double)(ue - ub) * (double)(ve - vb)));
                     int32_t common = 0;
-                    for (int64_t j = vb; j < ve && common < need; j++) {
-                        const int32_t x = ci[(size_t)j];
-                        common += (int32_t)((mark[(size_t)x >> 6] >> (x & 63)) & 1ull);
+                    // (eight probes between two looks at the exit condition: the decision -- common >= need -- is the same)
+                    int64_t j = vb;
+                    const int32_t *cj = ci.data();
+                    const uint64_t *mk = mark.data();
+                    for (; j + 8 <= ve && common < need; j += 8) {
+                        int32_t c8 = 0;
+                        for (int q = 0; q < 8; q++) {
+                            const uint32_t x = (uint32_t)cj[j + q];
+                            c8 += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
+                        }
+                        common += c8;
+                    }
+                    for (; j < ve && common < need; j++) {
+                        const uint32_t x = (uint32_t)cj[j];
+                        common += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
                     }
                     if (common >= need) {
                         keep[(size_t)k] = 1;
