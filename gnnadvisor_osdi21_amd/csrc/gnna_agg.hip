@@ -320,10 +320,22 @@ int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in
 
 }  // namespace
 
+// Share of the edges whose source lies within `half_rows` rows of the destination row (log-linear between the half-octave
+// thresholds of the counting pass' histogram).
+static double near_share(const SlicePlanStats &st, double half_rows)
+{
+    if (st.edges <= 0 || half_rows < 256.0) return 0.0;
+    const double pos = std::min(23.0, 2.0 * std::log2(half_rows / 256.0));
+    const int k = (int)pos;
+    const double lo = st.near[k], hi = st.near[std::min(23, k + 1)];
+    return (lo + (hi - lo) * (pos - k)) / st.edges;
+}
+
 // Number of phases of the sliced schedule from the slice statistics of the partition (st.cells[l] =
 // non-empty (group, slice) cells when the S = 32 fine slices are merged into S >> l).
-//  * not at all when the column ids of a row stay near the row (>= 60 % of the edges within a window of source
-//    rows that fits an XCD's L2: a locality-ordered graph gathers from a small moving window already) --
+//  * not at all when the column ids of a row stay near the row (>= 60 % of the edges -- 75 % for long rows over an
+//    Infinity-Cache-resident matrix, round 5 -- within a window of source rows that fits an XCD's L2: a locality-ordered
+//    graph gathers from a small moving window already) --
 //    measurable when rows and columns share one numbering; a caller's "scattered ids" hint settles it otherwise;
 //  * slices of at most 8 MiB of source rows (Reddit-like graph, D = 16 / 32 / 64 / 128: best 4 / 4 / 8 / 16
 //    phases; two slices are live while the chip moves from one to the next, and an XCD's L2 is 4 MiB);
@@ -337,19 +349,8 @@ int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in
 // fits the accumulators in at most two sets (Reddit-like: 233 K rows of 492 edges; products-like needs 21 sets and loses
 // 15 %, the 65-edge rows of an 8-rank shard's local part lose 40 %), (c) sources and destinations are the same node set
 // and the source matrix is Infinity-Cache sized (the multi-GPU shapes -- 8 x the source rows, 32 phases -- lose 10 %),
-// (d) the schedule is sliced anyway, and (e) the column ids are scattered (see below).  It takes twice the streaming kernel's phase count (no flush per piece), at most 16
-// and at most partSize / 4.
-// Share of the edges whose source lies within `half_rows` rows of the destination row (log-linear between the half-octave
-// thresholds of the counting pass' histogram).
-static double near_share(const SlicePlanStats &st, double half_rows)
-{
-    if (st.edges <= 0 || half_rows < 256.0) return 0.0;
-    const double pos = std::min(23.0, 2.0 * std::log2(half_rows / 256.0));
-    const int k = (int)pos;
-    const double lo = st.near[k], hi = st.near[std::min(23, k + 1)];
-    return (lo + (hi - lo) * (pos - k)) / st.edges;
-}
-
+// (d) the schedule is sliced anyway, and (e) the column ids are scattered (see below).  It takes twice the streaming kernel's
+// phase count (no flush per piece), at most 16 and at most partSize / 4.
 int sweep_auto_phases(const gnna_tuning &t, int mode, int dim, size_t x_bytes, int64_t num_out_rows, int64_t num_in_rows,
                       const SlicePlanStats &st, int B, int num_cus, bool deterministic, int part_size)
 {
