@@ -23,7 +23,9 @@
 // (schedule(static, 1), retry queues) and sorts the merge order with a parallel, unstable sort, so its permutation differs
 // from run to run; this file is the np = 1 execution with ties of equal degree broken by vertex id.  PARITY UNPINNED: the
 // vendored source needs boost, libnuma and tcmalloc, none of which is in the image, so no output of the reference itself
-// exists to compare with -- the invariants of its own check_result (:700-740) are asserted instead (tests/test_rabbit_yardstick.py).
+// exists to compare with.  What pins this file instead (tests/test_rabbit_yardstick.py): a case walked by hand, the invariants
+// of the reference's own check_result (:700-740), and a SECOND restatement written independently from the reference's text in
+// plain Python (dictionaries, no shared code) that must give the identical permutation on 60 random multigraphs.
 #include <algorithm>
 #include <chrono>
 #include <cstdint>

@@ -58,6 +58,102 @@ def test_edge_list_conventions_of_the_reference():
         pass
 
 
+def _py_rabbit(src, dst, n):
+    """A SECOND, independent restatement of the same algorithm in plain Python (dictionaries instead of sorted vectors,
+    recursion-free), written from the reference's text -- adjacency reorder.cpp:28-90; merge order rabbit_order.hpp:527-538;
+    unite :391-441; find_best :447-459; merge :470-522; compute_perm :633-673 -- not from the C++ restatement.  Small graphs
+    only.  All weights are small integers, so float32 / float64 make no difference to any comparison."""
+    adj = [dict() for _ in range(n)]
+    for s, t in zip(src.tolist(), dst.tolist()):
+        if s != t:
+            adj[s][t] = adj[s].get(t, 0.0) + 1.0
+            adj[t][s] = adj[t].get(s, 0.0) + 1.0
+    es = [sorted(a.items()) for a in adj]
+    strength = [float(sum(w for _, w in e)) for e in es]
+    total = float(sum(strength))
+    coms = list(range(n))
+    child, sibling, united = [None] * n, [None] * n, [None] * n
+
+    def trace(v):
+        c = v
+        while coms[c] != c:
+            c = coms[c]
+        return c
+
+    tops = []
+    for v in sorted(range(n), key=lambda u: (len(es[u]), u)):
+        nb = {}
+
+        def push(u):
+            for t, w in es[u]:
+                c = trace(t)
+                if c != v:
+                    nb[c] = nb.get(c, 0.0) + w
+        push(v)
+        while united[v] != child[v]:
+            c = child[v]
+            w_ = c
+            while w_ is not None and w_ != united[v]:
+                push(w_)
+                w_ = sibling[w_]
+            united[v] = c
+        es[v] = sorted(nb.items())
+        vstr = strength[v]
+        strength[v] = -1.0
+        best, dmax = v, 0.0
+        for t, w in es[v]:
+            d = w - vstr * strength[t] / total
+            if dmax < d:
+                dmax, best = d, t
+        if best == v:
+            strength[v] = vstr
+            tops.append(v)
+        else:
+            sibling[v] = child[best]
+            child[best] = v
+            strength[best] += vstr
+            coms[v] = best
+    new_id = [0] * n
+    base = 0
+    for top in tops:
+        stack, k = [], 0
+
+        def descendants(u):
+            while u is not None:
+                stack.append(u)
+                u = child[u]
+        descendants(top)
+        while stack:
+            u = stack.pop()
+            new_id[u] = base + k
+            k += 1
+            if sibling[u] is not None:
+                descendants(sibling[u])
+        base += k
+    return np.array(new_id, dtype=np.int32), len(tops)
+
+
+def test_two_independent_restatements_agree_on_random_small_graphs():
+    """The C++ restatement (oracle/rabbit_yardstick.cpp) and the plain-Python one above produce the SAME permutation and the
+    same number of communities on 60 random multigraphs with loops, duplicates, one-directional entries and isolated
+    vertices -- what pins the yardstick in the absence of the reference's binary."""
+    rng = np.random.default_rng(2024)
+    for case in range(60):
+        n = int(rng.integers(1, 120))
+        m = int(rng.integers(0, 6 * n + 1))
+        if case % 3 == 0:                                        # planted blocks: merges that matter
+            k = max(1, n // 12)
+            s = rng.integers(0, n, m)
+            d = np.where(rng.random(m) < 0.8, (s // k) * k + rng.integers(0, k, m), rng.integers(0, n, m)).clip(0, n - 1)
+        else:
+            s, d = rng.integers(0, n, m), rng.integers(0, n, m)
+        s, d = s.astype(np.int32), d.astype(np.int32)
+        got, st = oracle.rabbit_yardstick(s, d, n)
+        want, ntops = _py_rabbit(s, d, n)
+        assert st["communities"] == ntops, (case, n, m)
+        assert np.array_equal(got, want), (case, n, m)
+
+
 def test_invariants_on_random_graphs_and_reproducibility():
     """What the reference asserts about its own result: the permutation is a bijection (compute_perm, :668-671); the
     members of a top-level community are numbered contiguously (offsets, :655-662); and a merge only ever happens for a
