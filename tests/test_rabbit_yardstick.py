@@ -178,11 +178,21 @@ def test_invariants_on_random_graphs_and_reproducibility():
 
 
 def test_native_renumbering_against_the_rabbit_yardstick():
-    """Row f-3's quality bar made explicit: on graphs with hidden locality and scrambled ids the product's renumbering
+    """Row f-3's quality bar made explicit: on graphs with hidden structure and scrambled ids the product's renumbering
     (gnna_reorder_community_i32) leaves a mean edge span (the reference's own locality measure, dataset.py:99-100) no
     worse than 1.15 x what Rabbit Order -- the algorithm the reference runs -- reaches on the same edge list."""
-    for n, e, window, seed in ((20000, 1_200_000, 400, 3), (50000, 2_000_000, 1000, 5)):
-        g = graph.powerlaw_graph(n, e, 1500, locality=0.9, window=window, seed=seed)
+    cases = [
+        ("window 400", lambda: graph.powerlaw_graph(20000, 1_200_000, 1500, locality=0.9, window=400, seed=3)),
+        ("window 1000", lambda: graph.powerlaw_graph(50000, 2_000_000, 1500, locality=0.9, window=1000, seed=5)),
+        # families neither algorithm was shaped on: planted blocks (Rabbit Order's home ground) and R-MAT (no communities
+        # to speak of: Rabbit finds thousands) -- measured span ratios product / Rabbit: 0.86, 0.80, 0.62
+        ("100 blocks", lambda: graph.community_graph(50000, 3_000_000, 100, p_in=0.9, seed=7)),
+        ("300 blocks, 80 % inside", lambda: graph.community_graph(30000, 1_500_000, 300, p_in=0.8, seed=8)),
+        ("R-MAT 2^15", lambda: graph.rmat_graph(1 << 15, 2_000_000, seed=3)),
+    ]
+    for name, make in cases:
+        g = make()
+        n = g.num_nodes
         rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
         cols = g.column_index.long()
         perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
@@ -193,5 +203,5 @@ def test_native_renumbering_against_the_rabbit_yardstick():
         span_ours = _lib.edge_span(ours[src], ours[dst])
         span_rabbit = _lib.edge_span(rb[src], rb[dst])
         span_scrambled = _lib.edge_span(src, dst)
-        assert span_rabbit < 0.5 * span_scrambled, (span_rabbit, span_scrambled, st)   # the yardstick itself works here
-        assert span_ours <= 1.15 * span_rabbit, (span_ours, span_rabbit, span_scrambled)
+        assert span_rabbit < (0.8 if name.startswith("R-MAT") else 0.5) * span_scrambled, (name, span_rabbit, span_scrambled, st)   # the yardstick itself works here
+        assert span_ours <= 1.15 * span_rabbit, (name, span_ours, span_rabbit, span_scrambled)
