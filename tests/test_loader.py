@@ -251,3 +251,36 @@ def test_rmat_and_community_generators_are_seeded_symmetric_and_shaped_as_named(
     assert inside > 0.8
     cs = graph.community_graph(6000, 120000, 10, seed=2, p_in=0.9, scramble=True)
     assert cs.nnz == c.nnz and cs.avg_edgeSpan > 2.5 * c.avg_edgeSpan
+
+
+def test_renumbering_and_csr_do_not_depend_on_the_thread_count():
+    """The host passes split their work by the threads the container grants (GNNA_HOST_THREADS overrides the count, read
+    once per process): the community renumbering -- chunked sort + pairwise merge of the re-spread, per-thread bitmaps of
+    the backbone, slabs of the adjacency scatter -- and the native CSR builder must return the same arrays for 1, 3 and 8
+    threads.  A graph of 150,000 nodes, so that the re-spread really runs in several chunks (one per 65,536 nodes)."""
+    import hashlib
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from gnnadvisor_osdi21_amd import _lib, graph
+g = graph.powerlaw_graph(150000, 3000000, 600, locality=0.8, window=700, seed=21)
+n = g.num_nodes
+rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long())
+perm = torch.randperm(n, generator=torch.Generator().manual_seed(2))
+src, dst = perm[rows].to(torch.int32), perm[g.column_index.long()].to(torch.int32)
+p = _lib.reorder_community(src, dst, n)
+rp, ci = graph.csr_from_edges(src.long(), dst.long(), n)
+h = hashlib.sha256()
+for t in (p, rp, ci):
+    h.update(t.numpy().tobytes())
+print("DIGEST", h.hexdigest())
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, GNNA_HOST_THREADS=threads)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[threads] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
+    assert len(set(digests.values())) == 1, digests
