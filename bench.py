@@ -15,34 +15,36 @@ auto mode (`--manual` = the reference's manual mode, partSize 32, single pass).
 weak-scaling leg -- every rank owns a Reddit-sized block of destination rows whose sources are drawn from all
 ranks' nodes; each step exchanges source features over RCCL/xGMI (only the referenced remote rows when that is
 clearly less than the whole blocks, `--exchange`) and aggregates locally (gnnadvisor_osdi21_amd/dist.py) -- so that
-N = 1 is the single-GPU workload.  `--scaling strong,config5` (default) adds, inside `config.legs` / `config.values`,
+N = 1 is the single-GPU workload.  `--scaling strong,config5` (default) adds, inside `config.values` (detail file: `config.legs`),
 the strong-scaling leg (the SAME Reddit-like graph as the single-GPU line, split into N nnz-balanced destination
 blocks) and, at 8 ranks (or with --config5-leg), BASELINE config 5 (papers100M-like, D = 128, exchange chosen
 collectively), each verified on every rank.
 
-Rank 0 prints ONE JSON line; `value` = total aggregated edges per second over all ranks.  Everything beyond the
-contract's keys rides inside `config` (verification, other modes, the reference-style wall-clock timing, the N-rank
-legs) and `roofline` (`other_workloads`: the HBM-resident graph and config 5's per-rank shape).
+Rank 0 prints ONE compact JSON line (< 8 KB, normally ~2 KB: `compact_single` / `compact_sharded`; the driver keeps an 8 KB
+tail of stdout): the contract's keys, `config` as flat scalars, `roofline` and `cpu_baseline` as numbers.  `value` = total
+aggregated edges per second over all ranks.  The FULL record -- verification detail, the other modes, the reference-style
+wall-clock timing, the PMC detail, and with `--detail` the secondary legs (config 4's GIN widths, the HBM-resident graph,
+the node-order legs, config 5's per-rank shape, the prepared lifecycle) -- goes to `gpurun_out/bench_detail[_nN].json`
+(`--detail-file`) and a one-line summary to stderr.  Copies of the detail file are kept under profiles/.
 
 `verified`: after the timed loop the timed configuration itself is checked -- X = ones must give the
 exact row nnz in every column (the reference's own known-answer test, unitest.py:54-63), and 256
 sampled rows of the timed randn output are compared with an fp64 gather-sum.
 
-`roofline` (single-GPU line): the kernel is bound by the L2-miss path (L2 <-> Infinity Cache / HBM
-fabric), so `achieved` is the MEASURED fabric traffic of the aggregation kernel (rocprofv3 PMC passes
-FETCH_SIZE and WRITE_SIZE of this very invocation: bench.py re-runs itself as a short child under
-rocprofv3, FETCH_SIZE calibrated on a 1 GiB device copy in the same child) divided by the kernel
-time measured with HIP events on the launch stream during the timed loop; `frac` = that / 8 TB/s
-(`frac_of_achievable_6300GBs` beside it).  The gather-model rate of SURVEY.md 8(d) (bytes = nnz*(4D+4) + N*(4D+4) + P*8
-per step, which counts every gathered row whether it came from L2, Infinity Cache or HBM and therefore may exceed
-the HBM peak) and the compulsory-model rate are reported beside it, never as `frac`.
-`roofline.other_workloads.hbm_resident` repeats the measurement on a workload whose features (627 MB) exceed the
-256 MiB Infinity Cache (products-like, D = 64; bound "fabric (HBM + Infinity Cache)": a 157 MB slice still fits the
-cache), `config5_rank_of_8` / `config5_rank_of_8_halo` on BASELINE config 5 in its TRUE per-rank shape: rank 0 of 8 of a
-papers100M-like graph -- 13.9 M destination rows gathering D = 128 rows of all 111 M source nodes, from the resident
-56.9 GB all-gather buffer (one rectangular call, 64-bit offsets) and from the compact halo buffer the automatic
-exchange takes (local part + K pieces); one process plays the rank (`ShardedAggregator(emulate=...)`), the receive
-buffer is filled from the global features instead of by RCCL, so these are the KERNELS of a rank's step.
+`roofline` (definition frozen in round 5, tests/test_bench_cpu.py): `achieved` = SURVEY.md 8(d) ALGORITHMIC bytes per launch
+(gather model: nnz*(4D+4) + N*(4D+4) + P*8) / the aggregation kernel's time, measured with HIP events on the launch stream
+inside the timed loop; `peak` = the ceiling that binds -- 34.5 TB/s (the 8 L2s together) when the gathered source matrix is
+below the 256 MiB Infinity Cache (`ceiling: "l2"`, the headline: 59.6 MB), 8 TB/s otherwise (`ceiling: "hbm"`); `frac` =
+achieved / peak.  `traffic` = MEASURED fabric bytes per launch (rocprofv3 PMC child passes of this very invocation:
+FETCH_SIZE x a copy calibration made in the same child + WRITE_SIZE), `frac_hbm_measured` = traffic / kernel time / 8 TB/s
+-- the figure to quote for `ceiling == "hbm"` legs, whose gather-model `frac` can exceed 1 because repeated rows are served
+by the L2s; `l2_hit_rate`, `l2_requests_per_edge`, `frac_l2` from a TCC_HIT/TCC_MISS pass; `floor_ms` = the bare access
+stream of the timed schedule (tools/ceiling/gather_ceiling.hip), `frac_of_floor` = floor / kernel.
+With `--detail`, `roofline.other_workloads` (detail file only) repeats this on products-like graphs (627 MB of features,
+HBM-resident; GIN at D = 100 / 64; scrambled / renumbered / planted node orders) and on BASELINE config 5 in its TRUE per-rank
+shape: rank 0 of 8 of a papers100M-like graph -- 13.9 M destination rows gathering D = 128 rows of all 111 M source nodes,
+from the resident 56.9 GB all-gather buffer and from the compact halo buffer (`ShardedAggregator(emulate=...)`: the KERNELS
+of a rank's step, the receive buffer filled from the global features instead of by RCCL).
 `config.reference_style_ms`: the reference's own timing method (unitest.py:65-79: 10 warm-up + 200 GNNA.SAG calls
 through the pybind module, fresh outputs, wall clock).  `cpu_baseline` times the oracle (CPU port) on the host.
 """
@@ -116,7 +118,12 @@ def parse_args(argv=None):
     ap.add_argument("--locality", type=float, default=0.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC child passes (traffic = null)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the HBM-resident second workload")
+    ap.add_argument("--detail", action="store_true",
+                    help="also run the secondary legs (config 4 GIN widths, the HBM-resident graph, the node-order legs, config 5's "
+                         "per-rank shape, the prepared lifecycle); their records go to the detail file, never into the line")
+    ap.add_argument("--detail-file", default="",
+                    help="where the full record goes (default gpurun_out/bench_detail[_nN].json under the repo)")
+    ap.add_argument("--no-secondary", action="store_true", help="with --detail: skip the HBM-resident second workload and the node-order legs")
     ap.add_argument("--secondary-config", default="products-like")
     ap.add_argument("--prepared", action="store_true",
                     help="time the build's lifecycle extension (hints + gnna_prepare_graph + measured phases + producer-written "
@@ -1007,6 +1014,136 @@ def other_modes(w, steps: int = 10):
     return res
 
 
+# ---------------------------------------------------------------------------------------------- the line
+LINE_LIMIT = 8000       # the driver keeps an 8 KB tail of stdout: a longer line cannot be parsed (round 5's was 34.7 KB)
+LINE_TARGET = 4096
+
+
+def _clean(v, digits=7):
+    """Strict JSON for the line: no NaN / Infinity tokens, floats to `digits` significant figures."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {str(k): _clean(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_clean(x, digits) for x in v]
+    return str(v)
+
+
+def _pick(src, keys):
+    return {k: src.get(k) for k in keys if src.get(k) is not None or k in ("traffic", "vs_baseline")}
+
+
+def compact_roofline(r):
+    """The roofline object of the line: numbers and short tokens only (definitions live in DESIGN.md 5)."""
+    out = _pick(r, ("bound", "ceiling", "peak", "unit", "achieved", "frac"))
+    label = str(r.get("kernel", ""))
+    out["kernel"] = label.split(" (")[0] if label else None
+    out.update(_pick(r, ("kernel_ms", "kernel_launches_per_step", "column_phases", "prologue_ms", "traffic", "frac_hbm_measured",
+                         "l2_hit_rate", "l2_requests_per_edge", "frac_l2", "traffic_over_compulsory", "floor_ms", "frac_of_floor",
+                         "library_calls_per_step")))
+    out["algorithmic_bytes"] = r.get("algorithmic_bytes_per_launch", r.get("algorithmic_bytes_per_step"))
+    comp = r.get("compulsory_model") or {}
+    if comp.get("bytes_per_step") is not None:
+        out["compulsory_bytes"] = comp["bytes_per_step"]
+    if r.get("traffic") is None and r.get("traffic_error"):
+        out["traffic_error"] = str(r["traffic_error"])[:120]
+    if r.get("l2_hit_rate") is not None:
+        out["frac_note"] = "gather model; L2 hit %.2f" % r["l2_hit_rate"]
+    return out
+
+
+def compact_single(rec, detail_file=None):
+    """The ONE line of a single-GPU run: the contract's keys, `config` as flat scalars, `roofline` and `cpu_baseline` as
+    numbers.  Everything else of `rec` stays in the detail file."""
+    c = rec.get("config", {})
+    line = _pick(rec, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data", "verified"))
+    cfg = {"workload": c.get("workload"), "num_nodes": c.get("num_nodes_per_gpu"), "nnz": c.get("nnz_per_gpu"), "dim": c.get("dim"),
+           "partSize": c.get("partSize"), "num_parts": c.get("num_parts_per_gpu"), "feature_MB": c.get("feature_MB"),
+           "parallelism": c.get("parallelism"),
+           "call": "GNNA.SAG (pybind module, reference signature, fresh output)" if "pybind" in str(c.get("call", ""))
+                   else "gnna_agg_ld_f32 (C ABI, prepared lifecycle)",
+           "decider": "manual" if str(c.get("decider", "")).startswith("manual") else "auto/mi355x",
+           "column_phases": c.get("column_phases_used"), "build_id": c.get("build_id")}
+    cfg.update(_pick(c, ("ms_per_step_min", "ms_per_step_median", "ms_per_step_max", "reference_style_ms_hidden64",
+                         "reference_style_ms_hidden16", "gcn_weighted_value", "gin_value", "sddmm_value", "prepared_value")))
+    ver = c.get("verification") or {}
+    cfg.update({"ones_exact": ver.get("ones_exact"), "sampled_rows_ok": ver.get("sampled_rows_ok"),
+                "max_err_over_abs_ref": ver.get("max_err_over_abs_ref")})
+    if detail_file:
+        cfg["detail_file"] = detail_file
+    line["config"] = {k: v for k, v in cfg.items() if v is not None}
+    line["roofline"] = compact_roofline(rec.get("roofline", {}))
+    cb = rec.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms", "ms_min", "ms_max"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        lib = cb.get("libraries") or {}
+        for key, short in (("torch_sparse_csr", "torch_sparse_csr_value"), ("scipy_csr_1thread", "scipy_1thread_value")):
+            if isinstance(lib.get(key), dict):
+                line["cpu_baseline"][short] = lib[key].get("value")
+        line["cpu_baseline"]["dgl"] = "unavailable" if "unavailable" in str(lib.get("dgl_copy_u_sum", "unavailable")) else "importable"
+    return _clean(line)
+
+
+def compact_sharded(rec, detail_file=None):
+    """The ONE line of an N-rank run: headline (weak-scaling leg), the per-leg values, who counted the ranks."""
+    c = rec.get("config", {})
+    line = _pick(rec, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                       "vs_baseline", "dtype", "data", "verified"))
+    cfg = _pick(c, ("workload", "num_nodes_per_gpu", "nnz_per_gpu", "dim", "partSize", "num_parts_per_gpu", "source_nodes",
+                    "world_size", "backend", "communicator_ranks_counted", "parallelism", "exchange", "exchange_requested",
+                    "exchange_only_ms", "aggregate_only_ms", "exchange_GBs_per_rank", "bytes_received_per_rank_per_step",
+                    "allgather_bytes_per_rank_per_step", "decider", "force_collectives", "build_id"))
+    cfg["parallelism"] = str(cfg.get("parallelism", ""))[:120]
+    if c.get("values"):
+        cfg["values"] = {n: _pick(v, ("value", "ms_per_step", "scaling", "verified", "exchange")) for n, v in c["values"].items()}
+    if c.get("failed_legs"):
+        cfg["failed_legs"] = {n: str(v)[:120] for n, v in c["failed_legs"].items()}
+    if c.get("exchange_timed"):
+        cfg["exchange_timed"] = c["exchange_timed"]
+    if c.get("single_gpu_line"):
+        cfg["single_gpu_value"] = c["single_gpu_line"].get("value")
+        cfg["sharded_over_single"] = c["single_gpu_line"].get("sharded_over_single")
+    if detail_file:
+        cfg["detail_file"] = detail_file
+    line["config"] = cfg
+    line["roofline"] = compact_roofline(rec.get("roofline", {}))
+    return _clean(line)
+
+
+def emit(rec, result_fd, compact, args, suffix=""):
+    """Full record -> the detail file (and a short summary on stderr); the compact line -> the saved stdout."""
+    path = args.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail%s.json" % suffix)
+    shown = None
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(_clean(rec, 9), f, indent=1)
+        shown = os.path.relpath(path, ROOT)
+    except OSError as exc:                                   # (a read-only tree must not cost the line)
+        print(f"# bench.py: detail file not written ({exc})", file=sys.stderr)
+    line = compact(rec, shown)
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:                              # never print a line the driver cannot read: shed the optional keys
+        for key in ("cpu_baseline", "config"):
+            sub = line.get(key, {})
+            for k in [k for k in sub if k not in ("value", "unit", "cores", "kind", "workload", "nnz", "dim", "partSize")]:
+                sub.pop(k)
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    r = line.get("roofline", {})
+    print("# bench.py: %.4g %s, %.4f ms/step, verified %s; %s %.4f ms, frac %.3f of %s; line %d chars; detail: %s"
+          % (line.get("value") or 0, line.get("unit"), line.get("ms_per_step") or 0, line.get("verified"), r.get("kernel"),
+             r.get("kernel_ms") or 0, r.get("frac") or 0, r.get("ceiling", r.get("bound")), len(text), shown), file=sys.stderr, flush=True)
+    os.write(result_fd, (text + "\n").encode())
+
+
 # ---------------------------------------------------------------------------------------------- single GPU
 
 def leg_record(w, elapsed, prof, steps, check, traffic, what):
@@ -1043,9 +1180,10 @@ def run_single(args, result_fd):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.config, "shape": w5.describe()},
                "roofline": roofline_record(w5, p5["main_ms"], p5["prologue_ms"], None)}
-        os.write(result_fd, (json.dumps(rec) + "\n").encode())
+        emit(rec, result_fd, compact_single, args, "_rank_of")
         return
     extras = not args.headline_only
+    detail = extras and args.detail
     tmpdir = tempfile.mkdtemp(prefix="gnna_bench_", dir="/tmp")
 
     def free():
@@ -1084,7 +1222,7 @@ def run_single(args, result_fd):
         free()
 
     prepared = None
-    if extras and not args.prepared and not args.manual:
+    if detail and not args.prepared and not args.manual:
         # the build's lifecycle extension on the same graph: hints + gnna_prepare_graph + measured phase count + the
         # producer-written gapped layout through gnna_agg_ld_f32 (flat keys prepared_*; never `value`)
         wp = Workload(args.config, args.dim, dev, scale=args.scale, locality=args.locality, part_size=args.partSize,
@@ -1098,7 +1236,7 @@ def run_single(args, result_fd):
         del wp
         _lib.reset_tuning()            # (apply_tuning set process-wide knobs: the legs below run on the defaults again)
         free()
-    if extras and not args.no_secondary and args.scale == 1.0:
+    if detail and not args.no_secondary and args.scale == 1.0:
         sec = args.secondary_config
         # BASELINE config 4 in its own shape: GIN aggregation (eps x sum, GNNAdvisor_kernel.cu:620-689) of layer 1 at the
         # input width D = 100 and of layers 2-5 at D = 64; features 980 / 627 MB > Infinity Cache (HBM-resident)
@@ -1124,7 +1262,7 @@ def run_single(args, result_fd):
     # BASELINE config 5 in its true per-rank shape (rank 0 of 8; the 56.9 GB all-gather buffer, then the compact halo
     # buffer the automatic exchange takes): one after the other -- each keeps the global features resident
     fives = []
-    if extras and not args.no_config5 and args.scale == 1.0:
+    if detail and not args.no_config5 and args.scale == 1.0:
         for form in ("allgather-one-call", "halo"):
             w5 = RankOf8Workload(dev, 128, form=form, manual=args.manual, scale=args.config5_scale)
             e5, p5 = w5.time(4, 2)
@@ -1239,7 +1377,7 @@ def run_single(args, result_fd):
     if extras and not args.no_cpu_baseline:
         rec["cpu_baseline"] = cpu_baseline(g.to("cpu"), w.Xc.cpu(), w.pp, w.p2n, args.dim)
     shutil.rmtree(tmpdir, ignore_errors=True)
-    os.write(result_fd, (json.dumps(rec) + "\n").encode())
+    emit(rec, result_fd, compact_single, args)
 
 
 def desc_bytes(w5):
@@ -1522,11 +1660,12 @@ def run_sharded(args, result_fd, world, rank, local_rank):
                        "verification": {n: {"ones_exact_on_every_rank": l["verified"]} for n, l in legs.items()},
                        "legs": {n: l for n, l in legs.items() if n != "weak"}, "failed_legs": failed,
                        "values": {n: {"value": l["value"], "unit": "edges/s", "ms_per_step": l["ms_per_step"],
+                                      "verified": l["verified"], "exchange": l["exchange"],
                                       "scaling": "weak" if n == "weak" else ("strong" if n == "strong" else "config5 (fixed total graph)")}
                                   for n, l in legs.items()}},
             "roofline": {"bound": "hbm", "ceiling": roofline_ceiling(weak["source_nodes"] * D * 4)[0],
                          "peak": roofline_ceiling(weak["source_nodes"] * D * 4)[1], "unit": "GB/s",
-                         "achieved": k["gather_model"]["GBs"],
+                         "achieved": k["gather_model"]["GBs"], "algorithmic_bytes_per_step": k["gather_model"]["bytes_per_step"],
                          "frac": roofline_frac(k["gather_model"]["bytes_per_step"], t, weak["source_nodes"] * D * 4) if t > 0 else 0.0,
                          "frac_definition": "per rank: algorithmic (gather-model) bytes / kernel time (max over ranks) / ceiling, as on "
                                             "the single-GPU line (roofline_ceiling); no PMC passes in multi-rank runs",
@@ -1535,7 +1674,8 @@ def run_sharded(args, result_fd, world, rank, local_rank):
                          "compulsory_model": k["compulsory_model"], "kernel_edges_per_s": k["kernel_edges_per_s"],
                          "per_leg_kernels": {n: l["kernel"] for n, l in legs.items()}},
         }
-        os.write(result_fd, (json.dumps(rec) + "\n").encode())
+        rec["config"]["build_id"] = _lib.build_id()
+        emit(rec, result_fd, compact_sharded, args, "_n%d" % world)
     dist.barrier()
     dist.destroy_process_group()
 

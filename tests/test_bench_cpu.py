@@ -132,3 +132,72 @@ def test_roofline_record_follows_the_definition_and_keeps_measured_terms_beside_
     rec0 = bench.roofline_record(W, 1.3456, 0.021, {"error": "rocprofv3 not found"})
     assert rec0["traffic"] is None and rec0["frac_l2"] is None and rec0["frac_hbm_measured"] is None
     assert rec0["frac"] == rec["frac"] and rec0["traffic_error"] == "rocprofv3 not found"
+
+
+def _canned():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "bench_full_record.json")) as f:
+        return json.load(f)
+
+
+def test_the_line_is_short_strict_json_and_carries_the_contract(tmp_path):
+    """VERDICT r5 task 1: round 5's line was 34.7 KB and the driver (8 KB tail) could not parse it.  The line is built from
+    the full record (here: round 5's own, 34.7 KB) by `compact_single`; everything else goes to the detail file."""
+    import json
+    rec = _canned()
+    assert len(json.dumps(rec)) > 30000
+    rec["config"]["verification"]["max_err_over_abs_ref"] = float("nan")          # a NaN must not reach the line as a token
+    rec["roofline"]["floor_ms"] = float("inf")
+    line = bench.compact_single(rec, "gpurun_out/bench_detail.json")
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < bench.LINE_TARGET < bench.LINE_LIMIT == 8000
+    back = json.loads(text, parse_constant=lambda tok: pytest.fail("non-strict token " + tok))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "verified"):
+        assert key in back, key
+    assert back["vs_baseline"] is None and back["dtype"] == "f32" and back["config"]["workload"].startswith("reddit-like")
+    r = back["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    assert r["kernel"] == "sweep_kernel" and r["traffic"] > 0 and r["algorithmic_bytes"] == pytest.approx(29870822036, rel=1e-6)
+    assert back["cpu_baseline"]["value"] > 0 and back["cpu_baseline"]["cores"] == 16 and back["cpu_baseline"]["kind"] == "port"
+    assert abs(back["value"] - rec["value"]) / rec["value"] < 1e-6
+    assert not any(isinstance(v, (dict, list)) for v in back["config"].values())       # flat scalars only
+    assert all(not isinstance(v, (dict, list)) and (not isinstance(v, str) or len(v) <= 160) for v in r.values())
+    assert "other_workloads" not in r and r.get("floor_ms") is None
+
+
+def test_emit_writes_the_detail_file_and_one_line(tmp_path, capfd):
+    import json
+
+    class A:
+        detail_file = str(tmp_path / "d" / "detail.json")
+    rd, wr = os.pipe()
+    bench.emit(_canned(), wr, bench.compact_single, A)
+    os.close(wr)
+    out = os.read(rd, 1 << 16).decode()
+    os.close(rd)
+    assert out.endswith("\n") and out.count("\n") == 1 and len(out) < bench.LINE_TARGET
+    full = json.load(open(A.detail_file))
+    assert "other_workloads" in full["roofline"] and len(full["roofline"]["other_workloads"]) >= 9
+    assert "line" in capfd.readouterr().err
+
+
+def test_the_n_rank_line_is_short_too():
+    import json
+    legs = {n: {"value": 1e11, "unit": "edges/s", "ms_per_step": 9.5, "scaling": n, "verified": True, "exchange": "halo"}
+            for n in ("weak", "strong", "config5")}
+    rec = {"metric": "m", "value": 6.5e11, "unit": "edges/s", "n_gpus": 8, "steps": 20, "warmup": 5, "ms_per_step": 1.41,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "verified": True,
+           "config": {"workload": "reddit-like", "world_size": 8, "backend": "nccl", "communicator_ranks_counted": 8,
+                      "ranks": ["rank %d: AMD Instinct MI355X (cuda:%d)" % (i, i) for i in range(8)], "values": legs,
+                      "legs": {n: {"kernel": {"x": list(range(400))}} for n in legs}, "failed_legs": {},
+                      "exchange_only_ms_per_rank": [1.0] * 8, "parallelism": "dst-range shards x8 + halo " * 20,
+                      "tuning": {"a": 1}, "exchange": "halo"},
+           "roofline": {"bound": "hbm", "ceiling": "hbm", "peak": 8000.0, "unit": "GB/s", "achieved": 9000.0, "frac": 1.125,
+                        "kernel": "stream_kernel (x)", "kernel_ms": 1.2, "traffic": None,
+                        "per_leg_kernels": {n: {"x": list(range(300))} for n in legs}}}
+    line = bench.compact_sharded(rec, "gpurun_out/bench_detail_n8.json")
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) < bench.LINE_TARGET
+    assert line["config"]["values"]["config5"]["value"] == 1e11 and line["config"]["communicator_ranks_counted"] == 8
+    assert "legs" not in line["config"] and "per_leg_kernels" not in line["roofline"] and line["roofline"]["traffic"] is None
