@@ -46,7 +46,7 @@ EXPORTS = ("gnna_version", "gnna_build_id", "gnna_last_error", "gnna_count_parts
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_sddmm_ld_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
            "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
-           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld")
+           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld", "gnna_device_cus", "gnna_host_threads")
 
 
 def load() -> ctypes.CDLL:
@@ -62,6 +62,8 @@ def load() -> ctypes.CDLL:
     L.gnna_version.restype = ctypes.c_int
     L.gnna_build_id.restype = ctypes.c_char_p
     L.gnna_last_error.restype = ctypes.c_char_p
+    L.gnna_device_cus.restype = ctypes.c_int
+    L.gnna_host_threads.restype = ctypes.c_int
     L.gnna_count_parts.restype = ctypes.c_int64
     L.gnna_count_parts.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64]
     L.gnna_build_part_i32.restype = ctypes.c_int
@@ -171,6 +173,16 @@ def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_re
 
 def reset_tuning() -> None:
     _check(load().gnna_set_tuning(None))
+
+
+def device_cus() -> int:
+    """Compute units of the current device (0: no device visible)."""
+    return int(load().gnna_device_cus())
+
+
+def host_threads() -> int:
+    """Host threads the native builders and the renumbering use (affinity, cgroup quota, GNNA_HOST_THREADS)."""
+    return int(load().gnna_host_threads())
 
 
 def build_id() -> str:

@@ -10,6 +10,8 @@
 #include <cmath>
 #include <mutex>
 #include <numeric>
+#include <sched.h>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -110,32 +112,61 @@ int fail(int code, const char *fmt, ...)
     return code;
 }
 
+// quota of one cgroup v2 directory ("<quota|max> <period>" in cpu.max) in CPUs; 0 = no limit / unreadable
+static double cgroup2_quota(const std::string &dir)
+{
+    double quota = 0.0;
+    if (FILE *f = std::fopen((dir + "/cpu.max").c_str(), "r")) {
+        char q[64] = {0};
+        double period = 0.0;
+        if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) quota = std::atof(q) / period;
+        std::fclose(f);
+    }
+    return quota;
+}
+
+// CPUs this process may use: the smaller of the CPUs it is allowed to run on (sched_getaffinity: cpusets, taskset) and the
+// tightest CPU quota on the way from its own cgroup (/proc/self/cgroup) up to the root -- the root alone is what a process
+// inside a cgroup namespace sees, the nested path what one outside of it does.  A quota below one CPU means one thread.
+static int granted_cpus()
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = (int)(hw ? hw : 1u);
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+    double quota = 0.0;
+    auto tighten = [&](double q) { if (q > 0 && (quota == 0.0 || q < quota)) quota = q; };
+    std::string own;                                                           // cgroup v2 line: "0::/path"
+    if (FILE *f = std::fopen("/proc/self/cgroup", "r")) {
+        char line[1024];
+        while (std::fgets(line, sizeof(line), f))
+            if (std::strncmp(line, "0::", 3) == 0) { own = line + 3; while (!own.empty() && (own.back() == '\n' || own.back() == '/')) own.pop_back(); }
+        std::fclose(f);
+    }
+    tighten(cgroup2_quota("/sys/fs/cgroup"));
+    for (std::string path = own; !path.empty() && path[0] == '/'; path.erase(path.find_last_of('/')))
+        tighten(cgroup2_quota("/sys/fs/cgroup" + path));
+    if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        double q = 0.0, period = 0.0;
+        if (std::fscanf(fq, "%lf", &q) != 1) q = 0.0;
+        std::fclose(fq);
+        if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (std::fscanf(fp, "%lf", &period) != 1) period = 0.0;
+            std::fclose(fp);
+        }
+        if (q > 0 && period > 0) tighten(q / period);
+    }
+    if (quota > 0.0) n = std::min(n, std::max(1, (int)quota));
+    return std::max(1, n);
+}
+
 int host_thread_budget(int cap)
 {
-    static const int granted = [] {
-        unsigned hw = std::thread::hardware_concurrency();
-        int n = (int)(hw ? hw : 1u);
-        double quota = 0.0;
-        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {              // cgroup v2: "<quota|max> <period>"
-            char q[64] = {0};
-            double period = 0.0;
-            if (std::fscanf(f, "%63s %lf", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) quota = std::atof(q) / period;
-            std::fclose(f);
-        } else if (FILE *fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
-            double q = 0.0, period = 0.0;
-            if (std::fscanf(fq, "%lf", &q) != 1) q = 0.0;
-            std::fclose(fq);
-            if (FILE *fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-                if (std::fscanf(fp, "%lf", &period) != 1) period = 0.0;
-                std::fclose(fp);
-            }
-            if (q > 0 && period > 0) quota = q / period;
-        }
-        if (quota >= 1.0) n = std::min(n, (int)quota);
-        if (const char *e = std::getenv("GNNA_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n = v; }
-        return std::max(1, n);
-    }();
-    return std::max(1, std::min(granted, cap));
+    static const int granted = granted_cpus();
+    int n = granted;
+    if (const char *e = std::getenv("GNNA_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n = v; }   // read every time
+    return std::max(1, std::min(n, cap));
 }
 }  // namespace gnna
 
@@ -167,6 +198,8 @@ int gnna_version(void) { return GNNA_VERSION; }
 const char *gnna_build_id(void) { return "0.5.0+" GNNA_SOURCE_HASH; }
 
 const char *gnna_last_error(void) { return t_error; }
+
+int gnna_host_threads(void) { return gnna::host_thread_budget(64); }
 
 int gnna_set_tuning(const gnna_tuning *t)
 {

@@ -91,7 +91,8 @@ int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
     // a call that is being CAPTURED will run wherever and whenever its graph is replayed -- not in the order of the capture
     // stream (torch.cuda.graph captures every graph on one shared side stream and replays on the current one): such calls take
     // their block from the shared ring by sequence number, as do the calls of streams beyond the first kStreamBlocks
-    const int shared = kStreamBlocks + (int)((uint32_t)seq % (uint32_t)(kCallBlocks - kStreamBlocks));
+    // (seq is odd and unique per call, next_call_seq: its upper bits count the calls, so the ring uses every block)
+    const int shared = kStreamBlocks + (int)(((uint32_t)seq >> 1) % (uint32_t)(kCallBlocks - kStreamBlocks));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
     if (cap != hipStreamCaptureStatusNone) return shared;
@@ -109,7 +110,8 @@ int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
 int32_t next_call_seq(DeviceState *ds, hipStream_t stream, int32_t **flag_slot)
 {
     const uint32_t seq_u = g_seq.fetch_add(1) + 1;
-    const int32_t seq = (int32_t)(seq_u & 0x7fffffff) | 1;  // never 0
+    const int32_t seq = (int32_t)(((seq_u << 1) | 1u) & 0x7fffffffu);  // never 0, and different for consecutive calls: a flag raised
+                                                                       // by one call is never mistaken for the next one's on the same stream
     // the flags are compared with the call's own sequence number, so a slot can be shared by calls that follow each other on one
     // stream; calls on different streams use different slots (call_block_of), so none can overwrite the flag of another in flight
     *flag_slot = ds->flags + call_block_of(ds, stream, seq);
@@ -194,6 +196,16 @@ int gnna_profile_end(double *avg_main_ms, double *avg_prologue_ms, int *num_call
     if (avg_main_ms) *avg_main_ms = n ? main_ms / n : 0.0;
     if (avg_prologue_ms) *avg_prologue_ms = n ? pro_ms / n : 0.0;
     return rc_out;
+}
+
+int gnna_device_cus(void)
+{
+    int n = 0, dev = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return cus;
 }
 #pragma GCC visibility pop
 }  // extern "C"

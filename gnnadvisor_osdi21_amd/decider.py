@@ -18,9 +18,14 @@ Two policies:
   ``dimWorker``/``warpPerBlock`` keep their places in the API and are reported as the
   lane layout actually used (lanes per feature row, wavefronts per 256-thread block).
 
-Reference quirks preserved in both policies (SURVEY.md 8a "quirks"): in auto mode the
-reordered CSR is *not* copied back into this object (param.py:108-117), in manual mode it
-is (param.py:59-64); ``degrees`` is never refreshed after reordering.
+Renumbering (``enable_rabbit``).  The reference has two quirks (SURVEY.md 8a "quirks"): in auto mode the
+reordered CSR is *not* copied back into the profile (param.py:108-117: the renumbering is paid for and the
+kernels run on the ORIGINAL ids), in manual mode it is (param.py:59-64) but ``degrees`` is never refreshed
+(GNNA_main.py:70,75: GCN then weights the NEW rows with the OLD ids' degrees) and the node features / labels
+stay in the old order.  ``compat`` keeps both bug for bug.  ``mi355x`` fixes them: both modes adopt
+the renumbered CSR **and** the rebuilt ``degrees``, the dataset permutes ``x`` / ``y`` / masks with ``new_id``, and
+in auto mode the renumbering runs only when it pays for itself: predicted saving per aggregation x expected
+aggregations > predicted host seconds (``renumbering_gate``).
 """
 from __future__ import annotations
 
@@ -29,8 +34,21 @@ from dataclasses import dataclass
 from typing import Optional
 
 WAVE = 64                # CDNA4 wavefront
-NUM_CUS = 256            # MI355X
 WAVES_PER_BLOCK = 4      # 256-thread workgroups
+INFINITY_CACHE_BYTES = 256 << 20
+
+
+def num_cus() -> int:
+    """Compute units of the device libgnna runs on (256 on MI355X); 256 when no device is visible (CPU-side planning)."""
+    try:
+        from . import _lib
+        n = int(_lib.device_cus())
+        return n if n > 0 else 256
+    except Exception:
+        return 256
+
+
+NUM_CUS = 256            # MI355X (planning default; `num_cus()` asks the library)
 
 
 def _pow2_at_least(x: int) -> int:
@@ -137,6 +155,77 @@ def calibrate_phases(column_index, part_pointers, part2Node, num_out_rows, partS
     return chosen
 
 
+# ---------------------------------------------------------------------------------------------- renumbering gate
+# Gather-model rates (SURVEY 8d bytes / kernel time) the aggregation reaches, measured on MI355X (profiles/r5_bench.json,
+# profiles/r6/): ids scattered over a source matrix that fits the Infinity Cache 21.6-22.5 TB/s (Reddit-like, D = 64),
+# the same after renumbering 23.6 TB/s; scattered over an HBM-resident matrix 7.7 TB/s (products-like D = 64; config 5's
+# rank shape 6.6), after renumbering 17.0 TB/s.
+RATE_SCATTERED_CACHED, RATE_LOCAL_CACHED = 21.6e12, 23.6e12
+RATE_SCATTERED_HBM, RATE_LOCAL_HBM = 7.7e12, 17.0e12
+# Host seconds of gnna_reorder_community_i32 + the CSR rebuild, per raw edge and per node, at `threads` host threads
+# (fit of the round-6 measurements, profiles/r6/reorder_stages.log; the serial share does not shrink with threads)
+REORDER_S_PER_EDGE_SERIAL, REORDER_S_PER_EDGE_PARALLEL = 0.6e-8, 24e-8
+REORDER_S_PER_NODE = 1.0e-7
+REFERENCE_EPOCHS = 200 + 10          # GNNA_main.py:25 (--num_epoches) + the 10 dry runs (:188-189)
+
+
+def expected_aggregations(model, in_dim, hidden, classes, epochs=REFERENCE_EPOCHS):
+    """[(feature width, aggregations at that width)] of a whole training run of the reference's models (GNNA_main.py:143-171):
+    GCN aggregates X W, i.e. at each layer's OUTPUT width, forward and backward; GIN aggregates at each layer's input width
+    (forward; backward too unless it is the first layer) or, evaluated update-first (ops.GINConv), at the output width."""
+    units = lambda w: (int(w) + 63) // 64
+    out = []
+    if model == "gin":
+        dims = [in_dim] + [hidden] * 4 + [classes]
+        for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+            needs_dx = i > 0
+            if 2 * units(b) < (2 * units(a) if needs_dx else units(a)):
+                out.append((b, 2 * epochs))
+            else:
+                out.append((a, (2 if needs_dx else 1) * epochs))
+    else:
+        out = [(hidden, 2 * epochs), (classes, 2 * epochs)]
+    return out
+
+
+def predicted_aggregation_seconds(num_nodes, nnz, dim, scattered):
+    """Gather-model estimate of one aggregation at width `dim`: bytes / the measured rate of the regime."""
+    cached = num_nodes * dim * 4 < INFINITY_CACHE_BYTES
+    rate = (RATE_SCATTERED_CACHED if scattered else RATE_LOCAL_CACHED) if cached else \
+           (RATE_SCATTERED_HBM if scattered else RATE_LOCAL_HBM)
+    return nnz * (4.0 * dim + 4.0) / rate
+
+
+def predicted_reorder_seconds(num_nodes, num_edges, threads):
+    t = max(1, int(threads))
+    return num_edges * (REORDER_S_PER_EDGE_SERIAL + REORDER_S_PER_EDGE_PARALLEL / t) + num_nodes * REORDER_S_PER_NODE
+
+
+def renumbering_gate(num_nodes, num_edges, avg_edge_span, aggregations, threads=None):
+    """Does renumbering pay for itself?  -> dict(go, saving_per_epoch_set_s, aggregations, saving_s, reorder_s).
+    saving = sum over widths of count x (t_scattered - t_local) x how scattered the ids are (span / (N/3), capped at 1:
+    a random labelling has mean |src - dst| = N/3); go = saving_s > reorder_s.  The reference's own rule
+    (sqrt(span) > sqrt(N)/100, param.py:108) stays a precondition in the caller."""
+    if threads is None:
+        try:
+            from . import _lib
+            threads = _lib.host_threads()
+        except Exception:
+            import os
+            threads = os.cpu_count() or 1
+    scatter = min(1.0, max(0.0, float(avg_edge_span) / max(1.0, num_nodes / 3.0)))
+    total, count = 0.0, 0
+    for dim, k in aggregations:
+        gain = predicted_aggregation_seconds(num_nodes, num_edges, dim, True) - \
+               predicted_aggregation_seconds(num_nodes, num_edges, dim, False)
+        total += k * gain * scatter
+        count += int(k)
+    cost = predicted_reorder_seconds(num_nodes, num_edges, threads)
+    return {"go": bool(total > cost), "saving_s": total, "aggregations": count,
+            "saving_per_aggregation_s": total / count if count else 0.0, "reorder_s": cost,
+            "scatter": scatter, "threads": int(threads)}
+
+
 @dataclass
 class LaunchKnobs:
     """The (dimWorker, warpPerBlock) pair one layer kind is launched with (param.py:25-33)."""
@@ -144,9 +233,26 @@ class LaunchKnobs:
     warpPerBlock: Optional[int] = None
 
 
+def _adopt_renumbered(ip: "inputProperty") -> None:
+    """mi355x policy: the profile follows the dataset after rabbit_reorder() -- CSR, the REBUILT degrees, the statistics
+    the hints are derived from (the reference adopts the CSR in manual mode only and never the degrees)."""
+    ds = ip.dataset_obj
+    before = ip.avgEdgeSpan
+    ip.row_pointers, ip.column_index = ds.row_pointers, ds.column_index
+    if getattr(ds, "degrees", None) is not None:
+        ip.degrees = ds.degrees
+    after = getattr(ds, "avg_edgeSpan_after", None)
+    if after is not None:
+        ip.avgEdgeSpan_before, ip.avgEdgeSpan = before, float(after)
+        if ip.nonlocal_ids_hint is not None:
+            ip.nonlocal_ids_hint = 1 if ip.avgEdgeSpan > 0.28 * ip.num_nodes else 0
+        ip._say("# renumbered: avg edge span {:.0f} -> {:.0f}".format(before, after))
+
+
 class _Manual:
     """manual_mode=True (param.py:58-70): the caller's knobs stay; the only decision is whether the graph
-    is renumbered, and in this mode the renumbered CSR IS adopted by the profile."""
+    is renumbered, and in this mode the renumbered CSR IS adopted by the profile (compat: CSR only, stale degrees kept;
+    mi355x: CSR + rebuilt degrees, node data permuted by the dataset)."""
 
     @staticmethod
     def run(ip: "inputProperty") -> None:
@@ -154,22 +260,45 @@ class _Manual:
         ds.reorder_flag = bool(ip.enable_rabbit)
         ip.reorder_status = bool(ip.enable_rabbit)
         if ip.enable_rabbit:
-            ds.rabbit_reorder()
-            ip.row_pointers, ip.column_index = ds.row_pointers, ds.column_index
+            if ip.policy == "mi355x":
+                ds.permute_node_data = True
+                ds.rabbit_reorder()
+                _adopt_renumbered(ip)
+            else:
+                ds.rabbit_reorder()
+                ip.row_pointers, ip.column_index = ds.row_pointers, ds.column_index
         ip._say("\n=> MANUAL Config Complete !!!\n")
 
 
 class _Auto:
-    """manual_mode=False (param.py:72-120): knobs from the policy, then the reorder rule.  Quirk kept on
-    purpose: the renumbered CSR is NOT copied back into the profile here (param.py:108-117)."""
+    """manual_mode=False (param.py:72-120): knobs from the policy, then the reorder rule.  compat keeps the reference's
+    quirk -- the renumbered CSR is NOT copied back into the profile (param.py:108-117).  mi355x: the reference's rule is
+    the precondition, the cost gate decides, and a renumbered graph is adopted."""
 
     @staticmethod
     def run(ip: "inputProperty") -> None:
         (ip._decide_compat if ip.policy == "compat" else ip._decide_mi355x)()
         if ip.enable_rabbit:
+            ds = ip.dataset_obj
             wants = math.sqrt(ip.avgEdgeSpan) > math.sqrt(ip.num_nodes) / 100     # param.py:108
-            ip.dataset_obj.reorder_flag = ip.reorder_status = bool(wants)
-            ip.dataset_obj.rabbit_reorder()
+            if ip.policy == "mi355x":
+                if wants:
+                    aggs = ip.expected_aggregations or expected_aggregations("gcn", ip.inputDim, ip.hiddenDim, ip.hiddenDim)
+                    edges = getattr(ds, "num_edges", None) or int(ip.avgNodeDegree * ip.num_nodes)
+                    gate = ip.renumbering_decision = renumbering_gate(ip.num_nodes, edges, ip.avgEdgeSpan, aggs)
+                    wants = gate["go"] or ip.force_renumbering
+                    ip._say("# renumbering gate: predicted saving {:.3f} ms/aggregation x {} aggregations = {:.2f} s vs {:.2f} s "
+                            "of renumbering on {} host threads -> {}".format(
+                                gate["saving_per_aggregation_s"] * 1e3, gate["aggregations"], gate["saving_s"], gate["reorder_s"],
+                                gate["threads"], "renumber" if wants else "keep the ids"))
+                ds.reorder_flag = ip.reorder_status = bool(wants)
+                ds.permute_node_data = True
+                ds.rabbit_reorder()
+                if wants:
+                    _adopt_renumbered(ip)
+            else:
+                ds.reorder_flag = ip.reorder_status = bool(wants)
+                ds.rabbit_reorder()
         ip._say("\n=> AUTO Decider Complete !!!\n")
 
 
@@ -211,6 +340,9 @@ class inputProperty(object):
         # switches
         self.manual_mode, self.enable_rabbit, self.verbose_flag = manual_mode, enable_rabbit, verbose
         self.reorder_status = False
+        # mi355x renumbering gate: [(width, count)] of the run ahead (the driver fills it in; None = the reference's
+        # protocol, 2-layer GCN x 210 epochs), the gate's record, and an override for callers who know better
+        self.expected_aggregations, self.renumbering_decision, self.force_renumbering = None, None, False
         # constants of the reference's shared-memory model (compat policy only)
         self.MAX_warpPerBlock, self.gap_smem = 8, 100
         self.share_memory = 0.4 * (sharedMem if sharedMem is not None else 0)
@@ -288,7 +420,7 @@ class inputProperty(object):
         # items per wavefront slot for balance, and ~16-32 groups so that most rows are
         # wholly owned by one wavefront (plain stores instead of atomics)
         est_parts = self.num_nodes * max(1.0, self.avgNodeDegree / self.partSize)
-        slots = NUM_CUS * 32
+        slots = num_cus() * 32
         g = 32 if self.avgNodeDegree >= 128 else 16
         while g > 1 and est_parts / g < slots * 8:
             g //= 2
@@ -320,10 +452,11 @@ class inputProperty(object):
             return
         from . import _lib
         nonlocal_ids = self.nonlocal_ids_hint
-        if nonlocal_ids is not None and self.reorder_status and \
+        if nonlocal_ids is not None and self.policy == "compat" and self.reorder_status and \
                 self.row_pointers is getattr(self.dataset_obj, "row_pointers", None):
-            # the CSR these kernels will run on IS the renumbered one (manual mode adopts it; auto mode keeps the
-            # original, reference quirk param.py:108-117 -- there the ids are as scattered as they were)
+            # compat, manual mode: the CSR these kernels will run on IS the renumbered one (auto mode keeps the original,
+            # reference quirk param.py:108-117 -- there the ids are as scattered as they were); mi355x refreshed the hint
+            # from the renumbered graph's own span when it adopted it
             nonlocal_ids = 0
         _lib.set_tuning(groups_per_chunk=self.groups_per_chunk or -1,
                         loads_in_flight=self.loads_in_flight or -1)

@@ -40,6 +40,11 @@ class custom_dataset(torch.nn.Module):
         self.edge_index = None
         self.reorder_flag = False
         self.reorder_method = "community"                      # or "rcm" (reverse Cuthill-McKee)
+        # True: rabbit_reorder() also moves the per-node data (x, y, the masks) to the new ids, so that row i of x is
+        # still node i's embedding.  The reference leaves them where they were (dataset.py:138-172 relabels the edge
+        # list only), which goes unnoticed there because x is random and y constant; the mi355x Decider sets this.
+        self.permute_node_data = False
+        self.new_id = None
         self.verbose_flag = verbose
         self.avg_degree = -1
         self.avg_edgeSpan = -1
@@ -139,6 +144,15 @@ class custom_dataset(torch.nn.Module):
             print("# Reorder time (s): {}".format(time.perf_counter() - start))
         self.avg_edgeSpan_after = _lib.edge_span(self.edge_index[0], self.edge_index[1])
         self._build_csr("# Re-Build CSR (s): {:.3f}")
+        if self.permute_node_data:
+            where = torch.from_numpy(new_id).to(self.device)   # new position of old row i
+            for name in ("x", "y", "train_mask", "val_mask", "test_mask"):
+                old = getattr(self, name, None)
+                if old is not None and old.shape[0] == self.num_nodes:
+                    moved = torch.empty_like(old)
+                    moved[where] = old
+                    setattr(self, name, moved)
+        self.reorder_seconds = time.perf_counter() - start
 
 
 # ---------------------------------------------------------------------------------------------- sharded ingestion

@@ -48,6 +48,9 @@ def build_parser():
                    help="True: let PyTorch's TunableOp time the rocBLAS / hipBLASLt solutions for the layer GEMMs at "
                         "first use (X W and G W^T run 1.3-2x faster; costs 1-2 minutes of set-up, MI355X addition)")
     p.add_argument('--policy', type=str, default='mi355x', choices=['mi355x', 'compat'], help="Decider policy")
+    p.add_argument('--force_rabbit', default='False', **tf,
+                   help="True: with --enable_rabbit True in auto mode, renumber even when the mi355x cost gate says the run is "
+                        "too short to win the host seconds back (MI355X addition)")
     return p
 
 
@@ -93,6 +96,11 @@ def main(argv=None):
                               partSize, dimWorker, warpPerBlock, sharedMem,
                               hiddenDim=args.hidden, dataset_obj=dataset, enable_rabbit=enable_rabbit,
                               manual_mode=manual_mode, verbose=verbose_mode, policy=args.policy)
+    # what the run ahead will aggregate (the mi355x renumbering gate weighs the host seconds of a renumbering against it)
+    from .decider import expected_aggregations
+    inputInfo.expected_aggregations = [(args.hidden, args.num_epoches)] if (single_spmm or verify_spmm) else \
+        expected_aggregations(args.model, dataset.num_features, args.hidden, dataset.num_classes, args.num_epoches + 10)
+    inputInfo.force_renumbering = flag(args.force_rabbit)
     inputInfo.decider()
     inputInfo = inputInfo.set_input()
     if verbose_mode:

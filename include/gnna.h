@@ -69,6 +69,13 @@ GNNA_API int gnna_version(void);
 GNNA_API const char *gnna_build_id(void);
 GNNA_API const char *gnna_last_error(void);
 
+/* What the planners size their work for (param.py:4-164 reads the SM count and shared memory of "a GPU" from constants;
+ * here the Decider asks): compute units of the calling thread's current device (256 on MI355X; 0 when no device is visible --
+ * never an error) and the host threads the native builders / the renumbering may use (the CPUs this process is allowed:
+ * affinity mask, cgroup quota on the way up from its own cgroup, GNNA_HOST_THREADS overrides; at most 64). */
+GNNA_API int gnna_device_cus(void);
+GNNA_API int gnna_host_threads(void);
+
 /* ---- partitioner (host) --------------------------------------------------------------
  * Neighbor-group partition of a CSR: row i with degree d_i yields ceil(d_i / partSize)
  * groups of at most partSize consecutive neighbors; group p covers edge offsets
