@@ -65,6 +65,28 @@ import time
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); before HIP starts
 os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: pinned OpenMP threads (before libgomp starts)
 os.environ.setdefault("OMP_PLACES", "cores")
+# With OMP_PROC_BIND set, libgomp binds the INITIAL thread to the first place (one core) as soon as it starts -- and every
+# std::thread the native host code spawns from it inherits that one-core mask: round 5's "24.3 s" renumbering inside this script
+# was 16 threads on one core (4.6 s with the mask restored).  The mask the process started with is kept here; `unbound()` puts it
+# back on the main thread around native multi-threaded host work, `cpu_baseline` runs under the binding it asked for.
+_START_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+
+
+class unbound:
+    """Context: the main thread may run (and spawn threads) on every CPU the process started with."""
+
+    def __enter__(self):
+        self.saved = None
+        if _START_AFFINITY is not None:
+            self.saved = os.sched_getaffinity(0)
+            if self.saved != _START_AFFINITY:
+                os.sched_setaffinity(0, _START_AFFINITY)
+        return self
+
+    def __exit__(self, *exc):
+        if self.saved is not None and self.saved != _START_AFFINITY:
+            os.sched_setaffinity(0, self.saved)
+        return False
 
 
 def cpu_quota_cores():
@@ -228,9 +250,16 @@ class Workload:
                 if perm_file and os.path.exists(perm_file):
                     new_id = torch.load(perm_file).to(dev).long()          # (a PMC child re-uses the parent's renumbering)
                 else:
-                    t0 = time.perf_counter()
-                    new_id = _lib.reorder_community(src.cpu(), dst.cpu(), n).to(dev).long()
-                    self.reorder_seconds = time.perf_counter() - t0
+                    # what loader.custom_dataset.rabbit_reorder() does: the renumbering from the host CSR of the graph as loaded
+                    scr = graph.graph_from_edges(src, dst, n)
+                    rp_h, ci_h = scr.row_pointers.cpu(), scr.column_index.cpu()
+                    del scr
+                    with unbound():
+                        t0 = time.perf_counter()
+                        new_id = _lib.reorder_community_csr(rp_h, ci_h, n)
+                        self.reorder_seconds = time.perf_counter() - t0
+                    new_id = new_id.to(dev).long()
+                    del rp_h, ci_h
                     if perm_file:
                         torch.save(new_id.to(torch.int32).cpu(), perm_file)
                 src, dst = new_id[src], new_id[dst]

@@ -22,7 +22,7 @@ import importlib
 import os
 import sys
 
-__version__ = "0.1.0"
+__version__ = "0.6.0"          # = the library's (include/gnna.h GNNA_VERSION 600, gnna_build_id)
 _PKG = os.path.dirname(os.path.abspath(__file__))
 
 

@@ -29,7 +29,7 @@ class Tuning(ctypes.Structure):
                 ("avg_degree", ctypes.c_int), ("nonlocal_ids", ctypes.c_int), ("gcn_prescale", ctypes.c_int),
                 ("pad_rows", ctypes.c_int), ("zero_fill", ctypes.c_int),
                 ("sweep", ctypes.c_int), ("sweep_slack", ctypes.c_int), ("deterministic", ctypes.c_int),
-                ("pack_ids", ctypes.c_int), ("wide_blocks", ctypes.c_int)]
+                ("pack_ids", ctypes.c_int), ("ids_check_every", ctypes.c_int), ("wide_blocks", ctypes.c_int)]
 
 
 _lib = None
@@ -46,7 +46,8 @@ EXPORTS = ("gnna_version", "gnna_build_id", "gnna_last_error", "gnna_count_parts
            "gnna_last_num_phases", "gnna_sddmm_f32", "gnna_sddmm_ld_f32", "gnna_agg_rect_windows_f32", "gnna_set_graph_hints", "gnna_xtg_f32", "gnna_set_graph_phases",
            "gnna_last_num_launches", "gnna_reorder_community_i32", "gnna_prepare_graph", "gnna_release_graph",
            "gnna_runtime_counters", "gnna_row_counts_i64", "gnna_row_splits_i64", "gnna_csr_from_edges_range_i32",
-           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld", "gnna_device_cus", "gnna_host_threads")
+           "gnna_forget_graph", "gnna_agg_ld_f32", "gnna_preferred_ld", "gnna_device_cus", "gnna_host_threads",
+           "gnna_reorder_community_csr_i32", "gnna_relabel_edges_i32", "gnna_relabel_csr_i32", "gnna_runtime_counters_ex", "gnna_forget_plans")
 
 
 def load() -> ctypes.CDLL:
@@ -121,6 +122,13 @@ def load() -> ctypes.CDLL:
                                        ctypes.c_void_p]
     L.gnna_reorder_community_i32.restype = ctypes.c_int
     L.gnna_reorder_community_i32.argtypes = L.gnna_reorder_rcm_i32.argtypes
+    L.gnna_reorder_community_csr_i32.restype = ctypes.c_int
+    L.gnna_reorder_community_csr_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+    L.gnna_relabel_edges_i32.restype = ctypes.c_int
+    L.gnna_relabel_edges_i32.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                         ctypes.POINTER(ctypes.c_double)]
+    L.gnna_relabel_csr_i32.restype = ctypes.c_int
+    L.gnna_relabel_csr_i32.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int64] + [ctypes.c_void_p] * 3
     L.gnna_last_num_phases.restype = ctypes.c_int
     L.gnna_last_num_launches.restype = ctypes.c_int
     L.gnna_sddmm_ld_f32.restype = ctypes.c_int
@@ -137,8 +145,12 @@ def load() -> ctypes.CDLL:
     L.gnna_release_graph.argtypes = [ctypes.c_void_p]
     L.gnna_forget_graph.restype = ctypes.c_int
     L.gnna_forget_graph.argtypes = [ctypes.c_void_p]
+    L.gnna_forget_plans.restype = ctypes.c_int
+    L.gnna_forget_plans.argtypes = [ctypes.c_void_p]
     L.gnna_runtime_counters.restype = None
     L.gnna_runtime_counters.argtypes = [ctypes.POINTER(ctypes.c_int64)]
+    L.gnna_runtime_counters_ex.restype = ctypes.c_int
+    L.gnna_runtime_counters_ex.argtypes = [ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     L.gnna_profile_begin.restype = ctypes.c_int
     L.gnna_profile_begin.argtypes = [ctypes.c_int]
     L.gnna_profile_end.restype = ctypes.c_int
@@ -164,10 +176,12 @@ def _stream(device: torch.device) -> int:
 def set_tuning(groups_per_chunk=-1, loads_in_flight=-1, blocks_per_cu=-1, xcd_remap=-1,
                trust_canonical=-1, column_phases=-1, avg_degree=-1, nonlocal_ids=-1, gcn_prescale=-1,
                pad_rows=-1, zero_fill=-1, sweep=-1, sweep_slack=-1, deterministic=-1, pack_ids=-1,
-               wide_blocks=-1) -> None:
+               wide_blocks=-1, ids_check_every=-1) -> None:
+    """Fields < 0 (<= 0 where 0 has no meaning) keep the built-in choice; ids_check_every: 1 = a full hash of the ids
+    behind a packed copy on every call, n = every n-th (built-in 64), >= 2**30 = never (include/gnna.h)."""
     t = Tuning(ctypes.sizeof(Tuning), groups_per_chunk, loads_in_flight, blocks_per_cu, xcd_remap, trust_canonical, column_phases,
                avg_degree, nonlocal_ids, gcn_prescale, pad_rows, zero_fill, sweep, sweep_slack, deterministic,
-               pack_ids, wide_blocks)
+               pack_ids, ids_check_every, wide_blocks)
     _check(load().gnna_set_tuning(ctypes.byref(t)))
 
 
@@ -186,7 +200,7 @@ def host_threads() -> int:
 
 
 def build_id() -> str:
-    """"0.5.0+<source hash>" of the loaded libgnna.so (gnna_build_id)."""
+    """"0.6.0+<source hash>" of the loaded libgnna.so (gnna_build_id)."""
     return load().gnna_build_id().decode()
 
 
@@ -317,6 +331,34 @@ def reorder_community(src, dst, num_nodes: int) -> torch.Tensor:
     out = torch.empty(int(num_nodes), dtype=torch.int32)
     _check(load().gnna_reorder_community_i32(s.data_ptr(), d.data_ptr(), s.numel(), int(num_nodes), out.data_ptr()))
     return out
+
+
+def reorder_community_csr(row_pointers, column_index, num_nodes: int) -> torch.Tensor:
+    """new_id[old_id] of the community renumbering from a host CSR with sorted, duplicate-free rows (the loader's): a symmetric
+    CSR is the algorithm's adjacency as it stands (no second counting sort); same permutation as `reorder_community`."""
+    rp, ci = _host_i32(row_pointers), _host_i32(column_index)
+    assert rp.numel() == int(num_nodes) + 1
+    out = torch.empty(int(num_nodes), dtype=torch.int32)
+    _check(load().gnna_reorder_community_csr_i32(rp.data_ptr(), ci.data_ptr(), int(num_nodes), out.data_ptr()))
+    return out
+
+
+def relabel_edges_(src: torch.Tensor, dst: torch.Tensor, new_id: torch.Tensor, num_nodes: int) -> float:
+    """src, dst (int32 host tensors, contiguous) <- new_id[...] IN PLACE; returns the new mean |src - dst|."""
+    for t in (src, dst, new_id):
+        assert t.dtype == torch.int32 and t.is_contiguous() and not t.is_cuda
+    v = ctypes.c_double()
+    _check(load().gnna_relabel_edges_i32(src.data_ptr(), dst.data_ptr(), src.numel(), new_id.data_ptr(), int(num_nodes), ctypes.byref(v)))
+    return v.value
+
+
+def relabel_csr(row_pointers, column_index, new_id, num_nodes: int):
+    """The relabelled graph's CSR (rows sorted) from the old CSR and new_id[old] -- no global sort."""
+    rp, ci, nid = _host_i32(row_pointers), _host_i32(column_index), _host_i32(new_id)
+    out_rp = torch.empty(int(num_nodes) + 1, dtype=torch.int32)
+    out_ci = torch.empty(max(1, ci.numel()), dtype=torch.int32)
+    _check(load().gnna_relabel_csr_i32(rp.data_ptr(), ci.data_ptr(), int(num_nodes), nid.data_ptr(), out_rp.data_ptr(), out_ci.data_ptr()))
+    return out_rp, out_ci[:ci.numel()]
 
 
 def last_num_phases() -> int:
@@ -517,11 +559,11 @@ def release_graph(column_index) -> None:
 
 
 def runtime_counters() -> dict:
-    out = (ctypes.c_int64 * 8)()
-    load().gnna_runtime_counters(out)
+    out = (ctypes.c_int64 * 16)()
+    n = load().gnna_runtime_counters_ex(out, 16)
     names = ("plan_builds", "launch_syncs", "launch_frees", "launch_mallocs", "backoff_skips", "sweep_launches",
-             "pack_builds", "packed_launches")
-    return {n: int(out[i]) for i, n in enumerate(names)}
+             "pack_builds", "packed_launches", "full_hashes")
+    return {name: int(out[i]) for i, name in enumerate(names) if i < n}
 
 
 def set_graph_phases(column_index, dim: int, column_phases: int) -> None:

@@ -46,9 +46,9 @@ prologue_kernel(float *__restrict__ Y, size_t n_floats, int D, int ldy, const in
     const unsigned fill_blocks = chk_ids ? gridDim.x - 1 : gridDim.x;
     if (blockIdx.x >= fill_blocks) {
         if (threadIdx.x < kWave) {
-            const unsigned long long then = *chk_sum;
+            const unsigned long long then = chk_sum[0], distrusted = chk_sum[4];   // [4]: a full hash differed earlier (gnna_stream.hip)
             const unsigned long long now = graph_checksum(chk_ids, chk_n, pp, P, (int)threadIdx.x);
-            if (threadIdx.x == 0 && now != then) *stale_flag = seq;
+            if (threadIdx.x == 0 && (now != then || distrusted != 0ull)) *stale_flag = seq;
         }
         return;
     }
@@ -710,7 +710,8 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
         }
         const int32_t *sw_ids = nullptr; const uint32_t *sw_off = nullptr;
         if (plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned)) && tune.xcd_remap != 0) {
-            rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &sw_ids, &sw_off, &chk_sum, &chk_n);
+            rc = get_packed_ids(ds, stream, plan.handle, Bs, kWave, true, false, &sw_ids, &sw_off, &chk_sum, &chk_n, stale_flag, seq,
+                                tune.ids_check_every);
             if (rc != GNNA_OK) return rc;
             if (sw_ids) count_event(CTR_PACKED_LAUNCHES);
         }
@@ -771,7 +772,7 @@ int launch_agg(int mode, const float *input, int64_t ld_in, int64_t num_in_rows,
     // widths it was given; a width or phase count it has not seen gets its copy at first use, outside captures)
     if (cnt && !windowed && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned))) {
         rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
-                            &chk_sum, &chk_n);
+                            &chk_sum, &chk_n, stale_flag, seq, tune.ids_check_every);
         a.packed_stale = stale_flag;
         if (rc != GNNA_OK) return rc;
         if (a.ids_packed) count_event(CTR_PACKED_LAUNCHES);
@@ -983,6 +984,13 @@ int gnna_forget_graph(const int32_t *column_index)
     if (!column_index) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_forget_graph: null (gnna_release_graph(NULL) drops everything)");
     (void)release_slice_plans(column_index, true);
     return gnna_set_graph_hints(column_index, 0, 0);
+}
+
+int gnna_forget_plans(const int32_t *column_index)
+{
+    if (!column_index) return fail(GNNA_ERR_INVALID_ARGUMENT, "gnna_forget_plans: null column_index");
+    (void)release_slice_plans(column_index, true);
+    return GNNA_OK;
 }
 
 int gnna_last_num_phases(void) { return t_last_phases; }

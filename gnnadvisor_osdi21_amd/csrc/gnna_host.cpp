@@ -30,7 +30,7 @@ const gnna_tuning kDefaultTuning = {/*struct_size=*/(int)sizeof(gnna_tuning), /*
                                     /*column_phases=*/0, /*avg_degree=*/0, /*nonlocal_ids=*/0,
                                     /*gcn_prescale=*/0, /*pad_rows=*/0, /*zero_fill=*/0,
                                     /*sweep=*/0, /*sweep_slack=*/0, /*deterministic=*/0, /*pack_ids=*/0,
-                                    /*wide_blocks=*/0};
+                                    /*ids_check_every=*/64, /*wide_blocks=*/0};
 gnna_tuning g_tuning = kDefaultTuning;
 std::mutex g_tuning_mutex;
 std::once_flag g_env_once;
@@ -51,6 +51,8 @@ uint64_t g_hint_clock = 0;
 
 void apply_env()
 {
+    if (const char *c = std::getenv("GNNA_DEBUG_FULL_CHECKSUM"))
+        if (std::atoi(c) != 0) g_tuning.ids_check_every = 1;
     const char *s = std::getenv("GNNA_TUNE");
     if (!s) return;
     char buf[256];
@@ -73,6 +75,7 @@ void apply_env()
         else if (!std::strcmp(tok, "PAD")) g_tuning.pad_rows = v;
         else if (!std::strcmp(tok, "ZERO")) g_tuning.zero_fill = v;
         else if (!std::strcmp(tok, "SWEEP")) g_tuning.sweep = v;
+        else if (!std::strcmp(tok, "CHECK")) g_tuning.ids_check_every = v;
         else if (!std::strcmp(tok, "SLACK")) g_tuning.sweep_slack = v;
         else if (!std::strcmp(tok, "DET")) g_tuning.deterministic = v;
         else if (!std::strcmp(tok, "PACK")) g_tuning.pack_ids = v;
@@ -195,7 +198,7 @@ int gnna_version(void) { return GNNA_VERSION; }
 #ifndef GNNA_SOURCE_HASH
 #define GNNA_SOURCE_HASH "unhashed"        /* (built by hand, not by gnnadvisor_osdi21_amd/build.py) */
 #endif
-const char *gnna_build_id(void) { return "0.5.0+" GNNA_SOURCE_HASH; }
+const char *gnna_build_id(void) { return "0.6.0+" GNNA_SOURCE_HASH; }
 
 const char *gnna_last_error(void) { return t_error; }
 
@@ -224,6 +227,7 @@ int gnna_set_tuning(const gnna_tuning *t)
     if (t->sweep_slack >= 0) g_tuning.sweep_slack = t->sweep_slack;
     if (t->deterministic >= 0) g_tuning.deterministic = t->deterministic;
     if (t->pack_ids >= 0) g_tuning.pack_ids = t->pack_ids;
+    if (t->ids_check_every > 0) g_tuning.ids_check_every = t->ids_check_every;
     if (t->wide_blocks >= 0) g_tuning.wide_blocks = t->wide_blocks;
     return GNNA_OK;
 }

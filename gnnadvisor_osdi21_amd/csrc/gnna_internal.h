@@ -103,7 +103,7 @@ void drop_slice_plans();
 // caller decides whether the plan may have them (pinned, or gnna_tuning.pack_ids = 1).
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
                    const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum = nullptr,
-                   int64_t *num_ids = nullptr);
+                   int64_t *num_ids = nullptr, int32_t *stale_flag = nullptr, int32_t seq = 0, int check_every = 0);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
 // deferred: the device buffers are not freed now (no synchronisation: safe from a finalizer on any thread, during a
 // stream capture) but at the next gnna_prepare_graph / gnna_release_graph / plan allocation with no launch in flight.
@@ -124,7 +124,7 @@ int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slic
                   bool square, bool hinted_scattered);
 // Events on the launch path that the contract promises not to happen after gnna_prepare_graph (gnna_runtime_counters).
 enum { CTR_PLAN_BUILDS = 0, CTR_LAUNCH_SYNCS = 1, CTR_LAUNCH_FREES = 2, CTR_LAUNCH_MALLOCS = 3, CTR_BACKOFF_SKIPS = 4,
-       CTR_SWEEP_LAUNCHES = 5, CTR_PACK_BUILDS = 6, CTR_PACKED_LAUNCHES = 7, CTR_COUNT = 8 };
+       CTR_SWEEP_LAUNCHES = 5, CTR_PACK_BUILDS = 6, CTR_PACKED_LAUNCHES = 7, CTR_FULL_HASHES = 8, CTR_COUNT = 9 };
 void count_event(int which);
 
 struct StreamLaunch {

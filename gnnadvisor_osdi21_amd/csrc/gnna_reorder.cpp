@@ -68,87 +68,32 @@ void parallel_tasks(int64_t count, int threads, F &&fn)
 
 int host_threads() { return gnna::host_thread_budget(64); }      // (the CPUs the container is granted, not the ones it sees)
 
-}  // namespace
+// A symmetric, duplicate-free adjacency with sorted rows, wherever it lives (built here from an edge list, or the caller's CSR)
+struct IdList {
+    const int32_t *p = nullptr;
+    size_t len = 0;
+    size_t size() const { return len; }
+    const int32_t *data() const { return p; }
+    int32_t operator[](size_t i) const { return p[i]; }
+};
 
-extern "C" {
-#pragma GCC visibility push(default)
-
-int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t num_edges, int64_t num_nodes,
-                               int32_t *new_id)
-{
-    using gnna::fail;
-    if (num_edges < 0 || num_nodes < 0 || (num_nodes > 0 && !new_id) || (num_edges > 0 && (!src || !dst)))
-        return fail(GNNA_ERR_INVALID_ARGUMENT, "bad reorder arguments");
-    if (num_nodes > 0x7fffffffLL)
-        return fail(GNNA_ERR_UNSUPPORTED, "graph too large for int32 node ids");
-    const int64_t n = num_nodes;
-    if (n == 0) return GNNA_OK;
-    const int threads = host_threads();
-    const bool debug = std::getenv("GNNA_REORDER_DEBUG") != nullptr;
-    auto t_start = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!debug) return;
-        auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[reorder] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t_start).count());
-        t_start = now;
-    };
-
-    // symmetrised, duplicate-free adjacency (reorder.cpp:31-97 does the same before aggregating).  64-bit row offsets:
-    // the list may hold more than 2^31 entries once both directions are in (papers100M symmetrised: 3.2e9); built in
-    // parallel over slabs of the edge list (atomic degree counts and cursors), then sorted and de-duplicated per row.
-    std::vector<int64_t> rp((size_t)n + 1, 0);
-    std::vector<int32_t> ci;
+struct Lap {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit Lap(bool debug) : on(debug), t(std::chrono::steady_clock::now()) {}
+    void operator()(const char *what)
     {
-        for (int64_t e = 0; e < num_edges; e++)
-            if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n)
-                return fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)e, src[e], dst[e], (long long)n);
-        std::vector<int64_t> cursor((size_t)n + 1, 0);
-        auto over_edges = [&](auto &&fn) {
-            const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(threads, num_edges / (1 << 20) + 1));
-            std::vector<std::thread> th;
-            const int64_t step = (num_edges + nt - 1) / nt;
-            for (int64_t t = 0; t < nt; t++) {
-                const int64_t lo = t * step, hi = std::min(num_edges, lo + step);
-                if (lo >= hi) break;
-                th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
-            }
-            for (auto &t : th) t.join();
-        };
-        over_edges([&](int64_t lo, int64_t hi) {
-            for (int64_t e = lo; e < hi; e++) {
-                __atomic_fetch_add(&cursor[(size_t)src[e] + 1], 1, __ATOMIC_RELAXED);
-                __atomic_fetch_add(&cursor[(size_t)dst[e] + 1], 1, __ATOMIC_RELAXED);
-            }
-        });
-        lap("  adjacency: counted");
-        for (int64_t v = 0; v < n; v++) cursor[(size_t)v + 1] += cursor[(size_t)v];
-        std::vector<int64_t> start(cursor.begin(), cursor.end());
-        std::vector<int32_t> bucket((size_t)(2 * num_edges));
-        over_edges([&](int64_t lo, int64_t hi) {
-            for (int64_t e = lo; e < hi; e++) {
-                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)src[e]], 1, __ATOMIC_RELAXED)] = dst[e];
-                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)dst[e]], 1, __ATOMIC_RELAXED)] = src[e];
-            }
-        });
-        lap("  adjacency: scattered");
-        std::vector<int32_t> uniq((size_t)n, 0);
-        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
-            for (int64_t v = lo; v < hi; v++) {
-                int32_t *b = bucket.data() + start[(size_t)v], *e = bucket.data() + start[(size_t)v + 1];
-                std::sort(b, e);                                   // (the scatter order depends on the threads, the sorted row does not)
-                uniq[(size_t)v] = (int32_t)(std::unique(b, e) - b);
-            }
-        });
-        lap("  adjacency: rows sorted");
-        for (int64_t v = 0; v < n; v++) rp[(size_t)v + 1] = rp[(size_t)v] + uniq[(size_t)v];
-        ci.resize((size_t)rp[(size_t)n]);
-        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
-            for (int64_t v = lo; v < hi; v++)
-                std::copy_n(bucket.data() + start[(size_t)v], uniq[(size_t)v], ci.data() + rp[(size_t)v]);
-        });
+        if (!on) return;
+        auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[reorder] %-28s %.2f s\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
     }
+};
 
-    lap("symmetrised adjacency");
+// Steps 1-3 of the header comment on the adjacency (rp, ci) of n nodes -> new_id[old id].
+int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdList ci, int32_t *new_id, const int threads,
+                    const bool debug, Lap &lap)
+{
     // ---- 1. backbone: edges with >= T common neighbours ------------------------------------------------------
     const double avg_deg = (double)ci.size() / (double)n;
     const int T = std::getenv("GNNA_REORDER_SUPPORT") ? std::atoi(std::getenv("GNNA_REORDER_SUPPORT"))
@@ -180,6 +125,14 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                 if (ue - ub > hub) continue;
                 for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] |= 1ull << (ci[(size_t)k] & 63);
                 for (int64_t k = ub; k < ue; k++) {
+                    // the lists scanned below start anywhere in a 0.4 GB array: ask for the row pointer of the neighbour eight
+                    // ahead and the first lines of the list of the neighbour four ahead while this one is scanned (round 6: the
+                    // scan was waiting for memory, not probing -- 2.1 s -> see profiles/r6/reorder_stages.log)
+                    if (k + 8 < ue) __builtin_prefetch(&rp[(size_t)ci[(size_t)(k + 8)]]);
+                    if (k + 4 < ue) {
+                        const int32_t *nl = ci.data() + rp[(size_t)ci[(size_t)(k + 4)]];
+                        __builtin_prefetch(nl); __builtin_prefetch(nl + 16); __builtin_prefetch(nl + 32); __builtin_prefetch(nl + 48);
+                    }
                     const int32_t v = ci[(size_t)k];
                     const int64_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
                     if (ve - vb > ue - ub || (ve - vb == ue - ub && v >= u)) continue;     // (the pair is v's to count)
@@ -205,7 +158,7 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
                         keep[(size_t)k] = 1;
                         const int32_t *vl = ci.data() + vb, *vend = ci.data() + ve;
                         const int64_t back = std::lower_bound(vl, vend, (int32_t)u) - vl;    // (u is in v's list: the adjacency is symmetric)
-                        keep[(size_t)(vb + back)] = 1;
+                        if (back < ve - vb && vl[back] == (int32_t)u) keep[(size_t)(vb + back)] = 1;
                     }
                 }
                 for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] = 0;
@@ -533,6 +486,225 @@ int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t n
     respread();
     lap("median sweeps");
     for (int64_t v = 0; v < n; v++) new_id[(size_t)v] = (int32_t)pos[(size_t)v];
+    return GNNA_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t num_edges, int64_t num_nodes,
+                               int32_t *new_id)
+{
+    using gnna::fail;
+    if (num_edges < 0 || num_nodes < 0 || (num_nodes > 0 && !new_id) || (num_edges > 0 && (!src || !dst)))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "bad reorder arguments");
+    if (num_nodes > 0x7fffffffLL)
+        return fail(GNNA_ERR_UNSUPPORTED, "graph too large for int32 node ids");
+    const int64_t n = num_nodes;
+    if (n == 0) return GNNA_OK;
+    const int threads = host_threads();
+    const bool debug = std::getenv("GNNA_REORDER_DEBUG") != nullptr;
+    Lap lap(debug);
+
+    // symmetrised, duplicate-free adjacency (reorder.cpp:31-97 does the same before aggregating).  64-bit row offsets:
+    // the list may hold more than 2^31 entries once both directions are in (papers100M symmetrised: 3.2e9); built in
+    // parallel over slabs of the edge list (atomic degree counts and cursors), then sorted and de-duplicated per row.
+    std::vector<int64_t> rp((size_t)n + 1, 0);
+    std::vector<int32_t> ci;
+    {
+        std::vector<int64_t> cursor((size_t)n + 1, 0);
+        auto over_edges = [&](auto &&fn) {
+            const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(threads, num_edges / (1 << 20) + 1));
+            std::vector<std::thread> th;
+            const int64_t step = (num_edges + nt - 1) / nt;
+            for (int64_t t = 0; t < nt; t++) {
+                const int64_t lo = t * step, hi = std::min(num_edges, lo + step);
+                if (lo >= hi) break;
+                th.emplace_back([&fn, lo, hi] { fn(lo, hi); });
+            }
+            for (auto &t : th) t.join();
+        };
+        int64_t bad_edge = -1;
+        over_edges([&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++)
+                if (src[e] < 0 || src[e] >= n || dst[e] < 0 || dst[e] >= n) { __atomic_store_n(&bad_edge, e, __ATOMIC_RELAXED); return; }
+        });
+        if (bad_edge >= 0)
+            return fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld (%d -> %d) outside [0, %lld)", (long long)bad_edge, src[bad_edge],
+                        dst[bad_edge], (long long)n);
+        over_edges([&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++) {
+                __atomic_fetch_add(&cursor[(size_t)src[e] + 1], 1, __ATOMIC_RELAXED);
+                __atomic_fetch_add(&cursor[(size_t)dst[e] + 1], 1, __ATOMIC_RELAXED);
+            }
+        });
+        lap("  adjacency: counted");
+        for (int64_t v = 0; v < n; v++) cursor[(size_t)v + 1] += cursor[(size_t)v];
+        std::vector<int64_t> start(cursor.begin(), cursor.end());
+        std::vector<int32_t> bucket((size_t)(2 * num_edges));
+        over_edges([&](int64_t lo, int64_t hi) {
+            for (int64_t e = lo; e < hi; e++) {
+                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)src[e]], 1, __ATOMIC_RELAXED)] = dst[e];
+                bucket[(size_t)__atomic_fetch_add(&cursor[(size_t)dst[e]], 1, __ATOMIC_RELAXED)] = src[e];
+            }
+        });
+        lap("  adjacency: scattered");
+        std::vector<int32_t> uniq((size_t)n, 0);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t v = lo; v < hi; v++) {
+                int32_t *b = bucket.data() + start[(size_t)v], *e = bucket.data() + start[(size_t)v + 1];
+                std::sort(b, e);                                   // (the scatter order depends on the threads, the sorted row does not)
+                uniq[(size_t)v] = (int32_t)(std::unique(b, e) - b);
+            }
+        });
+        lap("  adjacency: rows sorted");
+        for (int64_t v = 0; v < n; v++) rp[(size_t)v + 1] = rp[(size_t)v] + uniq[(size_t)v];
+        ci.resize((size_t)rp[(size_t)n]);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t v = lo; v < hi; v++)
+                std::copy_n(bucket.data() + start[(size_t)v], uniq[(size_t)v], ci.data() + rp[(size_t)v]);
+        });
+    }
+
+    lap("symmetrised adjacency");
+    return community_order(n, rp, IdList{ci.data(), ci.size()}, new_id, threads, debug, lap);
+}
+
+// The same renumbering for a caller that already holds the graph as a CSR with sorted, duplicate-free rows (what the loader
+// builds, dataset.py:108-118): a symmetric CSR IS the adjacency the algorithm works on -- nothing is counted, scattered or sorted
+// again (1.2 of 4.6 s at 1.1e8 edges).  Symmetry is decided by two 64-bit sums over all entries, of a hash of (row, column) and
+// of (column, row): equal for a symmetric matrix, different otherwise up to 2^-128.  A directed CSR goes through the edge-list path.
+int gnna_reorder_community_csr_i32(const int32_t *row_pointers, const int32_t *column_index, int64_t num_nodes, int32_t *new_id)
+{
+    using gnna::fail;
+    if (num_nodes < 0 || (num_nodes > 0 && (!new_id || !row_pointers)))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "bad reorder arguments");
+    const int64_t n = num_nodes;
+    if (n == 0) return GNNA_OK;
+    const int64_t nnz = row_pointers[n];
+    if (row_pointers[0] != 0 || nnz < 0 || (nnz > 0 && !column_index)) return fail(GNNA_ERR_INVALID_ARGUMENT, "bad CSR");
+    const int threads = host_threads();
+    const bool debug = std::getenv("GNNA_REORDER_DEBUG") != nullptr;
+    Lap lap(debug);
+    auto mix = [](uint64_t x) { x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull; x ^= x >> 27; x *= 0x94d049bb133111ebull; return x ^ (x >> 31); };
+    std::vector<uint64_t> sums((size_t)threads * 4, 0);
+    std::vector<int64_t> bad((size_t)threads, -1);
+    {
+        std::vector<std::thread> th;
+        const int64_t step = (n + threads - 1) / threads;
+        for (int t = 0; t < threads; t++)
+            th.emplace_back([&, t] {
+                uint64_t a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                for (int64_t u = t * step; u < std::min(n, (t + 1) * step); u++) {
+                    const int64_t b = row_pointers[u], e = row_pointers[u + 1];
+                    if (e < b || e > nnz) { bad[(size_t)t] = u; return; }
+                    for (int64_t k = b; k < e; k++) {
+                        const int64_t v = column_index[k];
+                        if (v < 0 || v >= n || (k > b && column_index[k - 1] >= v)) { bad[(size_t)t] = u; return; }
+                        const uint64_t uv = ((uint64_t)u << 32) | (uint64_t)v, vu = ((uint64_t)v << 32) | (uint64_t)u;
+                        a0 += mix(uv); a1 += mix(uv ^ 0x9E3779B97F4A7C15ull);
+                        b0 += mix(vu); b1 += mix(vu ^ 0x9E3779B97F4A7C15ull);
+                    }
+                }
+                sums[(size_t)t * 4] = a0; sums[(size_t)t * 4 + 1] = a1; sums[(size_t)t * 4 + 2] = b0; sums[(size_t)t * 4 + 3] = b1;
+            });
+        for (auto &t : th) t.join();
+    }
+    for (int64_t u : bad)
+        if (u >= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "row %lld of the CSR: ids must lie in [0, %lld) in strictly increasing order",
+                                (long long)u, (long long)n);
+    uint64_t tot[4] = {0, 0, 0, 0};
+    for (int t = 0; t < threads; t++) for (int q = 0; q < 4; q++) tot[q] += sums[(size_t)t * 4 + q];
+    if (tot[0] != tot[2] || tot[1] != tot[3]) {
+        if (debug) std::fprintf(stderr, "[reorder] the CSR is not symmetric: edge-list path\n");
+        std::vector<int32_t> rows((size_t)nnz);
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t u = lo; u < hi; u++) std::fill(rows.begin() + row_pointers[u], rows.begin() + row_pointers[u + 1], (int32_t)u);
+        });
+        return gnna_reorder_community_i32(rows.data(), column_index, nnz, n, new_id);
+    }
+    std::vector<int64_t> rp((size_t)n + 1);
+    for (int64_t u = 0; u <= n; u++) rp[(size_t)u] = row_pointers[u];
+    lap("CSR checked (symmetric)");
+    return community_order(n, rp, IdList{column_index, (size_t)nnz}, new_id, threads, debug, lap);
+}
+
+// Applies a renumbering to what the loader holds (dataset.py:147-172 relabels the edge list and rebuilds everything from it):
+//   gnna_relabel_edges_i32: src[e] <- new_id[src[e]], dst[e] <- new_id[dst[e]] in place, and the new mean |src - dst|;
+//   gnna_relabel_csr_i32:   the CSR of the relabelled graph from the CSR of the old one -- row new_id[u] is row u with its ids
+//     mapped and sorted again; no global sort, no de-duplication (a permutation keeps distinct ids distinct).
+int gnna_relabel_edges_i32(int32_t *src, int32_t *dst, int64_t num_edges, const int32_t *new_id, int64_t num_nodes, double *avg_edge_span)
+{
+    using gnna::fail;
+    if (num_edges < 0 || num_nodes < 0 || (num_edges > 0 && (!src || !dst || !new_id)))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "bad relabel arguments");
+    const int threads = host_threads();
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(threads, num_edges / (1 << 20) + 1));
+    std::vector<double> span((size_t)nt, 0.0);
+    std::vector<int64_t> bad((size_t)nt, -1);
+    std::vector<std::thread> th;
+    const int64_t step = (num_edges + nt - 1) / nt;
+    for (int64_t t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            int64_t acc = 0;
+            for (int64_t e = t * step; e < std::min(num_edges, (t + 1) * step); e++) {
+                if (src[e] < 0 || src[e] >= num_nodes || dst[e] < 0 || dst[e] >= num_nodes) { bad[(size_t)t] = e; return; }
+                const int32_t a = new_id[src[e]], b = new_id[dst[e]];
+                src[e] = a; dst[e] = b;
+                acc += a > b ? (int64_t)a - b : (int64_t)b - a;
+            }
+            span[(size_t)t] = (double)acc;
+        });
+    for (auto &t : th) t.join();
+    for (int64_t e : bad) if (e >= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "edge %lld outside [0, %lld)", (long long)e, (long long)num_nodes);
+    if (avg_edge_span) {
+        double total = 0.0;
+        for (double v : span) total += v;
+        *avg_edge_span = num_edges ? total / (double)num_edges : 0.0;
+    }
+    return GNNA_OK;
+}
+
+int gnna_relabel_csr_i32(const int32_t *row_pointers, const int32_t *column_index, int64_t num_nodes, const int32_t *new_id,
+                         int32_t *out_row_pointers, int32_t *out_column_index)
+{
+    using gnna::fail;
+    const int64_t n = num_nodes;
+    if (n < 0 || (n > 0 && (!row_pointers || !new_id || !out_row_pointers)))
+        return fail(GNNA_ERR_INVALID_ARGUMENT, "bad relabel arguments");
+    if (n == 0) { if (out_row_pointers) out_row_pointers[0] = 0; return GNNA_OK; }
+    const int threads = host_threads();
+    std::vector<int32_t> old_of((size_t)n, -1);
+    for (int64_t u = 0; u < n; u++) {
+        const int32_t w = new_id[u];
+        if (w < 0 || w >= n || old_of[(size_t)w] >= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "new_id is not a permutation (entry %lld)", (long long)u);
+        old_of[(size_t)w] = (int32_t)u;
+    }
+    out_row_pointers[0] = 0;
+    for (int64_t w = 0; w < n; w++) {
+        const int32_t u = old_of[(size_t)w];
+        const int64_t d = (int64_t)row_pointers[u + 1] - row_pointers[u];
+        if (d < 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "row_pointers decrease at row %d", u);
+        out_row_pointers[w + 1] = (int32_t)(out_row_pointers[w] + d);
+    }
+    std::vector<int64_t> bad((size_t)threads + 1, -1);
+    parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+        for (int64_t w = lo; w < hi; w++) {
+            const int32_t u = old_of[(size_t)w];
+            int32_t *o = out_column_index + out_row_pointers[w];
+            const int64_t b = row_pointers[u], e = row_pointers[u + 1];
+            for (int64_t k = b; k < e; k++) {
+                const int32_t v = column_index[k];
+                if (v < 0 || v >= n) { __atomic_store_n(&bad[0], (int64_t)u, __ATOMIC_RELAXED); return; }
+                o[k - b] = new_id[v];
+            }
+            std::sort(o, o + (e - b));
+        }
+    });
+    if (bad[0] >= 0) return fail(GNNA_ERR_INVALID_ARGUMENT, "row %lld holds an id outside [0, %lld)", (long long)bad[0], (long long)n);
     return GNNA_OK;
 }
 

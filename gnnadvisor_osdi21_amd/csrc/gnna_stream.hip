@@ -817,6 +817,58 @@ ids_checksum_kernel(const int32_t *__restrict__ col, int64_t n, const int32_t *_
     if (threadIdx.x == 0) *out = v;
 }
 
+// 64-bit hash of ALL of column_index and part_pointers (gnna_tuning.ids_check_every): every entry, tagged with its position,
+// goes through a multiply-xorshift mixer and the results are summed -- order-free, so any grid shape and any interleaving of
+// the atomics gives the same value.  state[0] = the copy's sample checksum (ids_checksum_kernel), [1] = the hash stored when the
+// copy was made, [2] = running sum, [3] = workgroups finished, [4] = 1 once a later hash differed: the copy is never trusted
+// again (the prologue's sample check reads [4]).  The last workgroup to finish compares / stores and clears [2], [3].
+__device__ __forceinline__ unsigned long long mix_id(unsigned long long pos, uint32_t id, unsigned long long salt)
+{
+    unsigned long long x = ((pos << 32) | (unsigned long long)id) ^ salt;
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(kBlock)
+ids_full_hash_kernel(const int32_t *__restrict__ col, int64_t n, const int32_t *__restrict__ pp, int64_t P,
+                     unsigned long long *__restrict__ state, int store, int32_t *stale_flag, int32_t seq)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long sum = 0;
+    // the ids four at a time where the array allows it (16-byte loads: this pass is one read of 4 x nnz bytes)
+    const bool vec = (reinterpret_cast<uintptr_t>(col) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    for (int64_t i = tid; i < n4; i += nthreads) {
+        const i32x4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(col) + i);
+        const unsigned long long b = (unsigned long long)i << 2;
+        sum += mix_id(b, (uint32_t)v.x, 0) + mix_id(b + 1, (uint32_t)v.y, 0) + mix_id(b + 2, (uint32_t)v.z, 0) + mix_id(b + 3, (uint32_t)v.w, 0);
+    }
+    for (int64_t i = (n4 << 2) + tid; i < n; i += nthreads) sum += mix_id((unsigned long long)i, (uint32_t)col[i], 0);
+    for (int64_t i = tid; i <= P; i += nthreads) sum += mix_id((unsigned long long)i, (uint32_t)pp[i], 0x9E3779B97F4A7C15ull);
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d);
+    __shared__ unsigned long long part[kBlock / kWave];
+    __shared__ bool last;
+    if ((threadIdx.x & (kWave - 1)) == 0) part[threadIdx.x / kWave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < kBlock / kWave; w++) t += part[w];
+        atomicAdd(&state[2], t);
+        __threadfence();
+        last = atomicAdd(&state[3], 1ull) == (unsigned long long)gridDim.x - 1ull;
+        if (last) {
+            __threadfence();
+            const unsigned long long total = atomicAdd(&state[2], 0ull);
+            if (store) { state[1] = total; state[4] = 0ull; }
+            else if (total != state[1]) { state[4] = 1ull; if (stale_flag) *stale_flag = seq; }
+            state[2] = 0ull; state[3] = 0ull;
+            __threadfence();
+        }
+    }
+}
+
 // ---- plan cache -------------------------------------------------------------------------------------
 struct Plan {
     const void *col = nullptr, *pp = nullptr, *p2n = nullptr;
@@ -839,7 +891,9 @@ struct Plan {
         int B = 0, G = 0;
         int32_t *ids = nullptr;          // nnz ids, then (at item_off) B * num_chunks + 1 item starts
         uint32_t *item_off = nullptr;
-        unsigned long long *checksum = nullptr;   // sample_checksum of column_index when the copy was made
+        unsigned long long *checksum = nullptr;   // 8 words behind the copy: [0] sample checksum of the graph when the copy was made,
+                                                  // [1..4] full hash, its accumulator and the "never trust again" mark (ids_full_hash_kernel)
+        uint64_t hits = 0;               // launches that found this copy (every ids_check_every-th runs the full hash)
         int64_t num_ids = 0;
         hipEvent_t ready = nullptr;
         hipStream_t made_on = nullptr;
@@ -1077,8 +1131,18 @@ void drop_slice_plans() { (void)release_slice_plans(nullptr, false); }
 // capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
 // plan that already holds kMaxPacked is replaced after a device synchronisation -- at a launch only if it has not been
 // used for a while, in gnna_prepare_graph (force) always).  *ids stays null when there is none.
+static void launch_full_hash(DeviceState *ds, hipStream_t stream, const Plan *pl, int64_t nnz, unsigned long long *state, int store,
+                             int32_t *stale_flag, int32_t seq)
+{
+    const int64_t work = (nnz + 3) / 4 + pl->P + 1;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((work + kBlock - 1) / kBlock, (int64_t)ds->num_cus * 8));
+    hipLaunchKernelGGL(ids_full_hash_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, stream, static_cast<const int32_t *>(pl->col), nnz,
+                       static_cast<const int32_t *>(pl->pp), pl->P, state, store, stale_flag, seq);
+}
+
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
-                   const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum, int64_t *num_ids)
+                   const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum, int64_t *num_ids,
+                   int32_t *stale_flag, int32_t seq, int check_every)
 {
     *ids = nullptr; *item_off = nullptr;
     if (checksum) *checksum = nullptr;
@@ -1095,6 +1159,13 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
         if (pk.B == B && pk.G == G && pk.ids) {
             if (pk.made_on != stream && cap == hipStreamCaptureStatusNone) (void)hipStreamWaitEvent(stream, pk.ready, 0);
             pk.stamp = pl->pack_lookups;
+            // every check_every-th launch on this copy: the full hash of the graph behind it, on the same stream ahead of the
+            // aggregation (not while capturing: a replayed graph would either always or never pay for it)
+            if (stale_flag && check_every > 0 && check_every < (1 << 30) && cap == hipStreamCaptureStatusNone &&
+                ++pk.hits % (uint64_t)check_every == 0) {
+                launch_full_hash(ds, stream, pl, pk.num_ids, pk.checksum, 0, stale_flag, seq);
+                count_event(CTR_FULL_HASHES);
+            }
             *ids = pk.ids; *item_off = pk.item_off;
             if (checksum) *checksum = pk.checksum;
             if (num_ids) *num_ids = pk.num_ids;
@@ -1136,7 +1207,7 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
     }
     const size_t id_bytes = (((size_t)nnz * sizeof(int32_t)) + 255) & ~(size_t)255;
     const size_t off_bytes = ((((size_t)items + 1) * sizeof(uint32_t)) + 15) & ~(size_t)15;
-    const size_t bytes = id_bytes + off_bytes + 16;
+    const size_t bytes = id_bytes + off_bytes + 64;      // (+ the 8 state words of the checksums)
     e = hipMalloc(reinterpret_cast<void **>(&slot->ids), bytes);
     count_event(CTR_LAUNCH_MALLOCS);
     if (e != hipSuccess) {
@@ -1164,6 +1235,9 @@ int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B
                        static_cast<const int32_t *>(pl->pp), pl->cnt, pl->P, num_chunks, G, kMaxSlices, B, slot->item_off, slot->ids);
     hipLaunchKernelGGL(ids_checksum_kernel, dim3(1), dim3(kWave), 0, stream, static_cast<const int32_t *>(pl->col), nnz,
                        static_cast<const int32_t *>(pl->pp), pl->P, slot->checksum);
+    (void)hipMemsetAsync(slot->checksum + 1, 0, 7 * sizeof(unsigned long long), stream);
+    launch_full_hash(ds, stream, pl, nnz, slot->checksum, 1, nullptr, 0);
+    slot->hits = 0;
     e = hipGetLastError();
     if (e != hipSuccess) return fail(GNNA_ERR_HIP, "packed ids launch: %s", hipGetErrorString(e));
     (void)hipEventRecord(slot->ready, stream);
@@ -1255,6 +1329,11 @@ extern "C" {
 void gnna_runtime_counters(int64_t out[8])
 {
     for (int i = 0; i < 8; i++) out[i] = i < gnna::CTR_COUNT ? (int64_t)gnna::g_counters[i].load() : 0;
+}
+int gnna_runtime_counters_ex(int64_t *out, int capacity)
+{
+    for (int i = 0; i < capacity && i < gnna::CTR_COUNT; i++) out[i] = (int64_t)gnna::g_counters[i].load();
+    return gnna::CTR_COUNT;
 }
 #pragma GCC visibility pop
 }

@@ -47,11 +47,13 @@ enum AggKind { AGG_SAG, AGG_GCN, AGG_GIN };
 // from the packed copy (1.442 against 1.36 ms on the Reddit-like headline).  This module knows more
 // than a raw-pointer caller can tell the C ABI: a torch tensor carries a VERSION COUNTER that every in-place write
 // through torch bumps, and a storage that outlives or dies with it.  A graph -- the (column_index, part_pointers,
-// part2Node) triple -- that is seen a SECOND time with the same storages, data pointers, sizes and version counters is
-// the same immutable graph the first call saw, and is prepared then (one stream synchronisation + the packed copy, nnz x
-// 4 bytes, per width; never inside a stream capture).  Any change -- a version bump, a new storage at the old address,
+// part2Node) triple -- that is seen a THIRD time with the same storages, data pointers, sizes and version counters, while no
+// stream of new graphs is passing through (see note_graph), is the same immutable graph the first call saw, and is prepared
+// then (one stream synchronisation + the packed copy, nnz x 4 bytes, per width; never inside a stream capture).  Any change -- a version bump, a new storage at the old address,
 // another size or partSize -- forgets the library's plan for that address first (gnna_forget_graph) and starts over.  The
-// packed copy's own sample checksum stays as a second guard (writes that bypass torch).  GNNA_AUTO_PREPARE=0 turns it off.
+// packed copy's own checks stay as a second guard for writes that bypass torch: 2 x 1,024 samples at every call and a 64-bit hash of
+// all ids at every 64th (gnna_tuning.ids_check_every; GNNA.forget_graph(column_index) tells the module at once).  GNNA_AUTO_PREPARE=0
+// turns the automatic lifecycle off.
 struct SeenGraph {
     const void *ci = nullptr, *pp = nullptr, *p2n = nullptr;
     c10::weak_intrusive_ptr<c10::StorageImpl> s_ci{c10::intrusive_ptr<c10::StorageImpl>()},
@@ -60,7 +62,7 @@ struct SeenGraph {
     int64_t nnz = 0, parts = 0, rows = 0;
     int partSize = 0, device = -1;
     int sightings = 0;
-    uint64_t stamp = 0;
+    uint64_t stamp = 0, born = 0;     // call numbers (g_seen_clock) of the latest and of the first sighting
     std::vector<int> dims_done;       // widths gnna_prepare_graph has been called for (successfully or not: one attempt each)
 };
 constexpr int kSeenGraphs = 16;
@@ -74,24 +76,48 @@ bool same_storage(const c10::weak_intrusive_ptr<c10::StorageImpl> &w, const torc
     return !w.expired() && w._unsafe_get_target() == t.storage().unsafeGetStorageImpl();
 }
 
-// gnna_forget_graph() drops every plan keyed by this column_index -- those of the other partitions over the same array too:
-// their entries must prepare again (at their next call) instead of believing their plans are still pinned.  Caller holds the mutex.
+// gnna_forget_plans() drops every plan keyed by this column_index -- those of the other partitions over the same array too:
+// their entries must prepare again (at their next call) instead of believing their plans are still pinned.  Only what this
+// module pinned goes: hints and measured schedules the CALLER registered for a graph that is still alive (gnna_set_graph_hints,
+// gnna_set_graph_phases) are not this module's to wipe.  Caller holds the mutex.
 void forget_plans_of(const void *ci)
 {
-    (void)gnna_forget_graph(static_cast<const int32_t *>(ci));
+    (void)gnna_forget_plans(static_cast<const int32_t *>(ci));
     for (auto &g : g_seen)
         if (g.ci == ci) g.dims_done.clear();
 }
 
+// When is a graph "the same immutable graph again"?  Not at its second sighting (round 5's rule): in sampled / mini-batch
+// training every step's fresh subgraph is seen several times within the step (second layer, backward) and would be prepared --
+// a stream synchronisation, a counting pass, hipMalloc of the packed copy -- only to be dropped with a hipFree when its tensors
+// die.  The rule now:
+//   * at least kSightings calls with unchanged storages and version counters,
+//   * at least kMinEdges edges (the packed copy pays on the sliced schedules of large graphs only),
+//   * and the set of graphs is standing still: no OTHER graph made its first appearance within the last kQuietWindow calls
+//     (the module's counterpart of the library's own back-off for partitions that keep changing).  A second standing graph
+//     (train / validation) is therefore prepared kQuietWindow calls after it turned up; of a stream of mini-batches only the
+//     very first is.
+constexpr int kSightings = 3;
+constexpr int64_t kMinEdges = 1 << 18;
+constexpr uint64_t kQuietWindow = 32;
+constexpr int kQuietOthers = 0;
+uint64_t g_first_seen[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // call numbers of the latest first appearances (ring)
+int g_first_seen_at = 0;
+
 void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_pointers, const torch::Tensor &part2Node,
                 int64_t rows, int partSize, int dim, void *stream)
 {
-    static const bool enabled = !(std::getenv("GNNA_AUTO_PREPARE") && std::atoi(std::getenv("GNNA_AUTO_PREPARE")) == 0);
-    if (!enabled || part2Node.size(0) == 0 || column_index.numel() == 0 || dim <= 0) return;
+    // GNNA_AUTO_PREPARE (read at every call): 0 = off, 1 / unset = the rule above, 2 = eager -- the second sighting, any size,
+    // whatever else is passing through (round 5's rule: for callers who know their graphs are few and fixed, and for the tests)
+    const char *env = std::getenv("GNNA_AUTO_PREPARE");
+    const int policy = env ? std::atoi(env) : 1;
+    if (policy == 0 || part2Node.size(0) == 0 || column_index.numel() == 0 || dim <= 0) return;
+    const bool eager = policy == 2;
     if (column_index.is_inference() || part_pointers.is_inference() || part2Node.is_inference()) return;   // (no version counter)
     const void *ci = column_index.data_ptr();
     const int device = column_index.get_device();
     std::lock_guard<std::mutex> lock(g_seen_mutex);
+    const uint64_t now = ++g_seen_clock;
     // graphs whose tensors are gone: their plans (and packed copies: nnz x 4 bytes each) must not stay pinned in the library
     for (auto &g : g_seen)
         if (g.ci && (g.s_ci.expired() || g.s_pp.expired() || g.s_p2n.expired())) {
@@ -114,7 +140,7 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
                       e->partSize == partSize;
     if (!same) {
         if (e) {
-            forget_plans_of(ci);                                           // another graph lives at this address now
+            if (!e->dims_done.empty()) forget_plans_of(ci);               // another graph lives at this address now
         } else {
             e = victim;                                                    // (the least recently seen entry makes room:
             if (e->ci && !e->dims_done.empty()) forget_plans_of(e->ci);    // unpin what it pinned)
@@ -126,17 +152,37 @@ void note_graph(const torch::Tensor &column_index, const torch::Tensor &part_poi
         e->s_p2n = part2Node.storage().getWeakStorageImpl();
         e->v_ci = column_index._version(); e->v_pp = part_pointers._version(); e->v_p2n = part2Node._version();
         e->nnz = column_index.numel(); e->parts = part2Node.size(0); e->rows = rows; e->partSize = partSize; e->device = device;
+        e->born = now;
+        g_first_seen[g_first_seen_at] = now;
+        g_first_seen_at = (g_first_seen_at + 1) % 8;
     }
     e->sightings++;
-    e->stamp = ++g_seen_clock;
-    if (e->sightings < 2) return;
+    e->stamp = now;
+    if (e->sightings < (eager ? 2 : kSightings) || (!eager && e->nnz < kMinEdges)) return;
     for (int d : e->dims_done) if (d == dim) return;
+    int others = 0;
+    for (uint64_t born : g_first_seen)
+        if (born != 0 && born != e->born && now - born < kQuietWindow) others++;
+    if (!eager && others > kQuietOthers) return;   // the graphs keep changing (sampled training): nothing is pinned for them
     int phases = 0;
     const int rc = gnna_prepare_graph(static_cast<const int32_t *>(ci), part_pointers.data_ptr<int32_t>(),
                                       part2Node.data_ptr<int32_t>(), e->parts, rows, rows, partSize, &dim, 1, &phases, stream);
     if (rc == GNNA_ERR_UNSUPPORTED) return;        // inside a stream capture: try again at the next eager call
     e->dims_done.push_back(dim);                   // (a failed attempt -- no memory for the copy -- is not repeated per call)
     if (rc == GNNA_OK) g_auto_prepared.fetch_add(1);
+}
+
+// The module-level counterpart of gnna_forget_graph for callers that write into a graph's arrays behind torch's back
+// (`column_index.data[k] = v`, a raw pointer, another library): forgets what this module remembers about every partition over
+// this column_index and everything the library holds for it -- the next call sees the graph for the first time.
+void forget_graph(const torch::Tensor &column_index)
+{
+    CHECK_CUDA(column_index);
+    const void *ci = column_index.data_ptr();
+    std::lock_guard<std::mutex> lock(g_seen_mutex);
+    for (auto &g : g_seen)
+        if (g.ci == ci) g = SeenGraph();
+    (void)gnna_forget_graph(static_cast<const int32_t *>(ci));
 }
 
 // Runs one aggregation of `input` ([N, dim]) into a fresh tensor on input's device/stream.
@@ -493,8 +539,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 #ifndef GNNA_SOURCE_HASH
 #define GNNA_SOURCE_HASH "unhashed"
 #endif
+    m.def("forget_graph", &forget_graph,
+          "forget every plan, packed id copy and hint kept for this column_index (extension): call it after writing into a graph's "
+          "arrays in a way torch's version counter does not see (`t.data[...] = ...`, raw pointers)", pybind11::arg("column_index"));
     m.def("auto_prepared_graphs", []() { return (long long)g_auto_prepared.load(); },
-          "how many (graph, width) pairs the module prepared by itself on their second sighting (extension; see note_graph)");
+          "how many (graph, width) pairs the module prepared by itself once they had stood still for three calls (extension; see note_graph)");
     m.def("build_id", []() { return std::string("module ") + GNNA_SOURCE_HASH + ", library " + gnna_build_id(); },
           "source hashes this module and the libgnna.so it loaded were built from (extension)");
 }

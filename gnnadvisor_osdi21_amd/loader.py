@@ -69,14 +69,20 @@ class custom_dataset(torch.nn.Module):
                    _edges=(src, dst, num_nodes))
 
     @classmethod
-    def from_synthetic(cls, name, dim=None, num_class=None, scale=1.0, verbose=False, device=None):
-        """One of graph.CONFIGS (seeded power-law stand-ins for the BASELINE.json graphs)."""
+    def from_synthetic(cls, name, dim=None, num_class=None, scale=1.0, verbose=False, device=None, locality=0.0, scramble=False):
+        """One of graph.CONFIGS (seeded power-law stand-ins for the BASELINE.json graphs).  locality: that share of the edges
+        stays within +-4096 ids of a hidden order; scramble: the ids are then relabelled at random -- a graph with community
+        structure whose numbering hides it, which is what the renumbering has to recover."""
         from . import graph
         c = graph.CONFIGS[name]
-        g = graph.make_config_graph(name, device="cuda" if torch.cuda.is_available() else "cpu", scale=scale)
-        rows = torch.repeat_interleave(torch.arange(g.num_nodes, device=g.row_pointers.device),
+        g = graph.make_config_graph(name, device="cuda" if torch.cuda.is_available() else "cpu", scale=scale, locality=locality)
+        rows = torch.repeat_interleave(torch.arange(g.num_nodes, device=g.row_pointers.device, dtype=torch.int32),
                                        (g.row_pointers[1:] - g.row_pointers[:-1]).long())
-        return cls.from_edges(rows.cpu().numpy(), g.column_index.cpu().numpy(), g.num_nodes,
+        cols = g.column_index
+        if scramble:
+            perm = torch.randperm(g.num_nodes, device=rows.device, generator=torch.Generator(device=rows.device).manual_seed(1)).to(torch.int32)
+            rows, cols = perm[rows.long()], perm[cols.long()]
+        return cls.from_edges(rows.cpu().numpy(), cols.cpu().numpy(), g.num_nodes,
                               dim if dim is not None else c["feat"],
                               num_class if num_class is not None else c["classes"], verbose, device)
 
@@ -101,14 +107,20 @@ class custom_dataset(torch.nn.Module):
     def _set_edges(self, src, dst, num_nodes):
         self.num_nodes = int(num_nodes)
         self.num_edges = int(len(src))
-        self.edge_index = np.stack([np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)])
+        # [2, E] like the reference's (dataset.py:96), but int32 (the CSR and the kernels are int32: ids that do not fit are refused
+        # here instead of wrapping there; at 1.1e8 edges every int64 copy / conversion of this array is a second of a host thread)
+        if self.num_edges and (self.num_nodes > 2**31 - 1 or int(np.min(src)) < 0 or int(np.min(dst)) < 0
+                               or max(int(np.max(src)), int(np.max(dst))) >= self.num_nodes):
+            raise ValueError("node ids must lie in [0, num_nodes) with num_nodes < 2^31")
+        self.edge_index = np.empty((2, self.num_edges), dtype=np.int32)
+        self.edge_index[0], self.edge_index[1] = src, dst
         self.avg_degree = self.num_edges / self.num_nodes if self.num_nodes else 0.0
         self.avg_edgeSpan = _lib.edge_span(self.edge_index[0], self.edge_index[1])
         if self.verbose_flag:
             print('# nodes: {}'.format(self.num_nodes))
             print("# avg_degree: {:.2f}".format(self.avg_degree))
             print("# avg_edgeSpan: {}".format(int(self.avg_edgeSpan)))
-        self.val = [1] * self.num_edges
+        self.val = np.ones(self.num_edges, dtype=np.float32)   # (dataset.py:106 builds [1] * E: the same values, not 1e8 Python ints)
         self._build_csr("# Build CSR (s): {:.3f}")
 
     def _build_csr(self, msg):
@@ -136,14 +148,24 @@ class custom_dataset(torch.nn.Module):
                 print("Reorder flag is not set. Skipped...")
             return
         start = time.perf_counter()
-        renumber = _lib.reorder_rcm if self.reorder_method == "rcm" else _lib.reorder_community
-        new_id = renumber(self.edge_index[0], self.edge_index[1], self.num_nodes).numpy().astype(np.int64)
-        self.new_id = new_id                                   # new_id[old] (kept for callers that hold per-node data)
-        self.edge_index = np.stack([new_id[self.edge_index[0]], new_id[self.edge_index[1]]])
+        if self.reorder_method == "rcm":
+            new_id = _lib.reorder_rcm(self.edge_index[0], self.edge_index[1], self.num_nodes)
+        else:
+            # from the CSR this dataset already holds (symmetric graphs: it IS the algorithm's adjacency; same permutation as
+            # from the edge list, gnna_reorder_community_csr_i32)
+            new_id = _lib.reorder_community_csr(self.row_pointers, self.column_index, self.num_nodes)
+        self.new_id = new_id.numpy().astype(np.int64)              # new_id[old] (kept for callers that hold per-node data)
         if self.verbose_flag:
             print("# Reorder time (s): {}".format(time.perf_counter() - start))
-        self.avg_edgeSpan_after = _lib.edge_span(self.edge_index[0], self.edge_index[1])
-        self._build_csr("# Re-Build CSR (s): {:.3f}")
+        t1 = time.perf_counter()
+        # edge list relabelled in place (+ its new span), CSR rows permuted / mapped / re-sorted: no global sort again
+        self.avg_edgeSpan_after = _lib.relabel_edges_(torch.from_numpy(self.edge_index[0]), torch.from_numpy(self.edge_index[1]),
+                                                      new_id, self.num_nodes)
+        self.row_pointers, self.column_index = _lib.relabel_csr(self.row_pointers, self.column_index, new_id, self.num_nodes)
+        self.degrees = _lib.degrees(self.row_pointers).to(self.device)
+        if self.verbose_flag:
+            print("# Re-Build CSR (s): {:.3f}".format(time.perf_counter() - t1))
+        new_id = self.new_id
         if self.permute_node_data:
             where = torch.from_numpy(new_id).to(self.device)   # new position of old row i
             for name in ("x", "y", "train_mask", "val_mask", "test_mask"):

@@ -41,6 +41,8 @@ def build_parser():
     p.add_argument('--verify_spmm', default='False', help="True: verify one SpMM against the CPU reference", **tf)
     p.add_argument('--synthetic', type=str, default=None, help="use a seeded synthetic graph (graph.CONFIGS name)")
     p.add_argument('--scale', type=float, default=1.0, help="shrink the synthetic graph")
+    p.add_argument('--locality', type=float, default=0.0, help="synthetic graph: share of the edges within +-4096 ids of a hidden order")
+    p.add_argument('--scramble', default='False', **tf, help="synthetic graph: relabel the nodes at random (hides the locality)")
     p.add_argument('--hip_graph', default='False', **tf,
                    help="True: capture one training epoch (forward, backward, Adam) into a HIP graph and replay it "
                         "(MI355X addition; pays on small, launch-bound graphs)")
@@ -54,7 +56,8 @@ def build_parser():
     return p
 
 
-def main(argv=None):
+def main(argv=None, capture=None):
+    """capture: a dict that receives the run's objects (dataset, inputInfo, model) -- for tests and notebooks."""
     args = build_parser().parse_args(argv)
     print(args)
     flag = lambda s: s == 'True'
@@ -83,7 +86,8 @@ def main(argv=None):
     # ---- loading data --------------------------------------------------------------------
     if args.synthetic:
         dataset = custom_dataset.from_synthetic(args.synthetic, args.dim, args.classes, args.scale,
-                                                verbose=verbose_mode, device=device)
+                                                verbose=verbose_mode, device=device, locality=args.locality,
+                                                scramble=flag(args.scramble))
     elif loadFromTxt:
         dataset = custom_dataset(osp.join(args.dataDir, args.dataset), args.dim, args.classes,
                                  load_from_txt=True, verbose=verbose_mode, device=device)
@@ -140,6 +144,8 @@ def main(argv=None):
         _gnna_lib.prepare_graph(inputInfo.column_index, inputInfo.partPtr, inputInfo.part2Node, dataset.num_nodes,
                                 dataset.num_nodes, inputInfo.partSize, _prep_widths)
     degrees = inputInfo.degrees
+    if capture is not None:
+        capture.update(dataset=dataset, inputInfo=inputInfo, args=args)
 
     # ---- single-SpMM verification / profiling (GNNA_main.py:116-137) -------------------------------
     if verify_spmm or single_spmm:
@@ -183,6 +189,8 @@ def main(argv=None):
                 return F.log_softmax(x, dim=1)
 
     model = Net().to(device)
+    if capture is not None:
+        capture.update(dataset=dataset, inputInfo=inputInfo, model=model, args=args)
     if verbose_mode:
         print(model)
     use_graph = flag(args.hip_graph)

@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define GNNA_VERSION 500 /* 0.5.0: gnna_tuning opens with struct_size (checked by gnna_set_tuning, which now returns a status), gnna_build_id; 0.4.1: gnna_sddmm_ld_f32 (leading dimensions for both SDDMM sides); 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
+#define GNNA_VERSION 600 /* 0.6.0: gnna_tuning.ids_check_every (full hash of the ids behind a packed copy), gnna_device_cus, gnna_host_threads; 0.5.0: gnna_tuning opens with struct_size (checked by gnna_set_tuning, which now returns a status), gnna_build_id; 0.4.1: gnna_sddmm_ld_f32 (leading dimensions for both SDDMM sides); 0.4.0: gnna_agg_ld_f32 (leading dimensions, ReLU epilogue), gnna_forget_graph, chunk-walk kernel retired; 0.3.1: gnna_tuning grew (pack_ids); 0.3.0: sweep, sweep_slack, graph lifecycle, 64-bit CSR builder */
 #define GNNA_API __attribute__((visibility("default")))
 
 typedef enum gnna_status {
@@ -141,6 +141,21 @@ GNNA_API int gnna_reorder_rcm_i32(const int32_t *src, const int32_t *dst, int64_
  * offsets inside: papers100M symmetrised has 3.2e9). */
 GNNA_API int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
                                int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
+
+/* The same renumbering from the loader's CSR (sorted, duplicate-free rows; checked): a symmetric CSR is used as the adjacency
+ * as it stands -- no second counting sort (1.2 of 4.6 s at 1.1e8 edges); a directed one goes through the edge-list form.
+ * The permutation is the one gnna_reorder_community_i32 returns for the same graph. */
+GNNA_API int gnna_reorder_community_csr_i32(const int32_t *row_pointers, const int32_t *column_index, int64_t num_nodes,
+                                            int32_t *new_id /* [num_nodes] */);
+
+/* Applying a renumbering to what the loader holds (dataset.py:147-172 relabels the edge list, then rebuilds CSR and degrees from
+ * it): the edge list in place (+ the new mean |src - dst|, the Decider's statistic), and the relabelled graph's CSR straight from
+ * the old CSR -- row new_id[u] = the ids of row u mapped and sorted; no global sort (a permutation keeps rows duplicate-free). */
+GNNA_API int gnna_relabel_edges_i32(int32_t *src, int32_t *dst, int64_t num_edges, const int32_t *new_id, int64_t num_nodes,
+                                    double *avg_edge_span /* may be NULL */);
+GNNA_API int gnna_relabel_csr_i32(const int32_t *row_pointers, const int32_t *column_index, int64_t num_nodes,
+                                  const int32_t *new_id, int32_t *out_row_pointers /* [num_nodes + 1] */,
+                                  int32_t *out_column_index /* [nnz] */);
 
 /* ---- aggregation (device) ------------------------------------------------------------
  * out[i, :] = sum over groups p with part2Node[p] == i, over e in [part_pointers[p],
@@ -322,6 +337,13 @@ typedef struct gnna_tuning {
                              rewritten in place while the library holds a plan for it (the reference's own call sequence
                              never does; without the promise a stale copy would give wrong results, which is why it is
                              not the default) */
+    int ids_check_every;  /* packed ids: every n-th aggregation that reads a packed copy also compares a 64-bit hash of ALL of
+                             column_index and part_pointers (one read of both: ~0.1 ms per 114 M ids) with the hash taken when the
+                             copy was made; on a mismatch that call and every later one read column_index itself (the copy is
+                             marked on the device and never trusted again: gnna_forget_graph / gnna_prepare_graph make a new one).
+                             Closes what the 2 x 1,024 samples leave open -- a few ids rewritten in place -- within n calls.
+                             <= 0 = built-in (64: < 0.2 % of the aggregation time), 1 = every call (GNNA_DEBUG_FULL_CHECKSUM=1 sets it:
+                             the test suite), n > 1 = every n-th, >= 2^30 = never.  Not inside a stream capture (samples only there) */
     int wide_blocks;      /* wide rows in 64-float column blocks (one call per block, leading dimensions): 0 = automatic (rows of
                              >= 100 floats of long-row graphs, >= 192 otherwise, when every source row is gathered >= ~32 times
                              and the matrix is Infinity-Cache sized), 1 = whenever dim >= 72, 2 = never */
@@ -367,6 +389,10 @@ GNNA_API int gnna_release_graph(const int32_t *column_index);
  * the library next allocates a plan, and never while another thread's aggregation call is between looking a plan up
  * and enqueueing its kernels. */
 GNNA_API int gnna_forget_graph(const int32_t *column_index);
+/* gnna_forget_graph without touching what the CALLER registered for the graph: the plans and packed id copies go (deferred, as
+ * above), the hints (gnna_set_graph_hints) and measured schedules (gnna_set_graph_phases) stay.  For a layer that pinned plans
+ * on the caller's behalf and has to take them back -- the GNNAdvisor module's automatic lifecycle -- while the graph lives on. */
+GNNA_API int gnna_forget_plans(const int32_t *column_index);
 
 /* Events of the library's launch path since load (for tests and monitoring):
  *   [0] counting passes run, [1] stream / device synchronisations inside aggregation calls, [2] hipFree and
@@ -374,6 +400,9 @@ GNNA_API int gnna_forget_graph(const int32_t *column_index);
  *   never seen twice, [5] launches of the sweep kernel, [6] packed-id copies built, [7] aggregation launches that
  *   read packed ids. */
 GNNA_API void gnna_runtime_counters(int64_t out[8]);
+/* The same list, open-ended: fills out[0 .. min(capacity, count)) and returns the number of counters this library keeps.
+ *   [8] full hashes of the ids behind a packed copy run at a launch (gnna_tuning.ids_check_every). */
+GNNA_API int gnna_runtime_counters_ex(int64_t *out, int capacity);
 
 /* Number of column phases the calling thread's most recent aggregation call used (>= 1). */
 GNNA_API int gnna_last_num_phases(void);

@@ -209,12 +209,15 @@ def test_leading_dimensions_and_flags_random():
         _lib.reset_tuning()
 
 
-def test_module_repeated_calls_medium_graphs_random():
+def test_module_repeated_calls_medium_graphs_random(monkeypatch):
     """The reference caller's path on graphs large enough for the library's own schedule choices (sliced schedule, the sweep
     kernel, packed ids): GNNA.SAG / aggregate_gin three times on the same tensors -- the first call counts the partition, the
     second makes the module prepare the graph by itself, the third reads what was prepared -- every call against the fp64
     oracle, no knob forced.  Then the column ids are rewritten in place (version counter bumps): the module must forget the
-    plan and the next call must follow the new ids."""
+    plan and the next call must follow the new ids.  (GNNA_AUTO_PREPARE=2, the eager rule: a stream of fresh graphs like this
+    one is what the default rule takes for sampled training and does not prepare.)"""
+    if os.environ.get("GNNA_AUTO_PREPARE", "1") != "0":
+        monkeypatch.setenv("GNNA_AUTO_PREPARE", "2")
     GNNA = load_extension()
     rng = np.random.default_rng(SEED + 5)
     for k in range(max(3, CASES // 3)):

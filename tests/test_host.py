@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in gnna.h but not exported by libgnna.so"
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.gnna_version() == 500
+    assert lib.gnna_version() == 600
 
 
 def test_binaries_carry_the_hash_of_the_sources_beside_them():
@@ -33,8 +33,8 @@ def test_binaries_carry_the_hash_of_the_sources_beside_them():
     from gnnadvisor_osdi21_amd import build as gbuild
     want = gbuild.source_hash()
     assert re.fullmatch(r"[0-9a-f]{16}", want)
-    assert _lib.build_id() == "0.5.0+" + want
-    assert load_extension().build_id() == f"module {want}, library 0.5.0+{want}"
+    assert _lib.build_id() == "0.6.0+" + want
+    assert load_extension().build_id() == f"module {want}, library 0.6.0+{want}"
 
 
 def test_set_tuning_refuses_another_struct_layout():
@@ -137,7 +137,7 @@ def test_tuning_roundtrip():
         assert _lib.get_tuning() == dict(groups_per_chunk=8, loads_in_flight=4, blocks_per_cu=2,
                                          xcd_remap=0, trust_canonical=1, column_phases=0, avg_degree=0,
                                          nonlocal_ids=0, gcn_prescale=0, pad_rows=0, zero_fill=0,
-                                         sweep=0, sweep_slack=0, deterministic=0, pack_ids=0, wide_blocks=0)
+                                         sweep=0, sweep_slack=0, deterministic=0, pack_ids=0, ids_check_every=64, wide_blocks=0)
         _lib.set_tuning(column_phases=8)
         assert _lib.get_tuning()["column_phases"] == 8
         _lib.set_tuning(groups_per_chunk=32)      # others keep their values
@@ -241,3 +241,86 @@ def test_c_abi_example_compiles_and_links(tmp_path):
     subprocess.run([hipcc, "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "sag_c_abi.cpp"),
                     "-L", libdir, "-lgnna", "-Wl,-rpath," + libdir, "-o", exe], check=True, timeout=300)
     assert os.path.getsize(exe) > 0
+
+
+# ---- round 6: the mi355x policy fixes the reference's renumbering quirks, compat keeps them ------------------
+class _ReorderDS:
+    """A dataset double whose rabbit_reorder() 'rebuilds' CSR and degrees the way loader.custom_dataset does."""
+
+    def __init__(self, num_nodes, num_edges, span):
+        self.num_nodes, self.num_edges, self.num_features = num_nodes, num_edges, 64
+        self.avg_degree, self.avg_edgeSpan = num_edges / num_nodes, span
+        self.row_pointers, self.column_index, self.degrees = "rp-old", "ci-old", "deg-old"
+        self.reorder_flag, self.permute_node_data, self.reorder_calls, self.renumbered = False, False, 0, False
+
+    def rabbit_reorder(self):
+        self.reorder_calls += 1
+        if self.reorder_flag:
+            self.renumbered = True
+            self.row_pointers, self.column_index, self.degrees = "rp-new", "ci-new", "deg-new"
+            self.avg_edgeSpan_after = self.avg_edgeSpan / 10
+
+
+def _ip(ds, policy, manual, **kw):
+    ip = decider.inputProperty(ds.row_pointers, ds.column_index, ds.degrees, 32, 32, 4, 100, hiddenDim=64, dataset_obj=ds,
+                               enable_rabbit=True, manual_mode=manual, policy=policy)
+    for k, v in kw.items():
+        setattr(ip, k, v)
+    ip.decider()
+    return ip
+
+
+def test_mi355x_policy_adopts_the_renumbered_graph_and_compat_keeps_the_reference_quirks(monkeypatch):
+    monkeypatch.setenv("GNNA_HOST_THREADS", "16")           # the gate prices the renumbering for the host it runs on
+    big = dict(num_nodes=2449029, num_edges=123718280, span=2449029 / 3)
+    # manual mode: the reference adopts the CSR and keeps the OLD degrees (param.py:59-64, GNNA_main.py:70,75)
+    ds = _ReorderDS(**big); ip = _ip(ds, "compat", True)
+    assert (ip.row_pointers, ip.column_index, ip.degrees) == ("rp-new", "ci-new", "deg-old") and not ds.permute_node_data
+    ds = _ReorderDS(**big); ip = _ip(ds, "mi355x", True)
+    assert (ip.row_pointers, ip.column_index, ip.degrees) == ("rp-new", "ci-new", "deg-new") and ds.permute_node_data
+    assert ip.avgEdgeSpan == ds.avg_edgeSpan_after and ip.avgEdgeSpan_before == big["span"]
+    # auto mode: the reference renumbers and then runs on the ORIGINAL CSR (param.py:108-117)
+    ds = _ReorderDS(**big); ip = _ip(ds, "compat", False)
+    assert ds.renumbered and (ip.row_pointers, ip.column_index, ip.degrees) == ("rp-old", "ci-old", "deg-old")
+    # mi355x: a long run on an HBM-resident, scattered graph pays for the renumbering -> adopted, hints refreshed
+    ds = _ReorderDS(**big)
+    ip = _ip(ds, "mi355x", False, expected_aggregations=decider.expected_aggregations("gin", 100, 64, 47, 210))
+    gate = ip.renumbering_decision
+    assert gate["go"] and gate["saving_s"] > gate["reorder_s"] > 0 and gate["aggregations"] == 2100 - 210
+    assert ds.renumbered and ds.permute_node_data and ip.reorder_status
+    assert (ip.row_pointers, ip.column_index, ip.degrees) == ("rp-new", "ci-new", "deg-new") and ip.nonlocal_ids_hint == 0
+    # ... ten single aggregations do not -> the ids stay, nothing is renumbered, unless the caller insists
+    ds = _ReorderDS(**big); ip = _ip(ds, "mi355x", False, expected_aggregations=[(64, 10)])
+    assert not ip.renumbering_decision["go"] and not ds.renumbered and not ip.reorder_status and ip.row_pointers == "rp-old"
+    ds = _ReorderDS(**big); ip = _ip(ds, "mi355x", False, expected_aggregations=[(64, 10)], force_renumbering=True)
+    assert ds.renumbered and ip.row_pointers == "rp-new"
+    # a graph whose ids are local already fails the reference's own precondition (param.py:108): no gate, no renumbering
+    ds = _ReorderDS(num_nodes=1000000, num_edges=50000000, span=50.0); ip = _ip(ds, "mi355x", False)
+    assert ip.renumbering_decision is None and not ds.renumbered
+
+
+def test_renumbering_gate_numbers():
+    # Reddit-like (matrix fits the Infinity Cache): 0.12 ms saved per aggregation at D = 64 -- a 210-epoch 2-layer GCN does not
+    # win 2+ s of host time back; products-like (HBM resident): ~2 ms per aggregation -- it does
+    aggs = decider.expected_aggregations("gcn", 602, 64, 41, 210)
+    assert aggs == [(64, 420), (41, 420)]
+    small = decider.renumbering_gate(232965, 114615892, 232965 / 3, aggs, threads=16)
+    assert not small["go"] and 0.05e-3 < small["saving_per_aggregation_s"] < 0.3e-3
+    big = decider.renumbering_gate(2449029, 123718280, 2449029 / 3, decider.expected_aggregations("gin", 100, 64, 47, 210), threads=16)
+    assert big["go"] and 1e-3 < big["saving_per_aggregation_s"] < 4e-3 and big["reorder_s"] < 8
+    half = decider.renumbering_gate(2449029, 123718280, 2449029 / 6, [(64, 100)], threads=16)
+    assert abs(half["scatter"] - 0.5) < 1e-9
+    # GIN's first layer aggregates once per epoch at the narrower of (input, update-first output) widths
+    assert decider.expected_aggregations("gin", 602, 64, 41, 10)[0] == (64, 20)
+    assert decider.expected_aggregations("gin", 100, 64, 47, 10)[0] == (100, 10)
+
+
+def test_planner_inputs_come_from_the_library():
+    assert _lib.device_cus() == 0 or _lib.device_cus() >= 8          # no device here: 0, never an error
+    assert decider.num_cus() in (256, _lib.device_cus())
+    os.environ["GNNA_HOST_THREADS"] = "3"
+    try:
+        assert _lib.host_threads() == 3                                # read at every call
+    finally:
+        del os.environ["GNNA_HOST_THREADS"]
+    assert 1 <= _lib.host_threads() <= 64

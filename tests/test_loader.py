@@ -284,3 +284,72 @@ print("DIGEST", h.hexdigest())
         assert out.returncode == 0, out.stderr[-2000:]
         digests[threads] = [ln for ln in out.stdout.splitlines() if ln.startswith("DIGEST")][-1]
     assert len(set(digests.values())) == 1, digests
+
+
+# ---- round 6: renumbering from the CSR, native relabelling, node data that follows its node ----------------------
+def _scrambled_band(n=6000, seed=4):
+    rng = np.random.default_rng(seed)
+    u = np.arange(n).repeat(6)
+    v = (u + rng.integers(1, 30, u.size)) % n
+    perm = rng.permutation(n)
+    return perm[u], perm[v]
+
+
+def test_renumbering_from_the_csr_is_the_renumbering_from_the_edge_list():
+    """gnna_reorder_community_csr_i32: a symmetric CSR is used as the adjacency as it stands; a directed one takes the
+    edge-list path -- the permutation is gnna_reorder_community_i32's either way."""
+    n = 6000
+    su, sv = _scrambled_band(n)
+    for src, dst in ((np.concatenate([su, sv]), np.concatenate([sv, su])), (su, sv)):      # symmetric, directed
+        rp, ci = _lib.csr_from_edges(src, dst, n)
+        from_csr = _lib.reorder_community_csr(rp, ci, n).numpy()
+        from_edges = _lib.reorder_community(src, dst, n).numpy()
+        assert sorted(from_csr.tolist()) == list(range(n))
+        assert np.array_equal(from_csr, from_edges)
+    bad = ci.clone(); bad[1], bad[0] = ci[0], ci[1]                                        # a row that is not sorted
+    if rp[1] >= 2:
+        with pytest.raises(_lib.GnnaError, match="increasing"):
+            _lib.reorder_community_csr(rp, bad, n)
+
+
+def test_native_relabelling_is_the_rebuild_from_the_relabelled_edge_list():
+    n = 3000
+    src, dst = _edges(21, n, 40000)
+    rp, ci = _lib.csr_from_edges(src, dst, n)
+    new_id = torch.from_numpy(np.random.default_rng(3).permutation(n).astype(np.int32))
+    rp2, ci2 = _lib.relabel_csr(rp, ci, new_id, n)
+    s2, d2 = new_id.numpy()[src], new_id.numpy()[dst]
+    orp, oci = oracle.np_csr_from_edges(s2, d2, n)
+    assert np.array_equal(rp2.numpy(), orp) and np.array_equal(ci2.numpy(), oci)
+    es, ed = torch.from_numpy(src.astype(np.int32)), torch.from_numpy(dst.astype(np.int32))
+    span = _lib.relabel_edges_(es, ed, new_id, n)
+    assert np.array_equal(es.numpy(), s2) and np.array_equal(ed.numpy(), d2)
+    assert abs(span - np.mean(np.abs(s2.astype(np.int64) - d2))) < 1e-9
+    with pytest.raises(_lib.GnnaError, match="permutation"):
+        _lib.relabel_csr(rp, ci, torch.zeros(n, dtype=torch.int32), n)
+
+
+def test_node_data_follows_its_node_when_asked():
+    """permute_node_data (set by the mi355x Decider): x / y / masks move with the ids; the reference leaves them (dataset.py:138-172)."""
+    n = 2000
+    su, sv = _scrambled_band(n)
+    src, dst = np.concatenate([su, sv]), np.concatenate([sv, su])
+    for permute in (False, True):
+        ds = custom_dataset.from_edges(src, dst, n, 5, 3, device="cpu")
+        assert ds.edge_index.dtype == np.int32 and len(ds.val) == len(src)
+        x0, deg0 = ds.x.clone(), ds.degrees.clone()
+        ds.y = torch.arange(n)
+        ds.reorder_flag, ds.permute_node_data = True, permute
+        ds.rabbit_reorder()
+        new_id = torch.from_numpy(ds.new_id)
+        assert torch.equal(ds.degrees[new_id], deg0)                       # degrees are rebuilt either way (dataset.py:172)
+        if permute:
+            assert torch.equal(ds.x[new_id], x0) and torch.equal(ds.y[new_id], torch.arange(n))
+        else:
+            assert torch.equal(ds.x, x0) and torch.equal(ds.y, torch.arange(n))
+        assert ds.avg_edgeSpan_after < 0.2 * ds.avg_edgeSpan and ds.reorder_seconds > 0
+
+
+def test_loader_refuses_ids_the_int32_csr_cannot_hold():
+    with pytest.raises(ValueError, match="num_nodes"):
+        custom_dataset.from_edges(np.array([0, 9]), np.array([1, 2]), 5, 4, 2, device="cpu")

@@ -388,14 +388,21 @@ def test_reference_module_names_resolve_to_this_package():
         importlib.invalidate_caches()
 
 
-def test_module_prepares_a_graph_by_itself_on_its_second_sighting():
-    """Callers of the six reference functions have no lifecycle call to make (GNNAdvisor.cpp:253-263), so the module keeps
-    track itself (gnna_torch.cpp: note_graph): the same (column_index, part_pointers, part2Node) tensors -- same storages,
-    data pointers, sizes and torch VERSION COUNTERS -- seen a second time are prepared (packed ids); an in-place write
-    through torch bumps the version, the plan is forgotten and the next calls see the new contents."""
+def _eager_auto_prepare(monkeypatch):
+    """GNNA_AUTO_PREPARE=2: prepare at the SECOND sighting whatever the size and whatever else passes through -- the bookkeeping
+    tests below create graph after graph, which the default rule (rightly) takes for sampled training and leaves alone."""
     import os
     if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
         pytest.skip("automatic preparation is switched off / the schedule is forced")
+    monkeypatch.setenv("GNNA_AUTO_PREPARE", "2")
+
+
+def test_module_prepares_a_graph_by_itself_on_its_second_sighting(monkeypatch):
+    """Callers of the six reference functions have no lifecycle call to make (GNNAdvisor.cpp:253-263), so the module keeps
+    track itself (gnna_torch.cpp: note_graph): the same (column_index, part_pointers, part2Node) tensors -- same storages,
+    data pointers, sizes and torch VERSION COUNTERS -- seen again are prepared (packed ids); an in-place write
+    through torch bumps the version, the plan is forgotten and the next calls see the new contents."""
+    _eager_auto_prepare(monkeypatch)
     GNNA = load_extension()
     g = graph.powerlaw_graph(40000, 6000000, 4000, seed=23, device="cuda")
     ps, D = 64, 64
@@ -441,14 +448,13 @@ def test_module_prepares_a_graph_by_itself_on_its_second_sighting():
     assert GNNA.auto_prepared_graphs() == before + 3                      # (the graph itself is already known: third sighting)
 
 
-def test_a_new_graph_at_a_reused_address_is_a_new_graph():
+def test_a_new_graph_at_a_reused_address_is_a_new_graph(monkeypatch):
     """The caching allocator hands a freed graph's addresses to the next tensors of the same size.  The module's memory of a
     graph hangs on the STORAGES (weak references): when they are gone the entry -- and the library's pinned plan with its
     packed copy of the OLD ids -- is dropped, and the newcomer starts at its first sighting; results follow the new ids."""
     import gc
     import os
-    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
-        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    _eager_auto_prepare(monkeypatch)
     GNNA = load_extension()
     ps, D, n, e = 64, 64, 40000, 6000000
     X = torch.randn(n, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
@@ -471,14 +477,13 @@ def test_a_new_graph_at_a_reused_address_is_a_new_graph():
     print("column_index addresses:", [hex(p) for p in seen_ptrs])
 
 
-def test_second_sighting_inside_a_stream_capture_is_deferred():
+def test_second_sighting_inside_a_stream_capture_is_deferred(monkeypatch):
     """The module must neither synchronise nor allocate while a stream is being captured: a graph whose SECOND sighting
     happens inside a capture is not prepared there (gnna_prepare_graph refuses, the module carries on), the captured call
     runs on the plan the first, eager call built, and the next eager call prepares; a replay of the captured graph stays
     correct before and after that."""
     import os
-    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
-        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    _eager_auto_prepare(monkeypatch)
     GNNA = load_extension()
     g = graph.powerlaw_graph(40000, 6000000, 4000, seed=29, device="cuda")
     ps, D = 64, 64
@@ -512,12 +517,11 @@ def test_second_sighting_inside_a_stream_capture_is_deferred():
     assert close(yc)
 
 
-def test_two_partitions_over_one_column_index_do_not_evict_each_other():
+def test_two_partitions_over_one_column_index_do_not_evict_each_other(monkeypatch):
     """A graph aggregated with two neighbor-group sizes in turn (two `build_part` results over the same column_index): each
     partition is its own entry of the module's memory, each is prepared at ITS second sighting, neither forgets the other."""
     import os
-    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
-        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    _eager_auto_prepare(monkeypatch)
     GNNA = load_extension()
     g = graph.powerlaw_graph(40000, 6000000, 4000, seed=37, device="cuda")
     rp, ci, deg = g.row_pointers, g.column_index, g.degrees
@@ -542,14 +546,13 @@ def test_two_partitions_over_one_column_index_do_not_evict_each_other():
 
 
 @pytest.mark.gpu
-def test_dropping_one_partition_lets_the_other_prepare_again():
+def test_dropping_one_partition_lets_the_other_prepare_again(monkeypatch):
     """gnna_forget_graph() is keyed by column_index: when the tensors of one partition are freed, the module forgets the
     plans of EVERY partition over that array -- the surviving partition's entry must notice and prepare again at its next
     call, not go on believing its plan is pinned (results are the same either way; this pins the bookkeeping)."""
     import gc
     import os
-    if os.environ.get("GNNA_AUTO_PREPARE", "1") == "0" or os.environ.get("GNNA_TUNE"):
-        pytest.skip("automatic preparation is switched off / the schedule is forced")
+    _eager_auto_prepare(monkeypatch)
     GNNA = load_extension()
     g = graph.powerlaw_graph(30000, 4000000, 3000, seed=41, device="cuda")
     rp, ci, deg = g.row_pointers, g.column_index, g.degrees
@@ -572,3 +575,142 @@ def test_dropping_one_partition_lets_the_other_prepare_again():
     y = GNNA.SAG(X, rp, ci, deg, pp_a, p2n_a, 32, 32, 4)
     assert GNNA.auto_prepared_graphs() == mid + 1
     assert float(((y - ref).abs() / ref.abs().clamp_min(1.0)).max()) <= 1e-4
+
+
+
+def _want_rows(X, rp, ci, rows):
+    return torch.stack([X[ci[int(rp[i]):int(rp[i + 1])].long()].double().sum(0) for i in rows])
+
+
+def _rows_close(y, want, rows):
+    return float(((y[rows].double() - want).abs() / want.abs().clamp_min(1.0)).max()) <= 1e-4
+
+
+def test_default_rule_prepares_a_standing_graph_and_leaves_a_stream_of_graphs_alone():
+    """the module used to prepare ANY graph at its second sighting -- in sampled / mini-batch training every step's
+    fresh subgraph (seen again by the second layer and by backward) paid a stream synchronisation, a counting pass and a
+    hipMalloc for a packed copy that died with the step.  Default rule now: third sighting, >= 2^18 edges, and no other
+    graph first seen within the last 32 calls."""
+    import gc
+    import os
+    if os.environ.get("GNNA_AUTO_PREPARE", "1") != "1" or os.environ.get("GNNA_TUNE"):
+        pytest.skip("the default rule is not in force")
+    GNNA = load_extension()
+    ps, D = 64, 64
+    # (1) mini-batch pattern: fresh graph tensors every step, four aggregations each -> nothing is pinned, nothing packed
+    # (only the very first graph of the process can look like a standing one: nothing else has been seen yet)
+    before = c0 = None
+    for step in range(6):
+        g = graph.powerlaw_graph(30000, 3000000, 3000, seed=100 + step, device="cuda")
+        pp, p2n = [t.cuda() for t in GNNA.build_part(ps, g.row_pointers.cpu())]
+        X = torch.randn(g.num_nodes, D, device="cuda")
+        for _ in range(4):
+            y = GNNA.SAG(X, g.row_pointers, g.column_index, g.degrees, pp, p2n, ps, 32, 4)
+        rows = [0, 11, g.num_nodes - 1]
+        assert _rows_close(y, _want_rows(X, g.row_pointers, g.column_index, rows), rows)
+        del g, pp, p2n, X, y
+        gc.collect()
+        if step == 0:
+            before, c0 = GNNA.auto_prepared_graphs(), _lib.runtime_counters()
+    c1 = _lib.runtime_counters()
+    assert GNNA.auto_prepared_graphs() == before and c1["pack_builds"] == c0["pack_builds"]
+    # (2) a small graph is never worth it
+    g = graph.powerlaw_graph(2000, 50000, 200, seed=3, device="cuda")
+    pp, p2n = [t.cuda() for t in GNNA.build_part(ps, g.row_pointers.cpu())]
+    X = torch.randn(g.num_nodes, D, device="cuda")
+    for _ in range(5):
+        GNNA.SAG(X, g.row_pointers, g.column_index, g.degrees, pp, p2n, ps, 32, 4)
+    assert GNNA.auto_prepared_graphs() == before
+    # (3) once the stream of graphs has passed (32 calls of quiet), a standing graph is prepared at its third sighting
+    for _ in range(32):
+        GNNA.SAG(X, g.row_pointers, g.column_index, g.degrees, pp, p2n, ps, 32, 4)
+    big = graph.powerlaw_graph(40000, 6000000, 4000, seed=51, device="cuda")
+    ppb, p2nb = [t.cuda() for t in GNNA.build_part(ps, big.row_pointers.cpu())]
+    Xb = torch.randn(big.num_nodes, D, device="cuda")
+    rows = [0, 17, 12345, big.num_nodes - 1]
+    want = _want_rows(Xb, big.row_pointers, big.column_index, rows)
+    for call in range(4):
+        y = GNNA.SAG(Xb, big.row_pointers, big.column_index, big.degrees, ppb, p2nb, ps, 32, 4)
+        assert _rows_close(y, want, rows)
+        assert GNNA.auto_prepared_graphs() == before + (1 if call >= 2 else 0), call
+
+
+def test_ids_edited_behind_torchs_back_are_noticed(monkeypatch):
+    """VERDICT r5 task 4: `column_index.data[k] = v` does not bump the version counter and three edited ids among six million
+    slip through the 2 x 1,024 samples -- the packed copy went on serving the OLD ids.  Now a 64-bit hash of ALL ids is compared
+    at every ids_check_every-th call that reads a packed copy (64 by default; 1 here, as GNNA_DEBUG_FULL_CHECKSUM=1 sets it):
+    the first such call and every later one read column_index itself.  GNNA.forget_graph() is the explicit way."""
+    import os
+    if os.environ.get("GNNA_TUNE"):
+        pytest.skip("the schedule is forced")
+    _eager_auto_prepare(monkeypatch)
+    GNNA = load_extension()
+    ps, D = 64, 64
+    g = graph.powerlaw_graph(40000, 6000000, 4000, seed=61, device="cuda")
+    rp, ci, deg = g.row_pointers, g.column_index.clone(), g.degrees
+    pp, p2n = [t.cuda() for t in GNNA.build_part(ps, rp.cpu())]
+    X = torch.randn(g.num_nodes, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4))
+    edited = [5, 17, 12345]
+    rows = edited + [0, g.num_nodes - 1]
+    call = lambda: GNNA.SAG(X, rp, ci, deg, pp, p2n, ps, 32, 4)
+    try:
+        for every, calls_until_noticed in ((1, 1), (4, 4)):
+            _lib.reset_tuning()
+            _lib.set_tuning(ids_check_every=every)
+            before = GNNA.auto_prepared_graphs()
+            packed0 = _lib.runtime_counters()["packed_launches"]
+            for _ in range(3):
+                y = call()
+            assert GNNA.auto_prepared_graphs() == before + 1
+            if _lib.runtime_counters()["packed_launches"] == packed0:
+                pytest.skip("this graph is not aggregated from packed ids on this build's schedule")
+            assert _rows_close(y, _want_rows(X, rp, ci, rows), rows)
+            # three ids rewritten through .data: no version bump, (almost surely) none of the 1,024 samples
+            v0 = ci._version
+            for r in edited:
+                b = int(rp[r])
+                ci.data[b] = (int(ci[b]) + 7) % g.num_nodes
+            assert ci._version == v0
+            want = _want_rows(X, rp, ci, rows)
+            hashes0 = _lib.runtime_counters()["full_hashes"]
+            ys = [call() for _ in range(calls_until_noticed + 2)]
+            assert _lib.runtime_counters()["full_hashes"] > hashes0
+            # from the first call that ran the full hash on: the edited graph's result, for good (the copy is never trusted again)
+            for y in ys[calls_until_noticed - 1:]:
+                assert _rows_close(y, want, rows), every
+            if every == 1:
+                assert _rows_close(ys[0], want, rows)
+            # GNNA.forget_graph: the module and the library start over -> a fresh packed copy of the NEW ids
+            GNNA.forget_graph(ci)
+            before = GNNA.auto_prepared_graphs()
+            for _ in range(3):
+                y = call()
+            assert GNNA.auto_prepared_graphs() == before + 1 and _rows_close(y, want, rows)
+            GNNA.forget_graph(ci)
+    finally:
+        _lib.reset_tuning()
+
+
+def test_forgetting_plans_keeps_the_callers_hints():
+    """when the module takes back what it pinned (eviction, a new graph at an old address) the hints and measured
+    schedules the CALLER registered for a graph that is still alive stay (gnna_forget_plans); gnna_forget_graph drops both."""
+    g = graph.powerlaw_graph(30000, 4000000, 3000, seed=71, device="cuda")
+    ps, D = 64, 64
+    pp, p2n = [t.cuda() for t in _lib.build_part(ps, g.row_pointers.cpu())]
+    X = torch.randn(g.num_nodes, D, device="cuda")
+    ci = g.column_index
+    try:
+        _lib.set_graph_phases(ci, D, 4)
+        _lib.sag(X, g.row_pointers, ci, None, pp, p2n, ps, 32, 4)
+        assert _lib.last_num_phases() == 4
+        assert _lib.load().gnna_forget_plans(ci.data_ptr()) == 0
+        _lib.sag(X, g.row_pointers, ci, None, pp, p2n, ps, 32, 4)
+        assert _lib.last_num_phases() == 4                      # the measured schedule survived
+        assert _lib.load().gnna_forget_graph(ci.data_ptr()) == 0
+        _lib.sag(X, g.row_pointers, ci, None, pp, p2n, ps, 32, 4)
+        auto = _lib.last_num_phases()
+        _lib.set_graph_phases(ci, D, 3 if auto != 3 else 5)
+        _lib.sag(X, g.row_pointers, ci, None, pp, p2n, ps, 32, 4)
+        assert _lib.last_num_phases() == (3 if auto != 3 else 5)   # (the entry was really gone: a new one takes effect)
+    finally:
+        _lib.release_graph(ci)
