@@ -62,9 +62,19 @@ import sys
 import tempfile
 import time
 
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); before HIP starts
-os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: pinned OpenMP threads (before libgomp starts)
-os.environ.setdefault("OMP_PLACES", "cores")
+
+
+def process_env():
+    """Environment of a bench PROCESS, set by main() before torch / HIP / libgomp start -- not at import: tests/test_bench_cpu.py
+    imports this module, and OMP_PROC_BIND in the environment of the whole pytest process made libgomp bind ITS main thread to
+    one core (found in round 6: the GPU suite's host passes -- renumbering, CSR builders -- ran all their threads on one core)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes); before HIP starts
+    os.environ.setdefault("OMP_PROC_BIND", "close")            # cpu_baseline: pinned OpenMP threads (before libgomp starts)
+    os.environ.setdefault("OMP_PLACES", "cores")
+    if _QUOTA and _QUOTA < (os.cpu_count() or 1):
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, int(_QUOTA))))   # as many threads as the container is granted
+
+
 # With OMP_PROC_BIND set, libgomp binds the INITIAL thread to the first place (one core) as soon as it starts -- and every
 # std::thread the native host code spawns from it inherits that one-core mask: round 5's "24.3 s" renumbering inside this script
 # was 16 threads on one core (4.6 s with the mask restored).  The mask the process started with is kept here; `unbound()` puts it
@@ -114,8 +124,6 @@ def cpu_quota_cores():
 
 
 _QUOTA = cpu_quota_cores()
-if _QUOTA and _QUOTA < (os.cpu_count() or 1):
-    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, int(_QUOTA))))   # as many threads as the container is granted
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -1126,7 +1134,7 @@ def compact_sharded(rec, detail_file=None):
     line = _pick(rec, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                        "vs_baseline", "dtype", "data", "verified"))
     cfg = _pick(c, ("workload", "num_nodes_per_gpu", "nnz_per_gpu", "dim", "partSize", "num_parts_per_gpu", "source_nodes",
-                    "world_size", "backend", "communicator_ranks_counted", "parallelism", "exchange", "exchange_requested",
+                    "world_size", "backend", "rccl_world_size", "communicator_ranks_counted", "parallelism", "exchange", "exchange_requested",
                     "exchange_only_ms", "aggregate_only_ms", "exchange_GBs_per_rank", "bytes_received_per_rank_per_step",
                     "allgather_bytes_per_rank_per_step", "decider", "force_collectives", "build_id"))
     cfg["parallelism"] = str(cfg.get("parallelism", ""))[:120]
@@ -1710,6 +1718,7 @@ def run_sharded(args, result_fd, world, rank, local_rank):
 
 
 def main():
+    process_env()
     args = parse_args()
     if args.pmc_child:
         import torch  # noqa: F401

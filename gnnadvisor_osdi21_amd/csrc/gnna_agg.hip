@@ -320,6 +320,42 @@ int pick_row_stride(const gnna_tuning &t, int dim, bool hot_rows, int64_t num_in
 
 }  // namespace
 
+// The staged-copy decision of the aggregation for a caller outside this file (gnna_sddmm.hip): where should `dim`-float source
+// rows stored `ld_in` floats apart be gathered from when every row is gathered about est_edges / num_in_rows times -- from
+// `input` itself (*X = input, *ldx = ld_in) or from a copy in the stream's scratch (slot 1) with the row stride
+// pick_row_stride() names (rows of 17..64 floats that are re-read tens of times: every row on its own 256- / 512-byte
+// boundary; widths that straddle 128-byte lines: padded), made here by one pass of scale_rows_kernel.
+int stage_rows_for_gather(DeviceState *ds, hipStream_t stream, const gnna_tuning &tune, const float *input, int64_t ld_in,
+                          int64_t num_in_rows, int dim, int64_t est_edges, const float **X, int *ldx_out)
+{
+    *X = input; *ldx_out = (int)ld_in;
+    const bool hot_rows = est_edges >= 32 * num_in_rows && (size_t)num_in_rows * (size_t)dim * sizeof(float) <= ((size_t)1 << 30);
+    if (dim < 4 || !hot_rows) return GNNA_OK;
+    const int want = pick_row_stride(tune, dim, hot_rows, num_in_rows, true);
+    if (want == dim || ld_in == want) return GNNA_OK;
+    const bool aligned16 = (reinterpret_cast<uintptr_t>(input) & 15) == 0 && (ld_in & 3) == 0;
+    const int gapped = 2 * ((dim * 4 + 127) / 128) * 32;
+    bool direct;
+    if (want == gapped && dim > 16 && dim <= 64)
+        direct = (ld_in % gapped) == 0 && (reinterpret_cast<uintptr_t>(input) % ((size_t)gapped * 4)) == 0;
+    else
+        direct = aligned16 && avg_lines_per_row((int64_t)dim * 4, ld_in * 4) <= avg_lines_per_row((int64_t)dim * 4, (int64_t)want * 4) + 1e-9;
+    if (direct) return GNNA_OK;
+    const size_t x_bytes = (size_t)num_in_rows * (size_t)want * sizeof(float);
+    void *xs = nullptr;
+    int rc = get_workspace(ds, stream, 1, x_bytes, &xs);
+    if (rc != GNNA_OK) return rc;
+    const size_t s_bytes = (size_t)num_in_rows * (size_t)dim * sizeof(float);
+    int64_t sblocks = (int64_t)((s_bytes / 16 + kBlock - 1) / kBlock);
+    sblocks = std::max<int64_t>(1, std::min<int64_t>(sblocks, (int64_t)ds->num_cus * 8));
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)sblocks), dim3(kBlock), 0, stream, input, ld_in, (const float *)nullptr,
+                       static_cast<float *>(xs), num_in_rows, dim, want);
+    hipError_t es = hipGetLastError();
+    if (es != hipSuccess) return fail(GNNA_ERR_HIP, "staging launch: %s", hipGetErrorString(es));
+    *X = static_cast<const float *>(xs); *ldx_out = want;
+    return GNNA_OK;
+}
+
 // Share of the edges whose source lies within `half_rows` rows of the destination row (log-linear between the half-octave
 // thresholds of the counting pass' histogram).
 static double near_share(const SlicePlanStats &st, double half_rows)

@@ -128,16 +128,11 @@ static double cgroup2_quota(const std::string &dir)
     return quota;
 }
 
-// CPUs this process may use: the smaller of the CPUs it is allowed to run on (sched_getaffinity: cpusets, taskset) and the
-// tightest CPU quota on the way from its own cgroup (/proc/self/cgroup) up to the root -- the root alone is what a process
-// inside a cgroup namespace sees, the nested path what one outside of it does.  A quota below one CPU means one thread.
-static int granted_cpus()
+// CPUs the host passes may use: the smaller of the CPUs the calling thread is allowed to run on (sched_getaffinity: cpusets,
+// taskset) and the tightest CPU quota on the way from the process's own cgroup (/proc/self/cgroup) up to the root -- the root alone
+// is what a process inside a cgroup namespace sees, the nested path what one outside of it does.  A quota below one CPU means one thread.
+static int cgroup_cpu_quota()      // tightest CPU quota on the way up from this process's cgroup, rounded down (>= 1); 0 = none
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    int n = (int)(hw ? hw : 1u);
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
     double quota = 0.0;
     auto tighten = [&](double q) { if (q > 0 && (quota == 0.0 || q < quota)) quota = q; };
     std::string own;                                                           // cgroup v2 line: "0::/path"
@@ -160,14 +155,20 @@ static int granted_cpus()
         }
         if (q > 0 && period > 0) tighten(q / period);
     }
-    if (quota > 0.0) n = std::min(n, std::max(1, (int)quota));
-    return std::max(1, n);
+    return quota > 0.0 ? std::max(1, (int)quota) : 0;
 }
 
 int host_thread_budget(int cap)
 {
-    static const int granted = granted_cpus();
-    int n = granted;
+    static const int quota = cgroup_cpu_quota();
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = (int)(hw ? hw : 1u);
+    // the CALLING thread's affinity, at every call: the threads spawned below inherit it (a process started under taskset; a
+    // main thread an OpenMP runtime bound to one core -- sixteen workers there are slower than two)
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+    if (quota > 0) n = std::min(n, quota);
     if (const char *e = std::getenv("GNNA_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n = v; }   // read every time
     return std::max(1, std::min(n, cap));
 }

@@ -120,6 +120,9 @@ struct LaunchGuard {
     LaunchGuard &operator=(const LaunchGuard &) = delete;
 };
 // Number of phases of the sliced schedule from the statistics of the partition (gnna_agg.hip).
+// Where to gather `dim`-float source rows from: the caller's layout or a staged copy in the stream's scratch (gnna_agg.hip).
+int stage_rows_for_gather(DeviceState *ds, hipStream_t stream, const gnna_tuning &tune, const float *input, int64_t ld_in,
+                          int64_t num_in_rows, int dim, int64_t est_edges, const float **X, int *ldx_out);
 int choose_slices(const SlicePlanStats &st, size_t x_bytes, int S, uint32_t slice_rows, int64_t num_out_rows,
                   bool square, bool hinted_scattered);
 // Events on the launch path that the contract promises not to happen after gnna_prepare_graph (gnna_runtime_counters).

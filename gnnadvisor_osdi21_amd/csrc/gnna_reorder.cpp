@@ -23,12 +23,16 @@
 //
 // Threads: std::thread over contiguous node ranges; the result does not depend on the thread count.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -90,6 +94,63 @@ struct Lap {
     }
 };
 
+// How many ids of list[0 .. len) are marked in the bitmap -- counted up to `need` (the caller only asks "at least need?", so
+// any count >= need is as good as another).  Scalar: eight probes between two looks at the exit condition.  AVX-512 (where the
+// host has it, decided once at run time): sixteen ids per step -- one vector load, one gather of their bitmap words, a bit test
+// into a mask register, a popcount.  The backbone stage is this loop (4e10 probes on the Reddit-like graph: the end points of
+// an edge of a power-law graph have ~2,000 neighbours each); round 6 measured it compute-bound -- prefetching the lists ahead
+// changed nothing -- which is what makes the vector form pay.  Same decision either way (tests/test_loader.py compares them).
+inline int32_t count_marked_scalar(const int32_t *list, int64_t len, const uint64_t *mk, int32_t need)
+{
+    int32_t common = 0;
+    int64_t j = 0;
+    for (; j + 8 <= len && common < need; j += 8) {
+        int32_t c8 = 0;
+        for (int q = 0; q < 8; q++) {
+            const uint32_t x = (uint32_t)list[j + q];
+            c8 += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
+        }
+        common += c8;
+    }
+    for (; j < len && common < need; j++) {
+        const uint32_t x = (uint32_t)list[j];
+        common += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
+    }
+    return common;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx512f"))) int32_t count_marked_avx512(const int32_t *list, int64_t len, const uint64_t *mk, int32_t need)
+{
+    const int *mk32 = reinterpret_cast<const int *>(mk);       // (little endian: bit x of the 64-bit words is bit x & 31 of 32-bit word x >> 5)
+    const __m512i one = _mm512_set1_epi32(1), low5 = _mm512_set1_epi32(31);
+    int32_t common = 0;
+    int64_t j = 0;
+    for (; j + 16 <= len && common < need; j += 16) {
+        const __m512i ids = _mm512_loadu_si512(reinterpret_cast<const void *>(list + j));
+        const __m512i words = _mm512_i32gather_epi32(_mm512_srli_epi32(ids, 5), mk32, 4);
+        const __mmask16 hit = _mm512_test_epi32_mask(words, _mm512_sllv_epi32(one, _mm512_and_si512(ids, low5)));
+        common += __builtin_popcount((unsigned)hit);
+    }
+    for (; j < len && common < need; j++) {
+        const uint32_t x = (uint32_t)list[j];
+        common += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
+    }
+    return common;
+}
+#endif
+
+typedef int32_t (*CountMarkedFn)(const int32_t *, int64_t, const uint64_t *, int32_t);
+CountMarkedFn pick_count_marked()
+{
+    const char *e = std::getenv("GNNA_REORDER_SIMD");            // 0: the scalar loop whatever the host has
+    if (e && std::atoi(e) == 0) return count_marked_scalar;
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx512f")) return count_marked_avx512;
+#endif
+    return count_marked_scalar;
+}
+
 // Steps 1-3 of the header comment on the adjacency (rp, ci) of n nodes -> new_id[old id].
 int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdList ci, int32_t *new_id, const int threads,
                     const bool debug, Lap &lap)
@@ -118,42 +179,27 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
         // symmetric -- at a fraction of the time on graphs with rows of hundreds of edges (round 5: the merge made the
         // Reddit-like graph's renumbering the longest leg of bench.py; scanning the shorter list of a pair instead of the
         // list of the higher id halves what is left: a pair that is NOT kept costs min(du, dv) instead of dv).
-        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
-            std::vector<uint64_t> mark((size_t)((n + 63) / 64), 0);
+        // (nodes are handed out in blocks of 512 from a shared counter: the work of a node is the sum over its neighbours of the
+        // shorter list of the pair -- far from uniform along the id range of a locality-ordered or degree-sorted graph; the flags
+        // written do not depend on who counts a pair)
+        const CountMarkedFn count_marked = pick_count_marked();
+        std::atomic<int64_t> next_block{0};
+        constexpr int64_t kNodeBlock = 512;
+        parallel_nodes(n, threads, [&](int64_t, int64_t) {
+            std::vector<uint64_t> mark((size_t)((n + 63) / 64) + 1, 0);
+            for (;;) {
+            const int64_t lo = next_block.fetch_add(kNodeBlock), hi = std::min(n, lo + kNodeBlock);
+            if (lo >= n) break;
             for (int64_t u = lo; u < hi; u++) {
                 const int64_t ub = rp[(size_t)u], ue = rp[(size_t)u + 1];
                 if (ue - ub > hub) continue;
                 for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] |= 1ull << (ci[(size_t)k] & 63);
                 for (int64_t k = ub; k < ue; k++) {
-                    // the lists scanned below start anywhere in a 0.4 GB array: ask for the row pointer of the neighbour eight
-                    // ahead and the first lines of the list of the neighbour four ahead while this one is scanned (round 6: the
-                    // scan was waiting for memory, not probing -- 2.1 s -> see profiles/r6/reorder_stages.log)
-                    if (k + 8 < ue) __builtin_prefetch(&rp[(size_t)ci[(size_t)(k + 8)]]);
-                    if (k + 4 < ue) {
-                        const int32_t *nl = ci.data() + rp[(size_t)ci[(size_t)(k + 4)]];
-                        __builtin_prefetch(nl); __builtin_prefetch(nl + 16); __builtin_prefetch(nl + 32); __builtin_prefetch(nl + 48);
-                    }
                     const int32_t v = ci[(size_t)k];
                     const int64_t vb = rp[(size_t)v], ve = rp[(size_t)v + 1];
                     if (ve - vb > ue - ub || (ve - vb == ue - ub && v >= u)) continue;     // (the pair is v's to count)
                     const int32_t need = std::max<int32_t>(T, (int32_t)std::ceil(3.0 * chance * (double)(ue - ub) * (double)(ve - vb)));
-                    int32_t common = 0;
-                    // (eight probes between two looks at the exit condition: the decision -- common >= need -- is the same)
-                    int64_t j = vb;
-                    const int32_t *cj = ci.data();
-                    const uint64_t *mk = mark.data();
-                    for (; j + 8 <= ve && common < need; j += 8) {
-                        int32_t c8 = 0;
-                        for (int q = 0; q < 8; q++) {
-                            const uint32_t x = (uint32_t)cj[j + q];
-                            c8 += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
-                        }
-                        common += c8;
-                    }
-                    for (; j < ve && common < need; j++) {
-                        const uint32_t x = (uint32_t)cj[j];
-                        common += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
-                    }
+                    const int32_t common = count_marked(ci.data() + vb, ve - vb, mark.data(), need);
                     if (common >= need) {
                         keep[(size_t)k] = 1;
                         const int32_t *vl = ci.data() + vb, *vend = ci.data() + ve;
@@ -163,12 +209,16 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
                 }
                 for (int64_t k = ub; k < ue; k++) mark[(size_t)ci[(size_t)k] >> 6] = 0;
             }
+            }
         });
-        for (int64_t u = 0; u < n; u++) {
-            int64_t c = 0;
-            for (int64_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++) c += keep[(size_t)k];
-            brp[(size_t)u + 1] = brp[(size_t)u] + c;
-        }
+        parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
+            for (int64_t u = lo; u < hi; u++) {
+                int64_t c = 0;
+                for (int64_t k = rp[(size_t)u]; k < rp[(size_t)u + 1]; k++) c += keep[(size_t)k];
+                brp[(size_t)u + 1] = c;
+            }
+        });
+        for (int64_t u = 0; u < n; u++) brp[(size_t)u + 1] += brp[(size_t)u];
         bci.resize((size_t)brp[(size_t)n]);
         parallel_nodes(n, threads, [&](int64_t lo, int64_t hi) {
             for (int64_t u = lo; u < hi; u++) {

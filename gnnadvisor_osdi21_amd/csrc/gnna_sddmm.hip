@@ -21,12 +21,15 @@
 namespace gnna {
 namespace {
 
+#ifndef GNNA_SDDMM_FINER
+#define GNNA_SDDMM_FINER 1
+#endif
+
 int launch_sddmm(const float *dst_feat, int64_t ld_dst, const float *src_feat, int64_t ld_src, const int32_t *column_index,
                  const int32_t *part_pointers, const int32_t *part2Node, float *edge_out,
                  int64_t num_out_rows, int64_t num_in_rows, int dim, int64_t num_parts, int partSize,
                  void *stream_v)
 {
-    (void)partSize;
     if (num_out_rows < 0 || num_in_rows < 0 || dim < 0 || num_parts < 0)
         return fail(GNNA_ERR_INVALID_ARGUMENT, "negative size");
     if (num_out_rows >= ((int64_t)1 << 29))   // (a destination row travels with two flag bits in one 32-bit register)
@@ -47,6 +50,15 @@ int launch_sddmm(const float *dst_feat, int64_t ld_dst, const float *src_feat, i
     gnna_get_tuning(&tune);
     apply_graph_hints(column_index, 0, &tune);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    // the gathered side from the layout the gather likes best (round 6: 1.73 -> 1.62 ms on the Reddit-like graph at D = 64,
+    // tools/ceiling/probe_sddmm_floor.py): the staged copy the aggregation makes for hot rows, unless the caller's ld_src is it
+    {
+        const int64_t est_edges = num_parts * (int64_t)(tune.avg_degree > 0 ? std::min(partSize, tune.avg_degree) : partSize / 2 + 1);
+        int ldx = (int)ld_src;
+        rc = stage_rows_for_gather(ds, stream, tune, src_feat, ld_src, num_in_rows, dim, est_edges, &src_feat, &ldx);
+        if (rc != GNNA_OK) return rc;
+        ld_src = ldx;
+    }
     const bool wide = (size_t)num_in_rows * (size_t)ld_src * sizeof(float) > 0xffffffffull;
     // what the gather can touch of src_feat (whole 128-byte lines of every row): the size the slicing decision goes by
     const size_t b_bytes = (size_t)num_in_rows * (size_t)std::min<int64_t>(ld_src, (dim * 4 + 127) / 128 * 32) * sizeof(float);
@@ -61,9 +73,14 @@ int launch_sddmm(const float *dst_feat, int64_t ld_dst, const float *src_feat, i
     } else if (tune.column_phases == 0 && num_parts >= 1024 && num_in_rows >= 64 && b_bytes >= ((size_t)6 << 20)) {
         rc = get_slice_plan(ds, stream, column_index, part_pointers, part2Node, num_parts, num_in_rows, true, false, &plan);
         if (rc != GNNA_OK) return rc;
-        if (plan.cnt && plan.stats.valid)
+        if (plan.cnt && plan.stats.valid) {
             B = choose_slices(plan.stats, b_bytes, plan.S, plan.slice_rows, num_out_rows, num_in_rows == num_out_rows,
                               tune.nonlocal_ids == 1);
+            // a (row, slice) piece costs the aggregation a flush of the row; here it costs one more fetch of the destination
+            // row's piece and nothing else (every edge is written once, by the phase that owns it) -- slices of half the size
+            // pay: Reddit-like D = 64, 8 -> 16 phases 1.62 -> 1.56 ms (tools/ceiling/probe_sddmm_floor.py, profiles/r6/)
+            if (B >= 2 && GNNA_SDDMM_FINER) B = std::min(plan.S, 2 * B);
+        }
     }
     cnt = plan.cnt;
     if (cnt) S = plan.S;

@@ -274,7 +274,10 @@ def test_default_flow_trains_on_the_renumbered_graph(capsys):
         out = capsys.readouterr().out
         times[rabbit] = float(re.search(r"Time \(ms\): (\d+\.\d{3})", out).group(1))
         if rabbit == "True":
-            assert "# renumbering gate:" in out and "-> renumber" in out and "# renumbered: avg edge span" in out
+            from gnnadvisor_osdi21_amd import _lib
+            gate_line = [l for l in out.splitlines() if l.startswith("# renumbering gate:")]
+            assert gate_line and "-> renumber" in gate_line[0], (gate_line, runs[rabbit]["inputInfo"].renumbering_decision, _lib.host_threads())
+            assert "# renumbered: avg edge span" in out
     a, b = runs["False"], runs["True"]
     ia, ib, da, db = a["inputInfo"], b["inputInfo"], a["dataset"], b["dataset"]
     # (b) the kernels of run B ran on the renumbered CSR: the profile holds it, its statistics and its degrees
@@ -305,3 +308,51 @@ def test_default_flow_trains_on_the_renumbered_graph(capsys):
     print(f"# GIN-5 epoch on products-like (hidden locality, scrambled): {times['False']:.2f} ms as loaded, {times['True']:.2f} ms renumbered; "
           f"renumbering took {db.reorder_seconds:.2f} s (gate predicted {gate['reorder_s']:.2f} s, saving {gate['saving_s']:.2f} s)")
     assert times["True"] < 0.85 * times["False"], times
+
+
+@pytest.mark.parametrize("name,dim,classes", [("cora-like", 1433, 7), ("citeseer-like", 3703, 6)])
+def test_configs_1_and_2_at_their_true_widths(capsys, name, dim, classes):
+    """BASELINE configs 1-2 through the driver at the datasets' own widths (GNNA_main.py:15-39: Cora F = 1433 / 7 classes,
+    Citeseer F = 3703 / 6 classes, hidden 16): the second layer aggregates at D = 7 / 6 -- the widths that are not a multiple of
+    four (SURVEY a-2) -- the loss falls, and every layer's output and weight gradient equals the dense fp64 autograd
+    formulation within 1e-4 x sum|terms| (the same expression evaluated on |X|, |W|)."""
+    import numpy as np
+    from util import assert_close_f64
+    from gnnadvisor_osdi21_amd import main as driver
+    argv = ["--synthetic", name, "--dim", str(dim), "--hidden", "16", "--classes", str(classes), "--model", "gcn",
+            "--manual_mode", "False", "--verbose_mode", "True"]
+    finals, run = [], {}
+    for epochs in (1, 60):
+        torch.manual_seed(11)
+        run = {}
+        assert driver.main(argv + ["--num_epoches", str(epochs)], capture=run) == 0
+        out = capsys.readouterr().out
+        assert re.search(r"Time \(ms\): (\d+\.\d{3})", out)
+        finals.append(float(re.search(r"# final loss: (-?\d+\.\d+|nan|inf)", out).group(1)))
+    assert np.isfinite(finals).all() and finals[1] < finals[0], finals
+    ds, info, model = run["dataset"], run["inputInfo"], run["model"]
+    assert ds.num_features == dim and ds.num_classes == classes and model.conv2.weights.shape == (16, classes)
+    n = ds.num_nodes
+    rp, ci = info.row_pointers.cpu(), info.column_index.cpu()
+    A = torch.zeros(n, n, dtype=torch.float64)
+    rows = torch.repeat_interleave(torch.arange(n), (rp[1:] - rp[:-1]).long())
+    A[rows, ci.long()] = 1.0
+    deg = info.degrees.double().cpu()
+    Ahat = A * torch.outer(deg, deg)                                   # the reference's coefficient is the PRODUCT (.cu:355,389)
+    for conv, width_in, x in ((model.conv1, dim, ds.x), (model.conv2, 16, torch.randn(n, 16, device="cuda"))):
+        layer_info = info.set_input() if conv is model.conv1 else info.set_hidden()
+        W = conv.weights.detach()
+        conv.weights.grad = None
+        xg = x.detach().clone().requires_grad_(True)
+        y = conv(xg, layer_info)
+        y.square().sum().backward()
+        res = {}
+        for tag, f in (("ref", lambda t: t), ("abs", torch.abs)):
+            Xr = f(x.detach().double().cpu()).clone().requires_grad_(True)
+            Wr = f(W.double().cpu()).clone().requires_grad_(True)
+            o = Ahat @ (Xr @ Wr)
+            o.square().sum().backward()
+            res[tag] = (o.detach().numpy(), Xr.grad.numpy(), Wr.grad.numpy())
+        for got, k, what in ((y, 0, "out"), (xg.grad, 1, "dX"), (conv.weights.grad, 2, "dW")):
+            assert_close_f64(got.detach().cpu().numpy(), res["ref"][k], what=f"{name} layer {width_in}->{W.shape[1]} {what}",
+                             scale=res["abs"][k])

@@ -258,3 +258,75 @@ int gather_ceiling_launch(const float *X, const int32_t *ids, int64_t n, int dim
 #undef GO
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// SDDMM floor (round 6): the same walk as gather_ceiling -- the ids phase-major, U row loads in flight -- but every gathered row
+// is multiplied with a destination row's piece held in REGISTERS for the whole segment (the best any schedule can do for the
+// destination side), reduced over the LPR lanes of its slot, and the 64 dot products of a tile leave as ONE coalesced 256-byte
+// store (edge_out in the order the ids are consumed: the best any schedule can do for the output).  What is left is the
+// gather stream + 4 bytes per edge: the floor of edge_out[e] = <A[row(e)], X[col(e)]> on these slices.
+template <int LPR, int U>
+__global__ void __launch_bounds__(256) sddmm_ceiling(const float *__restrict__ X, const int32_t *__restrict__ ids,
+                                                     int64_t n, int seg, const float *__restrict__ A, int64_t a_rows,
+                                                     float *__restrict__ edge_out)
+{
+    constexpr int RPI = 64 / LPR;
+    constexpr int LOADS = 64 / RPI;
+    static_assert(LOADS % U == 0, "");
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t base = wave * (int64_t)seg;
+    if (base + seg > n) return;
+    const int lslot = lane / LPR, c = lane % LPR;
+    const char *xb = reinterpret_cast<const char *>(X) + c * 16;
+    const uint32_t row_bytes = LPR * 16;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(A + (wave % a_rows) * (int64_t)(LPR * 4) + c * 4);
+    int idv = ids[base + lane];
+    for (int t = 0; t < seg; t += 64) {
+        const int idn = (t + 64 < seg) ? ids[base + t + 64 + lane] : 0;
+        float mine = 0.f;                      // lane l ends up with the dot product of the tile's id l
+        auto finish = [&](f32x4 v, int load) {
+            const f32x4 pr = v * a;
+            float d = (pr.x + pr.y) + (pr.z + pr.w);
+#pragma unroll
+            for (int w = LPR / 2; w > 0; w >>= 1) d += __shfl_xor(d, w);      // every lane of the slot holds the slot's dot
+            // id index of (load, slot) = load * RPI + slot: lane l wants load l / RPI, slot l % RPI
+            const float got = __shfl(d, (lane % RPI) * LPR);
+            if (lane / RPI == load) mine = got;
+        };
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t id = (uint32_t)__shfl(idv, u * RPI + lslot);
+            v[u] = *reinterpret_cast<const f32x4 *>(xb + id * row_bytes);
+        }
+#pragma unroll
+        for (int b = 1; b < LOADS / U; b++) {
+            uint32_t nn[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) nn[u] = (uint32_t)__shfl(idv, (b * U + u) * RPI + lslot) * row_bytes;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                finish(v[u], (b - 1) * U + u);
+                v[u] = *reinterpret_cast<const f32x4 *>(xb + nn[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) finish(v[u], (LOADS / U - 1) * U + u);
+        __builtin_nontemporal_store(mine, edge_out + base + t + lane);
+        idv = idn;
+    }
+}
+
+extern "C" __attribute__((visibility("default")))
+int sddmm_ceiling_launch(const float *X, const int32_t *ids, int64_t n, int dim, int seg, int U, const float *A, int64_t a_rows,
+                         float *edge_out)
+{
+    if (seg % 64 != 0 || seg <= 0 || dim != 64) return -1;
+    const int64_t waves = n / seg;
+    const unsigned grid = (unsigned)((waves + 3) / 4);
+    if (grid == 0) return 0;
+    if (U == 4) hipLaunchKernelGGL((sddmm_ceiling<16, 4>), dim3(grid), dim3(256), 0, 0, X, ids, n, seg, A, a_rows, edge_out);
+    else if (U == 8) hipLaunchKernelGGL((sddmm_ceiling<16, 8>), dim3(grid), dim3(256), 0, 0, X, ids, n, seg, A, a_rows, edge_out);
+    else return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
