@@ -1143,7 +1143,7 @@ def compact_sharded(rec, detail_file=None):
     if c.get("failed_legs"):
         cfg["failed_legs"] = {n: str(v)[:120] for n, v in c["failed_legs"].items()}
     if c.get("exchange_timed"):
-        cfg["exchange_timed"] = c["exchange_timed"]
+        cfg["exchange_timed"] = _pick(c["exchange_timed"], ("allgather_ms", "halo_ms", "chosen"))
     if c.get("single_gpu_line"):
         cfg["single_gpu_value"] = c["single_gpu_line"].get("value")
         cfg["sharded_over_single"] = c["single_gpu_line"].get("sharded_over_single")
@@ -1448,9 +1448,15 @@ def sharded_leg(args, dev, world, rank, name, rp, ci, bounds, D, feat, avg_span,
     if not args.manual:
         info.apply_tuning()
     ps = args.partSize if args.partSize > 0 else info.partSize
-    agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
-                            pipeline_chunks=args.pipeline_chunks, exchange=exchange,
-                            force_collectives=args.force_collectives)
+    if exchange == "auto" and world > 1:
+        # a wire to time: both forms are built and run three steps each, the faster is kept (dist.timed_aggregator)
+        from gnnadvisor_osdi21_amd.dist import timed_aggregator
+        agg = timed_aggregator(rp, ci, bounds, ps, dim=D, reps=3, device=dev, force_overlap=args.force_dist,
+                               pipeline_chunks=args.pipeline_chunks)
+    else:
+        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, force_overlap=args.force_dist,
+                                pipeline_chunks=args.pipeline_chunks, exchange=exchange,
+                                force_collectives=args.force_collectives)
     calibrated = agg.calibrate([D]) if not (args.manual or args.headline_only) else None
     nnz_local = agg.nnz_local
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -1532,6 +1538,7 @@ def sharded_leg(args, dev, world, rank, name, rp, ci, bounds, D, feat, avg_span,
         "num_nodes_per_gpu": n_local, "nnz_per_gpu": nnz_local, "partSize": ps, "num_parts_per_gpu": P,
         "source_nodes": n_global, "parallelism": f"dst-range shards x{world} + " + agg.describe_exchange(),
         "exchange": agg.exchange, "exchange_requested": exchange, "pieces": agg.chunks,
+        "exchange_timed": getattr(agg, "exchange_timed", None),
         "bytes_received_per_rank_per_step": float(stats[2]), "allgather_bytes_per_rank_per_step": float(stats[3]),
         "exchange_volume_vs_allgather": float(stats[2]) / float(stats[3]) if float(stats[3]) else None,
         "exchange_only_ms": float(stats[4]), "aggregate_only_ms": float(stats[5]),
@@ -1685,7 +1692,7 @@ def run_sharded(args, result_fd, world, rank, local_rank):
                        "force_collectives": bool(args.force_collectives),
                        "device": str(dev) + (" (shared by all ranks)" if args.share_gpu else ""),
                        "parallelism": weak["parallelism"], "exchange": weak["exchange"],
-                       "exchange_requested": args.exchange,
+                       "exchange_requested": args.exchange, "exchange_timed": weak.get("exchange_timed"),
                        "bytes_received_per_rank_per_step": weak["bytes_received_per_rank_per_step"],
                        "allgather_bytes_per_rank_per_step": weak["allgather_bytes_per_rank_per_step"],
                        "exchange_volume_vs_allgather": weak["exchange_volume_vs_allgather"],

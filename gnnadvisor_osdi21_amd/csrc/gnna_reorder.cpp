@@ -30,9 +30,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
-#if defined(__x86_64__)
-#include <immintrin.h>
-#endif
 #include <numeric>
 #include <thread>
 #include <utility>
@@ -95,12 +92,13 @@ struct Lap {
 };
 
 // How many ids of list[0 .. len) are marked in the bitmap -- counted up to `need` (the caller only asks "at least need?", so
-// any count >= need is as good as another).  Scalar: eight probes between two looks at the exit condition.  AVX-512 (where the
-// host has it, decided once at run time): sixteen ids per step -- one vector load, one gather of their bitmap words, a bit test
-// into a mask register, a popcount.  The backbone stage is this loop (4e10 probes on the Reddit-like graph: the end points of
-// an edge of a power-law graph have ~2,000 neighbours each); round 6 measured it compute-bound -- prefetching the lists ahead
-// changed nothing -- which is what makes the vector form pay.  Same decision either way (tests/test_loader.py compares them).
-inline int32_t count_marked_scalar(const int32_t *list, int64_t len, const uint64_t *mk, int32_t need)
+// any count >= need is as good as another): eight probes between two looks at the exit condition.  The backbone stage is this
+// loop (4e10 probes on the Reddit-like graph: the end points of an edge of a power-law graph have ~2,000 neighbours each).
+// Round 6 tried two things against it on the GPU box's EPYC 9575F, both recorded in profiles/r6/reorder_stages.md and neither
+// kept: prefetching the lists ahead (2.11 -> 2.29 s: the scan is not waiting for memory) and an AVX-512 form -- sixteen ids per
+// step through a gather of the bitmap words and a mask popcount -- (1.67 s against 1.53 s for this loop: Zen 5's gather is
+// no faster than sixteen scalar probes of an L1-resident bitmap).  What did pay: handing the nodes out in blocks (below).
+inline int32_t count_marked(const int32_t *list, int64_t len, const uint64_t *mk, int32_t need)
 {
     int32_t common = 0;
     int64_t j = 0;
@@ -117,38 +115,6 @@ inline int32_t count_marked_scalar(const int32_t *list, int64_t len, const uint6
         common += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
     }
     return common;
-}
-
-#if defined(__x86_64__)
-__attribute__((target("avx512f"))) int32_t count_marked_avx512(const int32_t *list, int64_t len, const uint64_t *mk, int32_t need)
-{
-    const int *mk32 = reinterpret_cast<const int *>(mk);       // (little endian: bit x of the 64-bit words is bit x & 31 of 32-bit word x >> 5)
-    const __m512i one = _mm512_set1_epi32(1), low5 = _mm512_set1_epi32(31);
-    int32_t common = 0;
-    int64_t j = 0;
-    for (; j + 16 <= len && common < need; j += 16) {
-        const __m512i ids = _mm512_loadu_si512(reinterpret_cast<const void *>(list + j));
-        const __m512i words = _mm512_i32gather_epi32(_mm512_srli_epi32(ids, 5), mk32, 4);
-        const __mmask16 hit = _mm512_test_epi32_mask(words, _mm512_sllv_epi32(one, _mm512_and_si512(ids, low5)));
-        common += __builtin_popcount((unsigned)hit);
-    }
-    for (; j < len && common < need; j++) {
-        const uint32_t x = (uint32_t)list[j];
-        common += (int32_t)((mk[x >> 6] >> (x & 63u)) & 1ull);
-    }
-    return common;
-}
-#endif
-
-typedef int32_t (*CountMarkedFn)(const int32_t *, int64_t, const uint64_t *, int32_t);
-CountMarkedFn pick_count_marked()
-{
-    const char *e = std::getenv("GNNA_REORDER_SIMD");            // 0: the scalar loop whatever the host has
-    if (e && std::atoi(e) == 0) return count_marked_scalar;
-#if defined(__x86_64__)
-    if (__builtin_cpu_supports("avx512f")) return count_marked_avx512;
-#endif
-    return count_marked_scalar;
 }
 
 // Steps 1-3 of the header comment on the adjacency (rp, ci) of n nodes -> new_id[old id].
@@ -181,8 +147,7 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
         // list of the higher id halves what is left: a pair that is NOT kept costs min(du, dv) instead of dv).
         // (nodes are handed out in blocks of 512 from a shared counter: the work of a node is the sum over its neighbours of the
         // shorter list of the pair -- far from uniform along the id range of a locality-ordered or degree-sorted graph; the flags
-        // written do not depend on who counts a pair)
-        const CountMarkedFn count_marked = pick_count_marked();
+        // written do not depend on who counts a pair; Reddit-like on 16 threads: 2.2 -> 1.55 s)
         std::atomic<int64_t> next_block{0};
         constexpr int64_t kNodeBlock = 512;
         parallel_nodes(n, threads, [&](int64_t, int64_t) {

@@ -162,10 +162,12 @@ def calibrate_phases(column_index, part_pointers, part2Node, num_out_rows, partS
 # rank shape 6.6), after renumbering 17.0 TB/s.
 RATE_SCATTERED_CACHED, RATE_LOCAL_CACHED = 21.6e12, 23.6e12
 RATE_SCATTERED_HBM, RATE_LOCAL_HBM = 7.7e12, 17.0e12
-# Host seconds of gnna_reorder_community_i32 + the CSR rebuild, per raw edge and per node, at `threads` host threads
-# (fit of the round-6 measurements, profiles/r6/reorder_stages.log; the serial share does not shrink with threads)
-REORDER_S_PER_EDGE_SERIAL, REORDER_S_PER_EDGE_PARALLEL = 0.6e-8, 24e-8
-REORDER_S_PER_NODE = 1.0e-7
+# Host seconds of the renumbering as loader.rabbit_reorder() runs it (gnna_reorder_community_csr_i32 + the relabelling of the
+# CSR and the edge list), per adjacency entry and per node, at `threads` host threads -- a fit of the round-6 measurements on the
+# GPU box's 16 granted CPUs (profiles/r6/reorder_stages.md: Reddit-like 1.09e8 entries / 0.23 M nodes 3.1 s, products-like
+# 1.19e8 / 2.45 M 4.3 s); the walks over the backbone are one thread's work and do not shrink with the thread count
+REORDER_S_PER_EDGE_SERIAL, REORDER_S_PER_EDGE_PARALLEL = 0.5e-8, 36e-8
+REORDER_S_PER_NODE = 3.9e-7
 REFERENCE_EPOCHS = 200 + 10          # GNNA_main.py:25 (--num_epoches) + the 10 dry runs (:188-189)
 
 

@@ -106,7 +106,13 @@ def main(argv=None):
         bounds = [i * n_local for i in range(world + 1)]
     avg_degree = ci.numel() / max(1, n_local)
     ps = args.partSize or choose_part_size(avg_degree, hidden)
-    agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, pipeline_chunks=args.pipeline_chunks, exchange=args.exchange)
+    if args.exchange == "auto" and world > 1:
+        from .dist import timed_aggregator                     # a wire to time: the faster of the two forms, measured
+        agg = timed_aggregator(rp, ci, bounds, ps, dim=hidden, reps=3, device=dev, pipeline_chunks=args.pipeline_chunks)
+        if verbose and rank == 0:
+            print("# exchange (timed): {}".format(agg.exchange_timed))
+    else:
+        agg = ShardedAggregator(rp, ci, bounds, ps, device=dev, pipeline_chunks=args.pipeline_chunks, exchange=args.exchange)
     # sqrt(max(deg, 1)) of the local rows (dataset.py:121-122; in-degree == out-degree on a symmetric graph)
     deg_local = (rp[1:] - rp[:-1]).clamp(min=1).to(torch.float32).sqrt()
     gen = torch.Generator(device=dev).manual_seed(100 + rank)

@@ -455,3 +455,78 @@ def _forced_worker(rank, world, port, chunks, exchange, q):
 def test_one_rank_with_forced_collectives_matches_the_whole_graph(chunks, exchange):
     res = _run_ranks(_forced_worker, (chunks, exchange), world=1)
     assert all(ok for _, ok, *_ in res), res
+
+
+# ---- round 6: exchange="auto" decided by measurement (dist.timed_aggregator) -----------------------------------------
+def _timed_worker(rank, world, port, slow_form, q):
+    """Both forms are built and timed; an injected aggregate_fn makes `slow_form` the slower one (it sleeps), whatever the
+    bytes say -- the faster form must be kept on BOTH ranks, and it must still give the whole-graph result."""
+    import time
+    from gnnadvisor_osdi21_amd.dist import timed_aggregator
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, e, dim = 400, 3000, 6
+        g = graph.powerlaw_graph(n, e, 60, seed=13, locality=0.9, window=6)       # id-local: the byte rule says "halo"
+        bounds = balanced_row_splits(g.row_pointers, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        state = {"form": None}
+
+        def build_part(ps, rp_):
+            return _oracle_build_part(ps, rp_)
+
+        def aggregate(mode, X_all, column_index, *a, **k):
+            # the halo form's remote part reads a buffer of halo_rows rows, the all-gather form's one of world * rows_per_rank
+            if state["form"] == slow_form and rank == 1:                          # ONE slow rank is enough: MAX over ranks counts
+                time.sleep(0.02)
+            return _oracle_aggregate(mode, X_all, column_index, *a, **k)
+        # (the factory builds the all-gather form first, then the halo form)
+        order = iter(("allgather", "halo"))
+        real_init = ShardedAggregator.__init__
+
+        def tracking_init(self, *a, **k):
+            state["form"] = k.get("exchange")
+            real_init(self, *a, **k)
+        ShardedAggregator.__init__ = tracking_init
+        try:
+            calls = {"allgather": 0, "halo": 0}
+
+            def counting(mode, X_all, column_index, *a, **k):
+                calls[state["form"]] += 1
+                return aggregate(mode, X_all, column_index, *a, **k)
+            agg = timed_aggregator(rp, ci, bounds, 4, dim=dim, reps=3, aggregate_fn=counting, build_part_fn=build_part)
+        finally:
+            ShardedAggregator.__init__ = real_init
+        rec = agg.exchange_timed
+        state["form"] = agg.exchange
+        X = torch.randn(n, dim, generator=torch.Generator().manual_seed(14))
+        Y = agg.sag(X[lo:hi].contiguous())
+        ok = np.allclose(Y.numpy(), oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())[lo:hi], atol=1e-4)
+        # the byte rule alone would have said halo on this graph
+        byte_rule = ShardedAggregator(rp, ci, bounds, 4, aggregate_fn=_oracle_aggregate, build_part_fn=_oracle_build_part,
+                                      exchange="auto").exchange
+        q.put((rank, bool(ok), agg.exchange, rec, byte_rule, calls["allgather"] > 0 and calls["halo"] > 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("slow_form", ["halo", "allgather"])
+def test_exchange_is_chosen_by_measurement_when_there_is_a_wire(slow_form):
+    res = _run_ranks(_timed_worker, (slow_form,))
+    fast = "allgather" if slow_form == "halo" else "halo"
+    for rank, ok, chosen, rec, byte_rule, both_ran in res:
+        assert ok and both_ran and chosen == fast == rec["chosen"], (rank, chosen, rec)
+        assert rec[slow_form + "_ms"] > rec[fast + "_ms"] and rec["reps"] == 3 and rec["dim"] == 6
+        assert byte_rule == "halo"                       # (what "auto" by bytes picks here, whichever form measured faster)
+    assert res[0][3] == res[1][3]                        # the same numbers on both ranks: the slowest rank's time
+
+
+def test_timed_choice_falls_back_to_the_byte_rule_without_a_wire():
+    from gnnadvisor_osdi21_amd.dist import timed_aggregator
+    g = graph.powerlaw_graph(200, 2000, 40, seed=5)
+    bounds = balanced_row_splits(g.row_pointers, 4)
+    rp, ci = shard_csr(g.row_pointers, g.column_index, bounds[1], bounds[2])
+    agg = timed_aggregator(rp, ci, bounds, 4, dim=8, aggregate_fn=_oracle_aggregate, build_part_fn=_oracle_build_part, emulate=(1, 4))
+    assert agg.exchange_timed is None and agg.exchange in ("allgather", "halo")

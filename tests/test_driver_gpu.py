@@ -256,7 +256,8 @@ def test_community_renumbering_speeds_up_the_aggregation():
 
 def test_default_flow_trains_on_the_renumbered_graph(capsys):
     """SURVEY 8 f-3 through the driver's DEFAULT flow (auto mode, mi355x policy, --enable_rabbit True): products-like with hidden
-    locality and scrambled ids, 5-layer GIN, the reference's 200 epochs.  The cost gate lets the renumbering run, the kernels
+    locality and scrambled ids, 5-layer GIN, 300 epochs (at the reference's 200 the predicted saving, 4.4 s, is within 5 % of
+    the renumbering's 4.2 host seconds: the gate's answer there depends on the box).  The cost gate lets the renumbering run, the kernels
     run on the renumbered CSR, every layer equals the un-renumbered run's under the permutation within 1e-4 x sum|terms|, and
     the epochs are faster than on the ids as they came."""
     if os.environ.get("GNNA_TUNE"):
@@ -265,7 +266,7 @@ def test_default_flow_trains_on_the_renumbered_graph(capsys):
     from gnnadvisor_osdi21_amd import main as driver
     GNNA = load_extension()
     argv = ["--synthetic", "products-like", "--locality", "0.9", "--scramble", "True", "--dim", "100", "--hidden", "64",
-            "--classes", "47", "--model", "gin", "--num_epoches", "200", "--manual_mode", "False", "--verbose_mode", "True"]
+            "--classes", "47", "--model", "gin", "--num_epoches", "300", "--manual_mode", "False", "--verbose_mode", "True"]
     runs, times = {}, {}
     for rabbit in ("False", "True"):
         torch.manual_seed(7)

@@ -353,19 +353,3 @@ def test_node_data_follows_its_node_when_asked():
 def test_loader_refuses_ids_the_int32_csr_cannot_hold():
     with pytest.raises(ValueError, match="num_nodes"):
         custom_dataset.from_edges(np.array([0, 9]), np.array([1, 2]), 5, 4, 2, device="cpu")
-
-
-def test_vector_and_scalar_backbone_probes_decide_alike():
-    """The backbone's bitmap probe loop has an AVX-512 form (sixteen ids per step) chosen at run time; GNNA_REORDER_SIMD=0 forces
-    the scalar loop.  Both count "at least `need` common neighbours?" -- the permutation must be the same (read at every call)."""
-    n = 20000
-    g = graph.community_graph(n, 1500000, 40, seed=12, scramble=True)
-    rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long()).numpy()
-    cols = g.column_index.numpy()
-    a = _lib.reorder_community(rows, cols, n).numpy()
-    os.environ["GNNA_REORDER_SIMD"] = "0"
-    try:
-        b = _lib.reorder_community(rows, cols, n).numpy()
-    finally:
-        del os.environ["GNNA_REORDER_SIMD"]
-    assert np.array_equal(a, b) and sorted(a.tolist()) == list(range(n))
