@@ -1076,7 +1076,7 @@ def _pick(src, keys):
 
 
 def compact_roofline(r):
-    """The roofline object of the line: numbers and short tokens only (definitions live in DESIGN.md 5)."""
+    """The roofline object of the line: numbers and short tokens only (definitions live in DESIGN.md 4)."""
     out = _pick(r, ("bound", "ceiling", "peak", "unit", "achieved", "frac"))
     label = str(r.get("kernel", ""))
     out["kernel"] = label.split(" (")[0] if label else None
@@ -1119,7 +1119,8 @@ def compact_single(rec, detail_file=None):
     cb = rec.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "ms", "ms_min", "ms_max"))
-        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        line["cpu_baseline"]["sample"] = "full graph, D=%s, median of %s passes of the OpenMP CSR SpMM in oracle/gnna_oracle.c, %s pinned threads" % (
+            c.get("dim"), len(cb.get("pass_ms_in_order") or []) or "all", cb.get("cores"))
         lib = cb.get("libraries") or {}
         for key, short in (("torch_sparse_csr", "torch_sparse_csr_value"), ("scipy_csr_1thread", "scipy_1thread_value")):
             if isinstance(lib.get(key), dict):

@@ -379,7 +379,7 @@ static double near_share(const SlicePlanStats &st, double half_rows)
 //    enough for the split that makes a slice fit the Infinity Cache (products-like, average degree 50, X = 627 MB: best
 //    4 phases; amazon0505-like, degree 12: none).
 // Phases for the sweep kernel when the library picks it by itself (gnna_tuning.sweep = 0), or 0: the streaming kernel
-// runs.  Measured (DESIGN 3.1b, round 3 end): with plain id loads and 8 row loads in flight the sweep beats the streaming
+// runs.  Measured (DESIGN.md 3, round 3 end): with plain id loads and 8 row loads in flight the sweep beats the streaming
 // kernel by 3-4 % where (a) a destination row is 33-64 floats -- narrower rows flush cheaply, wider ones halve the rows
 // the LDS accumulators hold --, (b) the rows are long (>= 300 edges on average) and few enough that a workgroup's share
 // fits the accumulators in at most two sets (Reddit-like: 233 K rows of 492 edges; products-like needs 21 sets and loses

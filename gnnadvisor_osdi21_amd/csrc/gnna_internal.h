@@ -43,6 +43,7 @@ struct DeviceState {
     unsigned long long *gap_lists = nullptr;   // kCallBlocks lists of kGapWords words (call_block_of)
     uint32_t *sweep_sync = nullptr;  // kCallBlocks counter blocks for the sweep kernel's soft barrier (call_block_of)
     std::map<hipStream_t, int> stream_block;   // streams that own one of the first kStreamBlocks call blocks
+    int captured_blocks = 0;                   // call blocks handed to captured calls so far (never returned)
     std::map<std::pair<hipStream_t, int>, Workspace> ws;  // per stream: slot 1 staged / pre-scaled X, slot 2 partial rows of the
                                                           // deterministic schedule / slabs of the weight-gradient kernel
 };
@@ -51,11 +52,16 @@ constexpr int kFlagSlots = 1024;
 constexpr int kGapEntries = 63, kGapWords = 2 + 2 * kGapEntries;   // word 0: count, pairs (first row, rows)
 // Per-call device scratch that is NOT tagged with the call's sequence number (the gap list of the sparse prologue, the sweep
 // kernel's step counters and ReLU list) lives in "call blocks".  Work on one stream is ordered, so a stream needs one block:
-// the first kStreamBlocks streams that call the library get a block of their own (no allocation), calls on any further stream
-// -- and calls that are being captured into a graph, which run in the order of their replays, not of the capture stream --
-// share a ring of kCallBlocks - kStreamBlocks blocks by sequence number.  (A ring alone, shared by all
-// streams, lets a call on one stream clear the block of a call 64 sequence numbers earlier that is still running on another.)
-constexpr int kStreamBlocks = 64, kCallBlocks = 128;
+//   * the first kStreamBlocks streams that call the library get a block of their own (no allocation);
+//   * a call that is being CAPTURED into a graph runs whenever and wherever its graph is replayed -- not in the order of the
+//     capture stream (torch.cuda.graph captures every graph on one shared side stream) and possibly next to a replay of another
+//     graph: each of the first kCapturedBlocks captured calls of a device gets a block of its own FOR GOOD (the graph may be
+//     replayed at any time; round 6, ADVICE r5 -- before, they shared the ring below by sequence number);
+//   * calls on further streams, and captured calls beyond those, share a ring of the remaining blocks by call count: graphs
+//     captured after the first kCapturedBlocks calls must not be replayed concurrently with each other (include/gnna.h).
+// (A ring alone, shared by all streams, lets a call on one stream clear the block of a call that is still running on another.)
+constexpr int kStreamBlocks = 64, kCapturedBlocks = 160, kCallBlocks = 256;
+static_assert(kCallBlocks <= kFlagSlots && kStreamBlocks + kCapturedBlocks < kCallBlocks, "call blocks");
 
 // State of the current device (lazily created: CU count, flag ring).
 int get_device_state(DeviceState **out);

@@ -86,17 +86,20 @@ int get_workspace(DeviceState *ds, hipStream_t stream, int slot, size_t bytes, v
     return GNNA_OK;
 }
 
-int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
+namespace {
+thread_local int32_t t_block_seq = 0;     // the calling thread's current call and the block it was given (a call asks several
+thread_local int t_block = 0;             // times: flags, gap list, sweep counters -- and must get the same answer)
+
+int pick_call_block(DeviceState *ds, hipStream_t stream, int32_t seq)
 {
-    // a call that is being CAPTURED will run wherever and whenever its graph is replayed -- not in the order of the capture
-    // stream (torch.cuda.graph captures every graph on one shared side stream and replays on the current one): such calls take
-    // their block from the shared ring by sequence number, as do the calls of streams beyond the first kStreamBlocks
     // (seq is odd and unique per call, next_call_seq: its upper bits count the calls, so the ring uses every block)
-    const int shared = kStreamBlocks + (int)(((uint32_t)seq >> 1) % (uint32_t)(kCallBlocks - kStreamBlocks));
+    const int ring0 = kStreamBlocks + kCapturedBlocks;
+    const int shared = ring0 + (int)(((uint32_t)seq >> 1) % (uint32_t)(kCallBlocks - ring0));
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess) (void)hipGetLastError();
-    if (cap != hipStreamCaptureStatusNone) return shared;
     std::lock_guard<std::mutex> lock(g_dev_mutex);
+    if (cap != hipStreamCaptureStatusNone)
+        return ds->captured_blocks < kCapturedBlocks ? kStreamBlocks + ds->captured_blocks++ : shared;
     auto it = ds->stream_block.find(stream);
     if (it != ds->stream_block.end()) return it->second;
     if ((int)ds->stream_block.size() < kStreamBlocks) {
@@ -105,6 +108,13 @@ int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
         return b;
     }
     return shared;
+}
+}  // namespace
+
+int call_block_of(DeviceState *ds, hipStream_t stream, int32_t seq)
+{
+    if (seq != t_block_seq) { t_block = pick_call_block(ds, stream, seq); t_block_seq = seq; }
+    return t_block;
 }
 
 int32_t next_call_seq(DeviceState *ds, hipStream_t stream, int32_t **flag_slot)

@@ -38,12 +38,12 @@
 // always in flight -> fold at the last load of a row piece.
 //
 // Selected by the library (gnna_tuning.sweep = 0) where it measures faster than stream_kernel -- rows of 33..64 floats,
-// long rows, a square Infinity-Cache-sized problem: sweep_auto_phases() in gnna_agg.hip, DESIGN.md 3.1b -- and by sweep = 1.
+// long rows, a square Infinity-Cache-sized problem: sweep_auto_phases() in gnna_agg.hip, DESIGN.md 3 -- and by sweep = 1.
 //
 // (A first version of this file gave every WAVEFRONT its own set and 5.5 KiB of accumulators, 20 wavefronts per
 // CU, barrier per wavefront: 2.25-2.5 ms on the Reddit-like headline without the barrier, 5-17 ms with it,
 // against 1.59 ms for stream_kernel -- too few loads in flight, static sets, and a barrier whose unit is one
-// latency chain.  DESIGN.md 3.1b.)
+// latency chain.  DESIGN.md 3.)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -34,7 +34,10 @@
  *     is being captured.  Library scratch is allocated on first use and never grown during capture
  *     (GNNA_ERR_UNSUPPORTED instead): warm a path up once before capturing it -- or call
  *     gnna_prepare_graph() once per graph: after it no aggregation on that graph synchronises,
- *     allocates or frees, and a captured call takes the same schedule as an eager one.
+ *     allocates or frees, and a captured call takes the same schedule as an eager one.  Captured calls keep a block of
+ *     per-call device scratch (step counters, lists) of their own for good, so graphs may be replayed concurrently; the
+ *     library holds 160 such blocks per device -- graphs whose calls were captured after those are used up share a ring and
+ *     must not be replayed concurrently with each other.
  *   - return value: GNNA_OK or a negative gnna_status; gnna_last_error() gives the
  *     message for the calling thread.  (The reference printf()s and exit(-1)s on launch
  *     failure, .cu:177-181; this library reports instead.)
@@ -137,7 +140,7 @@ GNNA_API int gnna_reorder_rcm_i32(const int32_t *src, const int32_t *dst, int64_
  * neighbours), a breadth-first order over it in which a node is discovered once several of its backbone neighbours
  * have been walked (unfolded when the walk runs on two fronts), then median sweeps -- the role of rabbit.reorder
  * (community-based Rabbit Order, rabbit_module/src/reorder.cpp:235-295) with a different, reproducible algorithm
- * (gnna_reorder.cpp, DESIGN.md 5.1).  Node ids are int32; the edge list may hold any number of entries (64-bit
+ * (gnna_reorder.cpp, DESIGN.md 5.2).  Node ids are int32; the edge list may hold any number of entries (64-bit
  * offsets inside: papers100M symmetrised has 3.2e9). */
 GNNA_API int gnna_reorder_community_i32(const int32_t *src, const int32_t *dst, int64_t num_edges,
                                int64_t num_nodes, int32_t *new_id /* [num_nodes] */);
@@ -303,7 +306,7 @@ typedef struct gnna_tuning {
                              a source row is gathered >= ~32 times; rows of 17..64 floats then start at
                              multiples of twice their 128-byte lines -- stride 64 / 128 / 128 floats for
                              32 / 41 / 64 -- while the copy stays Infinity-Cache sized: 2-6 % off the
-                             gather, DESIGN.md 3.1), > 2 = this stride in floats (experiments) */
+                             gather, DESIGN.md 2), > 2 = this stride in floats (experiments) */
     int zero_fill;        /* what the prologue clears before a single pass of the streaming kernel that overwrites
                              `out`: 1 = only the rows that pass does not store (rows without edges, rows shared by
                              two work items), 2 = the whole output, 0 = automatic (1 once `out` is >= 32 MiB).
@@ -314,7 +317,7 @@ typedef struct gnna_tuning {
                              rows of >= 4 floats <= 128 wide, source matrix <= 4 GiB), 2 = never, 0 = automatic: where it
                              measures faster than the streaming kernel -- rows of 33..64 floats, a sliced schedule over a
                              square, Infinity-Cache-sized problem, long rows (>= 300 edges on average) and few enough of
-                             them that a workgroup's share fits its LDS accumulators in two sets (DESIGN.md 3.1b).  While it is selected by 1 two other knobs are read in its terms:
+                             them that a workgroup's share fits its LDS accumulators in two sets (DESIGN.md 3).  While it is selected by 1 two other knobs are read in its terms:
                              blocks_per_cu = workgroups per CU (1: one 16-wavefront workgroup with all of the CU's LDS,
                              else two), groups_per_chunk > 64 = 64 x (sets per workgroup) instead of the automatic count */
     int sweep_slack;      /* sweep kernel: how many slice steps a wavefront may run ahead of the slowest wavefront of

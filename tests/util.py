@@ -66,7 +66,7 @@ def gcn_gin_reference(g, F, W1, W2, wgt, eps=0.5, H1_got=None, amb_tol=1e-5):
     happens to compute (which depends on the summation order, i.e. on the order float atomics land in) decides a whole
     column entry of dH1.  One such flip moves dF in every neighbour row of node i by far more than 1e-4 of the scale
     (a degree-10 node: 9 rows, up to 6e-3) while out / dW1 / dW2 stay inside the bound -- the "two-rank transient" of
-    rounds 3-4.  So for the elements that cancel to |H1_ref| <= amb_tol * (sum of |terms|) -- amb_tol =
+    rounds 3-4 (profiles/r5/DESIGN_as_of_round5.md 6).  So for the elements that cancel to |H1_ref| <= amb_tol * (sum of |terms|) -- amb_tol =
     1e-5: ~100 x the fp32 error these sums actually show (<= 1e-7 of the sum of |terms|), 10 x inside the 1e-4 bound H1
     itself is checked with -- the mask follows the sign the path under test computed; everywhere else it is the fp64
     sign.  "ambiguous" = how many elements that concerned (about one per 30,000), "min_ratio" = the smallest
