@@ -110,6 +110,9 @@ void drop_slice_plans();
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
                    const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum = nullptr,
                    int64_t *num_ids = nullptr, int32_t *stale_flag = nullptr, int32_t seq = 0, int check_every = 0);
+// One-wavefront comparison of the graph's samples with a packed copy's state words (for calls without a prologue).
+int launch_ids_sample_check(hipStream_t stream, const int32_t *col, int64_t n, const int32_t *pp, int64_t P,
+                            const unsigned long long *state, int32_t *stale_flag, int32_t seq);
 // Forgets the plans whose column_index starts at this address (all plans when null).  -> number of plans dropped.
 // deferred: the device buffers are not freed now (no synchronisation: safe from a finalizer on any thread, during a
 // stream capture) but at the next gnna_prepare_graph / gnna_release_graph / plan allocation with no launch in flight.

@@ -94,6 +94,23 @@ int launch_sddmm(const float *dst_feat, int64_t ld_dst, const float *src_feat, i
     a.flag = flag; a.trust = 1; a.P = num_parts; a.D = dim; a.ldx = (int)ld_src; a.lda = (int)ld_dst; a.ldy = dim; a.num_out_rows = num_out_rows;
     a.G = std::min(64, std::max(1, tune.groups_per_chunk) * B); a.U = tune.loads_in_flight >= 8 ? 8 : 4; a.S = S; a.B = B;
     a.wide = wide; a.plain_ok = true; a.xcd_remap = tune.xcd_remap != 0; a.eps = 1.f;
+    // prepared graph: the ids from the copy the sliced schedule reads contiguously (round 6: the kernel carries the edges'
+    // original positions beside their place in the copy, because edge_out is indexed like column_index).  There is no prologue
+    // here for the copy's checks to ride in: one wavefront compares the samples first, the full hash runs on its own schedule.
+    if (cnt && plan.handle && (tune.pack_ids == 1 || (tune.pack_ids == 0 && plan.pinned))) {
+        int32_t *stale_flag = flag + kFlagSlots;
+        const unsigned long long *chk = nullptr;
+        int64_t chk_n = 0;
+        rc = get_packed_ids(ds, stream, plan.handle, B, std::max(1, std::min(a.G, kWave)), true, false, &a.ids_packed, &a.item_off,
+                            &chk, &chk_n, stale_flag, a.seq, tune.ids_check_every);
+        if (rc != GNNA_OK) return rc;
+        if (a.ids_packed) {
+            a.packed_stale = stale_flag;
+            rc = launch_ids_sample_check(stream, column_index, chk_n, part_pointers, num_parts, chk, stale_flag, a.seq);
+            if (rc != GNNA_OK) return rc;
+            count_event(CTR_PACKED_LAUNCHES);
+        }
+    }
     return launch_stream(a, stream);
 }
 

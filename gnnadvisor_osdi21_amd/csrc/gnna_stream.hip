@@ -333,7 +333,7 @@ stream_kernel(const StreamParams p)
     int prev_row = -1, next_row = -1;
     if (g0 > 0) prev_row = p.p2n[g0 - 1];
     if (g0 + ng < p.P) next_row = p.p2n[g0 + ng];
-    const bool packed = MODE != MODE_SDDMM && p.ids_packed != nullptr && *p.packed_stale != p.seq;
+    const bool packed = p.ids_packed != nullptr && *p.packed_stale != p.seq;
     const uint32_t item_base = packed ? p.item_off[(size_t)phase * (size_t)p.num_chunks + (size_t)chunk] : 0u;
     const int32_t *__restrict__ ids = packed ? p.ids_packed : p.col;
 
@@ -357,7 +357,9 @@ stream_kernel(const StreamParams p)
     // part of the slice) are merged into one piece, headed by the first: no padding, no bookkeeping between them
     // (packed ids: the item's edges are contiguous in group order, so consecutive non-empty groups always are)
     const int up_end = __shfl_up(pa + end, 1), up_n = __shfl_up(n_own, 1);
-    const bool cont = n_own > 0 && !seg_start && up_n > 0 && (packed || up_end == pa + beg);
+    // (MODE_SDDMM writes edge_out at the edges' ORIGINAL positions: its pieces merge only where those are adjacent too -- which,
+    // with sorted ids, is wherever the aggregation's merge)
+    const bool cont = n_own > 0 && !seg_start && up_n > 0 && ((packed && MODE != MODE_SDDMM) || up_end == pa + beg);
     const unsigned long long NE = __ballot(n_own > 0 && !cont);        // piece heads
     const int n_cum = wave_inclusive_scan(n_own);
     const int own_beg = packed ? (int)item_base + (n_cum - n_own) : pa + beg;    // first edge of this group's part
@@ -382,6 +384,8 @@ stream_kernel(const StreamParams p)
     const int R = __popcll(NE);
     const int dst = (n > 0 ? rank : 63) << 2;       // empty pieces all land on lane 63 (unused unless R == 64, then none is empty)
     const int c_pbeg = __builtin_amdgcn_ds_permute(dst, own_beg);
+    // MODE_SDDMM with packed ids: where the piece's edges sit in column_index / edge_out (own_beg is its place in the copy)
+    const int c_obeg = MODE == MODE_SDDMM ? __builtin_amdgcn_ds_permute(dst, pa + beg) : 0;
     const int t_n = __builtin_amdgcn_ds_permute(dst, n);   // (executed by every lane: the senders are not the receivers)
     const int c_n = lane < R ? t_n : 0;
     const int c_meta = __builtin_amdgcn_ds_permute(dst, (my_row << 2) | (last_in_seg ? 2 : 0) | use_atomic_l);
@@ -441,6 +445,8 @@ stream_kernel(const StreamParams p)
             const bool active = J < L && lane < RL;
             const int i = J - k_offX;
             const int e_j = k_pbeg + i * RPI;
+            int o_j = e_j;                                   // MODE_SDDMM: position of the load's first edge in edge_out
+            if constexpr (MODE == MODE_SDDMM) o_j = __shfl(c_obeg, k) + i * RPI;
             int v_j = active ? k_n - i * RPI : 0;
             const bool fl_j = active && (k_meta & 2) && v_j <= RPI;   // last load of the last piece of its row
             v_j = v_j > RPI ? RPI : v_j;
@@ -583,7 +589,7 @@ stream_kernel(const StreamParams p)
                 for (int q = 0; q < (RL * RPI + kWave - 1) / kWave; q++) {
                     const int f = q * kWave + lane;
                     const int j = f / RPI, sl = f % RPI;
-                    const int ej = __shfl(e_j, j), vj = __shfl(v_j, j);
+                    const int ej = __shfl(o_j, j), vj = __shfl(v_j, j);
                     if (f < RL * RPI && j < nr && sl < vj) {
                         float dot = pend[f];
                         float *dst = p.Y + ej + sl;
@@ -869,6 +875,15 @@ ids_full_hash_kernel(const int32_t *__restrict__ col, int64_t n, const int32_t *
     }
 }
 
+// The packed copy's per-call sample check for a call that has no prologue to ride in (SDDMM): one wavefront.
+__global__ void __launch_bounds__(kWave)
+ids_sample_check_kernel(const int32_t *__restrict__ col, int64_t n, const int32_t *__restrict__ pp, int64_t P,
+                        const unsigned long long *__restrict__ state, int32_t *stale_flag, int32_t seq)
+{
+    const unsigned long long now = graph_checksum(col, n, pp, P, (int)threadIdx.x);
+    if (threadIdx.x == 0 && (now != state[0] || state[4] != 0ull)) *stale_flag = seq;
+}
+
 // ---- plan cache -------------------------------------------------------------------------------------
 struct Plan {
     const void *col = nullptr, *pp = nullptr, *p2n = nullptr;
@@ -1127,10 +1142,14 @@ void drain_dead_buffers()
 
 void drop_slice_plans() { (void)release_slice_plans(nullptr, false); }
 
-// Packed ids of a plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
-// capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
-// plan that already holds kMaxPacked is replaced after a device synchronisation -- at a launch only if it has not been
-// used for a while, in gnna_prepare_graph (force) always).  *ids stays null when there is none.
+int launch_ids_sample_check(hipStream_t stream, const int32_t *col, int64_t n, const int32_t *pp, int64_t P,
+                            const unsigned long long *state, int32_t *stale_flag, int32_t seq)
+{
+    hipLaunchKernelGGL(ids_sample_check_kernel, dim3(1), dim3(kWave), 0, stream, col, n, pp, P, state, stale_flag, seq);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? GNNA_OK : fail(GNNA_ERR_HIP, "packed ids check launch: %s", hipGetErrorString(e));
+}
+
 static void launch_full_hash(DeviceState *ds, hipStream_t stream, const Plan *pl, int64_t nnz, unsigned long long *state, int store,
                              int32_t *stale_flag, int32_t seq)
 {
@@ -1140,6 +1159,10 @@ static void launch_full_hash(DeviceState *ds, hipStream_t stream, const Plan *pl
                        static_cast<const int32_t *>(pl->pp), pl->P, state, store, stale_flag, seq);
 }
 
+// Packed ids of a plan for (B phases, G groups per chunk): looked up, or -- with may_build, outside a stream
+// capture -- built on `stream` (two small kernels + one pass over column_index; the least recently used copy of a
+// plan that already holds kMaxPacked is replaced after a device synchronisation -- at a launch only if it has not been
+// used for a while, in gnna_prepare_graph (force) always).  *ids stays null when there is none.
 int get_packed_ids(DeviceState *ds, hipStream_t stream, void *plan_handle, int B, int G, bool may_build, bool force,
                    const int32_t **ids, const uint32_t **item_off, const unsigned long long **checksum, int64_t *num_ids,
                    int32_t *stale_flag, int32_t seq, int check_every)
@@ -1298,7 +1321,7 @@ int launch_stream(const StreamLaunch &a, hipStream_t stream)
                      : (a.mode == MODE_GCN ? pick_stream_lpr<MODE_GCN>(lpr, a.wide, a.U)
                      : (a.mode == MODE_SDDMM ? pick_stream_lpr<MODE_SDDMM>(lpr, a.wide, a.U) : pick_stream_lpr<MODE_SAG>(lpr, a.wide, a.U)));
     p.det = 0; p.det_part = nullptr; p.det_stamp = nullptr; p.stamp = 0;
-    p.ids_packed = (a.mode == MODE_SDDMM || !a.packed_stale) ? nullptr : a.ids_packed; p.item_off = a.item_off;
+    p.ids_packed = !a.packed_stale ? nullptr : a.ids_packed; p.item_off = a.item_off;
     p.packed_stale = a.packed_stale;
     if (a.det && a.mode != MODE_SDDMM) {
         // deterministic schedule: the phases are separate launches in order, each followed by the ordered sum of

@@ -242,3 +242,64 @@ def test_packed_in_a_captured_graph():
     finally:
         _lib.reset_tuning()
         _lib.release_graph(ci)
+
+
+@pytest.mark.parametrize("dim,partSize,phases", [(64, 64, 0), (64, 128, 16), (32, 32, 8), (41, 64, 4), (16, 16, 8), (100, 64, 4), (128, 32, 0)])
+def test_sddmm_on_a_prepared_graph_reads_the_packed_ids(dim, partSize, phases):
+    """Round 6: SDDMM reads the packed copy of a prepared graph's ids too -- the kernel carries every piece's place in the copy
+    AND its original position, because edge_out is indexed like column_index.  Against the dense formula, every edge; then three
+    ids are rewritten behind the library's back (`.data`): with the full hash at every call the very next result is the edited
+    graph's."""
+    import numpy as np
+    import oracle
+    from util import assert_close_f64
+    g = graph.powerlaw_graph(30000, 3000000, 3000, seed=dim + partSize, device="cuda")
+    n = g.num_nodes
+    ci = g.column_index.clone()
+    pp, p2n = [t.cuda() for t in _lib.build_part(partSize, g.row_pointers.cpu())]
+    gen = torch.Generator(device="cuda").manual_seed(dim)
+    A = torch.randn(n, dim, device="cuda", generator=gen)
+    B = torch.randn(n, dim, device="cuda", generator=gen)
+    rp_h = g.row_pointers.cpu().numpy()
+    rows = np.repeat(np.arange(n), np.diff(rp_h))
+
+    rows_d = torch.from_numpy(rows).cuda()
+
+    def check(what):
+        # the dense formula in fp64 on the device for all 3 M edges (the numpy oracle holds it on a sample: its [E, D] fp64
+        # temporaries are GBs at this size)
+        cl = ci.long()
+        ref = torch.zeros(cl.numel(), dtype=torch.float64, device="cuda")
+        scale = torch.zeros_like(ref)
+        for c0 in range(0, cl.numel(), 1 << 20):
+            a, b = A[rows_d[c0:c0 + (1 << 20)]].double(), B[cl[c0:c0 + (1 << 20)]].double()
+            ref[c0:c0 + (1 << 20)] = (a * b).sum(1)
+            scale[c0:c0 + (1 << 20)] = (a.abs() * b.abs()).sum(1)
+        lo = cl.numel() // 3
+        hi = lo + 20000
+        rp_s = np.clip(rp_h.astype(np.int64), lo, hi) - lo                   # row pointers of the edges [lo, hi) alone
+        ora = oracle.np_sddmm(A.cpu().numpy(), B.cpu().numpy(), rp_s, ci[lo:hi].cpu().numpy())
+        assert np.allclose(ora, ref[lo:hi].cpu().numpy(), rtol=1e-9, atol=1e-9)
+        out = _lib.sddmm(A, B, ci, pp, p2n, partSize)
+        assert_close_f64(out.cpu().numpy(), ref.cpu().numpy(), what=f"{what}: sddmm dim={dim} ps={partSize} phases={phases}",
+                         scale=scale.cpu().numpy(), rtol=1e-5)
+    try:
+        _lib.reset_tuning()
+        _lib.set_tuning(column_phases=phases if phases else -1, ids_check_every=1, nonlocal_ids=1, avg_degree=100)
+        check("unprepared")
+        _lib.prepare_graph(ci, pp, p2n, n, n, partSize, [dim])
+        packed0 = _lib.runtime_counters()["packed_launches"]
+        check("prepared")
+        check("prepared, again")
+        used_packed = _lib.runtime_counters()["packed_launches"] > packed0
+        if phases >= 2:
+            assert used_packed, "a sliced SDDMM on a prepared graph must read the packed copy"
+        for r in (3, 1717, n - 5):
+            b = int(g.row_pointers[r])
+            if int(g.row_pointers[r + 1]) > b:
+                ci.data[b] = (int(ci[b]) + 11) % n
+        check("three ids edited behind the library's back")
+        check("... and the call after")
+    finally:
+        _lib.release_graph(ci)
+        _lib.reset_tuning()
