@@ -359,9 +359,12 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
                 leftovers.insert(leftovers.end(), walk.begin(), walk.end());
                 continue;
             }
+            if (debug && &c == &comps.front()) lap("  second sweep: largest component walked");
             unfold(walk);
+            if (debug && &c == &comps.front()) lap("  second sweep: largest component unfolded");
             for (int32_t v : walk) { pos[(size_t)v] = (double)at++; in_backbone[(size_t)v] = 1; }
         }
+        lap("  second sweep: the other components");
         if (debug) std::fprintf(stderr, "[reorder] %zu leftover nodes of tiny walks\n", leftovers.size());
         // a few rounds: a leftover whose neighbours are leftovers too gets its place once they have theirs
         for (int round = 0; round < 3 && !leftovers.empty(); round++) {
