@@ -243,19 +243,32 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
         // discovery order interleaves the two arms -- the ring comes out folded.  If, a few levels in, the level
         // set falls into two backbone-connected parts of comparable size, the nodes beyond are told apart by
         // which part they descend from and the order becomes: arm B reversed, the core, arm A.
-        std::vector<int32_t> arm((size_t)n, 0), stack;
+        // (round 6: the levels are examined side by side -- each level's connected parts touch only that level's nodes, so the
+        // threads share `arm` -- and the FIRST level that splits decides, as in the one-thread walk through the levels)
+        std::vector<int32_t> arm((size_t)n, 0);
         auto unfold = [&](std::vector<int32_t> &w) {
             if (w.size() < 4096) return;
             const int32_t maxd = depth[(size_t)w.back()];
-            size_t lo = 0;
-            for (int32_t L = 1; L <= std::min(maxd / 2, 16); L++) {
-                while (lo < w.size() && depth[(size_t)w[lo]] < L) lo++;
-                size_t hi = lo;
-                while (hi < w.size() && depth[(size_t)w[hi]] == L) hi++;
-                if (hi - lo < 64) continue;
+            const int Lmax = std::min(maxd / 2, 16);
+            if (Lmax < 1) return;
+            std::vector<size_t> level_at((size_t)Lmax + 2, w.size());          // level L = w[level_at[L] .. level_at[L + 1])
+            {
+                size_t at = 0;
+                for (int L = 1; L <= Lmax + 1; L++) {
+                    while (at < w.size() && depth[(size_t)w[at]] < L) at++;
+                    level_at[(size_t)L] = at;
+                }
+            }
+            struct Verdict { bool split = false; int32_t first = 0, second = 0; };
+            std::vector<Verdict> verdict((size_t)Lmax + 1);
+            parallel_tasks(Lmax, threads, [&](int64_t t) {
+                const int32_t L = (int32_t)t + 1;
+                const size_t lo = level_at[(size_t)L], hi = level_at[(size_t)L + 1];
+                if (hi - lo < 64) return;
                 // connected parts of level L (arm = -1 - part while exploring)
                 for (size_t i = lo; i < hi; i++) arm[(size_t)w[i]] = -1;
                 std::vector<std::pair<int64_t, int32_t>> parts;   // (size, id)
+                std::vector<int32_t> stack;
                 int32_t np = 0;
                 for (size_t i = lo; i < hi; i++) {
                     if (arm[(size_t)w[i]] != -1) continue;
@@ -269,7 +282,7 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
                         sz++;
                         for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
                             const int32_t u = bci[(size_t)k];
-                            if (arm[(size_t)u] == -1 && depth[(size_t)u] == L) { arm[(size_t)u] = id; stack.push_back(u); }
+                            if (depth[(size_t)u] == L && arm[(size_t)u] == -1) { arm[(size_t)u] = id; stack.push_back(u); }   // (depth first: `arm` of another level's node is another thread's)
                         }
                     }
                     parts.emplace_back(sz, id);
@@ -280,14 +293,21 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
                                    5 * (parts[0].first + parts[1].first) >= 4 * (int64_t)(hi - lo);
                 if (!split) {
                     for (size_t i = lo; i < hi; i++) arm[(size_t)w[i]] = 0;
-                    continue;
+                    return;
                 }
+                verdict[(size_t)L].split = true;
+                verdict[(size_t)L].first = parts[0].second;
+                verdict[(size_t)L].second = parts[1].second;
+            });
+            for (int32_t L = 1; L <= Lmax; L++) {
+                if (!verdict[(size_t)L].split) continue;
+                const size_t lo = level_at[(size_t)L], hi = level_at[(size_t)L + 1];
                 // arms: 1 = descends from the largest part, 2 = from the second; earlier levels are the core (0)
                 for (size_t i = 0; i < lo; i++) arm[(size_t)w[i]] = 0;
                 for (size_t i = lo; i < w.size(); i++) {
                     const int32_t v = w[i];
                     int32_t a = 0;
-                    if (i < hi) a = arm[(size_t)v] == parts[0].second ? 1 : (arm[(size_t)v] == parts[1].second ? 2 : 0);
+                    if (i < hi) a = arm[(size_t)v] == verdict[(size_t)L].first ? 1 : (arm[(size_t)v] == verdict[(size_t)L].second ? 2 : 0);
                     if (a == 0) {
                         int64_t c1 = 0, c2 = 0;
                         for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
