@@ -694,6 +694,9 @@ def test_ids_edited_behind_torchs_back_are_noticed(monkeypatch):
 def test_forgetting_plans_keeps_the_callers_hints():
     """when the module takes back what it pinned (eviction, a new graph at an old address) the hints and measured
     schedules the CALLER registered for a graph that is still alive stay (gnna_forget_plans); gnna_forget_graph drops both."""
+    import os
+    if os.environ.get("GNNA_TUNE"):
+        pytest.skip("a process-wide phase count outranks the per-graph measured schedule this test reads back")
     g = graph.powerlaw_graph(30000, 4000000, 3000, seed=71, device="cuda")
     ps, D = 64, 64
     pp, p2n = [t.cuda() for t in _lib.build_part(ps, g.row_pointers.cpu())]
