@@ -208,105 +208,35 @@ int community_order(const int64_t n, const std::vector<int64_t> &rp, const IdLis
         // neighbourhood starts the walk): the front advances through a neighbourhood only when it is adjacent to
         // it in many places, so the odd long-range edge that survived step 1 does not open a second front far away.
         const int theta = avg_deg < 32 ? 1 : 3;
-        // walk tag and hit counter of a node share one 64-bit word ((tag + 1) << 32 | count; a 32-bit pack overflowed from 32768
-        // walks on): a count is this walk's only while the tag matches, and the word can be advanced with one compare-and-swap
-        std::vector<uint64_t> hitw((size_t)n, 0);
+        // walk tag and hit counter of a node are separate words: packed into one int32 (tag * 65536 + count) the tag
+        // overflowed from 32768 walks on -- common once unsupported edges and hubs are dropped on a large graph
+        std::vector<int32_t> hit_tag((size_t)n, -1), hits((size_t)n, 0);
         std::vector<int32_t> depth((size_t)n, 0);
-        std::vector<uint32_t> walked_at((size_t)n, 0);      // when a node joined a walk (one clock over all walks)
-        uint32_t walk_clock = 0;
-        auto push = [&](std::vector<int32_t> &out, int32_t u, int32_t tag, int32_t d) {
-            comp[(size_t)u] = tag; depth[(size_t)u] = d; walked_at[(size_t)u] = walk_clock++; out.push_back(u);
-        };
         // `only`: the walk may take nodes whose component tag is `only` and nothing else -- -1 (unassigned) in the first
         // sweep, the component's own first-sweep tag in the second.  (Without the restriction a walk re-absorbed the
         // nodes of components walked before it: with thousands of small components next to a giant one -- a graph of
         // average degree ~50 -- the second sweep walked the giant component once per component, 65 s for 1e5 nodes.)
-        //
-        // The walk is defined by its one-thread form: nodes are processed in the order they joined, a node joins the moment the
-        // theta-th of its backbone neighbours is processed.  Nodes that joined while one LEVEL (nodes of equal depth: a
-        // contiguous stretch of the walk) was processed form the next level, so a level with enough edges is processed by all
-        // threads (round 6) and gives the same walk: (A) every thread counts the hits of a share of the level's nodes
-        // (compare-and-swap on the packed counters; WHICH nodes reach theta does not depend on the order), (B) every node that
-        // did looks its neighbours up for the theta-th EARLIEST processed one -- the neighbour whose processing made it join --
-        // and (C) the new level is those nodes ordered by (that neighbour's place in the walk, own id: a node's neighbours are
-        // visited in increasing id).
-        // edges of a level from which the threads are worth starting (GNNA_REORDER_PARALLEL_LEVEL: the tests force small levels through)
-        const int64_t kParallelLevel = std::getenv("GNNA_REORDER_PARALLEL_LEVEL") ? std::atoll(std::getenv("GNNA_REORDER_PARALLEL_LEVEL"))
-                                                                                    : ((int64_t)1 << 20);
         auto bfs = [&](int32_t seed, int32_t tag, int32_t only, std::vector<int32_t> &out) {   // nodes of comp `tag` in discovery order
             out.clear();
-            push(out, seed, tag, 0);
+            out.push_back(seed);
+            comp[(size_t)seed] = tag;
+            depth[(size_t)seed] = 0;
             for (int64_t k = brp[(size_t)seed]; k < brp[(size_t)seed + 1]; k++) {
                 const int32_t u = bci[(size_t)k];
-                if (comp[(size_t)u] == only) push(out, u, tag, 0);
+                if (comp[(size_t)u] == only) { comp[(size_t)u] = tag; depth[(size_t)u] = 0; out.push_back(u); }
             }
-            const uint64_t mine = ((uint64_t)(uint32_t)(tag + 1)) << 32;
-            size_t lo = 0;
-            while (lo < out.size()) {
-                const size_t hi = out.size();                    // the level [lo, hi): everything that joins now is the next one
-                const int32_t d = depth[(size_t)out[lo]];
-                int64_t volume = 0;
-                if (threads > 1 && (int64_t)(hi - lo) * 64 >= std::min<int64_t>(kParallelLevel, 65536))
-                    for (size_t i = lo; i < hi; i++) volume += brp[(size_t)out[i] + 1] - brp[(size_t)out[i]];
-                if (volume < kParallelLevel) {
-                    for (size_t head = lo; head < hi; head++) {
-                        const int32_t v = out[head];
-                        for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
-                            const int32_t u = bci[(size_t)k];
-                            if (comp[(size_t)u] != only) continue;
-                            uint64_t &w = hitw[(size_t)u];
-                            if ((w >> 32 << 32) != mine) w = mine;                     // counter of this walk
-                            if ((int32_t)(++w & 0xffffffffull) >= theta) push(out, u, tag, d + 1);
-                        }
+            for (size_t head = 0; head < out.size(); head++) {
+                const int32_t v = out[head];
+                for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
+                    const int32_t u = bci[(size_t)k];
+                    if (comp[(size_t)u] != only) continue;
+                    if (hit_tag[(size_t)u] != tag) { hit_tag[(size_t)u] = tag; hits[(size_t)u] = 0; }   // counter of this walk
+                    if (++hits[(size_t)u] >= theta) {
+                        comp[(size_t)u] = tag;
+                        depth[(size_t)u] = depth[(size_t)v] + 1;
+                        out.push_back(u);
                     }
-                } else {
-                    // (A) hits of the level, counted by all threads; the thread that brings a node to theta lists it
-                    std::atomic<size_t> next{lo};
-                    std::vector<std::vector<int32_t>> joined((size_t)threads);
-                    std::atomic<int> slot{0};
-                    parallel_nodes((int64_t)(hi - lo), threads, [&](int64_t, int64_t) {
-                        std::vector<int32_t> &found = joined[(size_t)slot.fetch_add(1)];
-                        for (;;) {
-                            const size_t b = next.fetch_add(256), e = std::min(hi, b + 256);
-                            if (b >= hi) break;
-                            for (size_t i = b; i < e; i++) {
-                                const int32_t v = out[i];
-                                for (int64_t k = brp[(size_t)v]; k < brp[(size_t)v + 1]; k++) {
-                                    const int32_t u = bci[(size_t)k];
-                                    if (comp[(size_t)u] != only) continue;
-                                    uint64_t seen = __atomic_load_n(&hitw[(size_t)u], __ATOMIC_RELAXED), want;
-                                    do {
-                                        want = ((seen >> 32 << 32) == mine ? seen : mine) + 1;
-                                    } while (!__atomic_compare_exchange_n(&hitw[(size_t)u], &seen, want, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
-                                    if ((int32_t)(want & 0xffffffffull) == theta) found.push_back(u);
-                                }
-                            }
-                        }
-                    });
-                    std::vector<int32_t> all;
-                    for (auto &f : joined) all.insert(all.end(), f.begin(), f.end());
-                    // (B) the processed neighbour that made each of them join: the theta-th earliest in the walk(s) of this tag
-                    const uint32_t level_end = walk_clock;           // everything that joined before this level was closed
-                    std::vector<uint64_t> key(all.size());
-                    parallel_nodes((int64_t)all.size(), threads, [&](int64_t b, int64_t e) {
-                        for (int64_t i = b; i < e; i++) {
-                            const int32_t u = all[(size_t)i];
-                            uint32_t small[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};   // theta <= 3
-                            for (int64_t k = brp[(size_t)u]; k < brp[(size_t)u + 1]; k++) {
-                                const int32_t v = bci[(size_t)k];
-                                if (comp[(size_t)v] != tag) continue;
-                                uint32_t q = walked_at[(size_t)v];
-                                if (q >= level_end) continue;
-                                for (int j = 0; j < 3; j++) if (q < small[j]) std::swap(q, small[j]);
-                            }
-                            key[(size_t)i] = ((uint64_t)small[theta - 1] << 32) | (uint32_t)u;
-                        }
-                    });
-                    // (C) the next level, in the order the one-thread walk would have met them
-                    std::sort(key.begin(), key.end());
-                    for (uint64_t kk : key) push(out, (int32_t)(kk & 0xffffffffull), tag, d + 1);
                 }
-                lo = hi;
             }
         };
         // A walk that starts inside a ring (or in the middle of a long strip) advances on two fronts, and its

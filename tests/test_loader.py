@@ -353,26 +353,3 @@ def test_node_data_follows_its_node_when_asked():
 def test_loader_refuses_ids_the_int32_csr_cannot_hold():
     with pytest.raises(ValueError, match="num_nodes"):
         custom_dataset.from_edges(np.array([0, 9]), np.array([1, 2]), 5, 4, 2, device="cpu")
-
-
-def test_walks_processed_level_by_level_by_all_threads_are_the_one_thread_walks(monkeypatch):
-    """Round 6: a level of the backbone walk with enough edges is processed by all threads (hits counted with compare-and-swap,
-    the joining order rebuilt from the neighbours' places in the walk).  Forced down to every level
-    (GNNA_REORDER_PARALLEL_LEVEL=1) and switched off (a threshold no level reaches), with 2 and 7 threads, on graphs with
-    theta = 1 and theta = 3, one and many components: the permutation must not move."""
-    cases = []
-    g = graph.community_graph(12000, 900000, 30, seed=5, scramble=True)                      # average degree 75: theta = 3
-    cases.append(g)
-    cases.append(graph.powerlaw_graph(20000, 200000, 300, seed=6, locality=0.8, window=64))   # average degree 10: theta = 1, many components
-    for g in cases:
-        n = g.num_nodes
-        rows = torch.repeat_interleave(torch.arange(n), (g.row_pointers[1:] - g.row_pointers[:-1]).long()).numpy()
-        cols = g.column_index.numpy()
-        monkeypatch.setenv("GNNA_REORDER_PARALLEL_LEVEL", str(1 << 40))
-        monkeypatch.setenv("GNNA_HOST_THREADS", "4")
-        want = _lib.reorder_community(rows, cols, n).numpy()
-        assert sorted(want.tolist()) == list(range(n))
-        for threads in ("2", "7"):
-            monkeypatch.setenv("GNNA_HOST_THREADS", threads)
-            monkeypatch.setenv("GNNA_REORDER_PARALLEL_LEVEL", "1")
-            assert np.array_equal(_lib.reorder_community(rows, cols, n).numpy(), want), threads
