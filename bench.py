@@ -840,6 +840,9 @@ def roofline_record(w, kern_ms, prologue_ms, traffic, floor=None):
                 % (traffic["fetch_calibration"], fabric / t / 1e12, kg, gb / t / 1e12))
     elif traffic:
         rec["traffic_error"] = traffic.get("error", "not measured")
+    # which number a reader should take as "share of the ceiling" (a partly cached matrix under the HBM ceiling reads
+    # > 1 in the frozen gather-model `frac`; there the measured fabric share is the honest figure)
+    rec["fraction_to_read"] = "frac" if ceiling == "l2" else ("frac_hbm_measured" if rec.get("frac_hbm_measured") is not None else "frac (gather model: can exceed 1 under the HBM ceiling)")
     return rec
 
 
