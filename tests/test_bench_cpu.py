@@ -201,3 +201,17 @@ def test_the_n_rank_line_is_short_too():
     assert len(text) < bench.LINE_TARGET
     assert line["config"]["values"]["config5"]["value"] == 1e11 and line["config"]["communicator_ranks_counted"] == 8
     assert "legs" not in line["config"] and "per_leg_kernels" not in line["roofline"] and line["roofline"]["traffic"] is None
+
+
+def test_importing_bench_does_not_touch_the_process_environment():
+    """Round 6: `import bench` used to put OMP_PROC_BIND=close into the environment; in the pytest process (this module imports
+    bench) libgomp then bound the main thread to one core and every native host pass ran its threads there.  The environment of
+    a bench PROCESS is set by bench.main() only."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); before = dict(os.environ); import bench; "
+            "changed = {k for k in set(os.environ) | set(before) if os.environ.get(k) != before.get(k)}; "
+            "assert not changed, changed; bench.process_env(); assert os.environ['OMP_PROC_BIND'] == 'close'; print('ok')" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip().endswith("ok"), res.stderr[-1500:]
