@@ -315,3 +315,46 @@ def test_sweep_in_a_captured_graph_after_prepare():
     finally:
         _lib.reset_tuning()
         _lib.release_graph(ci)
+
+
+def test_two_captured_sweep_graphs_replayed_side_by_side():
+    """the sweep kernel's step counters and lists live in a per-call block of device scratch; captured calls used to
+    take theirs from a ring by sequence number, so two graphs replayed concurrently on different streams could land in one block
+    (a hang or wrong rows).  Since round 6 every captured call keeps a block of its own for good: two graphs, each one sweep
+    aggregation on its own graph, replayed together forty times on two streams, both results right every time."""
+    cases = []
+    _lib.reset_tuning()
+    _lib.set_tuning(sweep=1, column_phases=8, deterministic=0)
+    try:
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for k, s in enumerate(streams):
+            g, X, pp, p2n = make_case(6000, 700000, 64, 32, seed=31 + k, kind="powerlaw")
+            Xd, rp, ci, deg, ppd, p2nd = dev(X, g.row_pointers, g.column_index, g.degrees, pp, p2n)
+            out = torch.empty_like(Xd)
+            with torch.cuda.stream(s):
+                _lib.prepare_graph(ci, ppd, p2nd, g.num_nodes, g.num_nodes, 32, [64])
+                _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4, out=out)      # warm-up (scratch)
+                s.synchronize()
+                before = _lib.runtime_counters()["sweep_launches"]
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=s):
+                    _lib.sag(Xd, rp, ci, deg, ppd, p2nd, 32, 32, 4, out=out)
+                assert _lib.runtime_counters()["sweep_launches"] == before + 1
+            ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())
+            cases.append((gr, out, ref, ci, (Xd, rp, deg, ppd, p2nd)))
+        torch.cuda.synchronize()
+        for rep in range(40):
+            for (gr, out, _, _, _), s in zip(cases, streams):
+                out.fill_(float("nan"))
+            torch.cuda.synchronize()
+            for (gr, _, _, _, _), s in zip(cases, streams):
+                with torch.cuda.stream(s):
+                    gr.replay()
+            torch.cuda.synchronize()
+            if rep % 8 == 0 or rep == 39:
+                for k, (_, out, ref, _, _) in enumerate(cases):
+                    assert_close_f64(out.cpu().numpy(), ref, what=f"graph {k}, concurrent replay {rep}")
+    finally:
+        _lib.reset_tuning()
+        for c in cases:
+            _lib.release_graph(c[3])
