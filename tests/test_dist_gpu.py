@@ -188,3 +188,74 @@ def test_sharded_training_driver_two_ranks(model):
     assert "# weights identical on all ranks: True" in out, out
     loss = float(re.search(r"# final loss: (-?\d+\.\d+|nan|inf)", out).group(1))
     assert loss == loss and abs(loss) < 1e6
+
+
+# ---- round 6: exchange="auto" by measurement, with the real kernels -----------------------------------------------------
+def _timed_worker(rank, world, port, q, backend="gloo"):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    device_index = rank if backend == "nccl" else 0
+    if backend == "nccl":
+        torch.cuda.set_device(device_index)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import oracle
+        from gnnadvisor_osdi21_amd import graph
+        from gnnadvisor_osdi21_amd.dist import balanced_row_splits, shard_csr, timed_aggregator
+        torch.cuda.set_device(device_index)
+        n, e, D, ps = 20000, 600000, 32, 32
+        g = graph.powerlaw_graph(n, e, 1500, seed=9, locality=0.9, window=300)
+        bounds = balanced_row_splits(g.row_pointers, world)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        rp, ci = shard_csr(g.row_pointers, g.column_index, lo, hi)
+        agg = timed_aggregator(rp, ci, bounds, ps, dim=D, reps=3, device="cuda")
+        rec = agg.exchange_timed
+        X = torch.randn(n, D, generator=torch.Generator().manual_seed(10))
+        y = agg.sag(X[lo:hi].contiguous().cuda())
+        ref = oracle.csr_f64(0, X.numpy(), g.row_pointers.numpy(), g.column_index.numpy())[lo:hi]
+        err = np.abs(y.cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref))
+        q.put((rank, bool(err.max() <= 1e-4), agg.exchange, rec))
+    except Exception as exc:
+        import traceback
+        q.put((rank, False, traceback.format_exc(), None))
+        raise exc
+    finally:
+        dist.destroy_process_group()
+
+
+def _timed_once(backend):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timed_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0, res
+    return res
+
+
+def _check_timed(res):
+    assert all(ok for _, ok, _, _ in res), res
+    (_, _, ex0, rec0), (_, _, ex1, rec1) = sorted(res)
+    assert ex0 == ex1 == rec0["chosen"] and rec0 == rec1            # one choice, from the same two numbers, on both ranks
+    assert rec0["allgather_ms"] > 0 and rec0["halo_ms"] > 0
+    assert rec0[rec0["chosen"] + "_ms"] == min(rec0["allgather_ms"], rec0["halo_ms"])
+
+
+def test_exchange_chosen_by_timing_with_the_real_kernels():
+    """dist.timed_aggregator on two ranks sharing the GPU (gloo): both forms are built on the device, each runs three whole steps
+    with the HIP kernels, the faster is kept on both ranks and gives the whole graph's result."""
+    _check_timed(_timed_once("gloo"))
+
+
+def test_exchange_chosen_by_timing_over_rccl_on_two_gpus():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL takes one device per rank)")
+    _check_timed(_timed_once("nccl"))
